@@ -1,0 +1,199 @@
+/*
+ * nanocall_hip.h -- C ABI of the MI355X-native HMM basecalling core for nanocall.
+ *
+ * The reference (mateidavid/nanocall) has no FFI seam: its DP layer is header-only templates
+ * instantiated inside nanocall.cpp.  The seam this library replaces is therefore defined by the
+ * reference's call sites; every entry point below names the reference interface it stands in for
+ * (paths relative to the reference root).  INTEGRATION.md shows the C++ binding a nanocall
+ * maintainer would add (the headers under include/nanocall_amd/ are drop-in mirrors of the reference classes
+ * that forward to these functions).
+ *
+ * Conventions
+ *   - plain C types only; all functions return 0 on success or a negative NCHMM_E_* code;
+ *     nothing throws, nothing calls exit().  nchmm_strerror() describes a code.
+ *   - "host" functions are pure CPU prep the reference also does on the host (they use libm so
+ *     that logs are bit-identical to the reference's); they never touch the GPU.
+ *   - "device" functions need a context; a context is bound to one GPU and is not thread-safe
+ *     (use one context per host thread, as the reference uses one DP object per pfor worker,
+ *     src/nanocall/nanocall.cpp:611-621).
+ *   - S = 4096 states (6-mers, 2 bits per base, first base in the top bits, Kmer.hpp:41-50).
+ *   - There is NO CPU fallback: device entry points fail with NCHMM_E_NO_DEVICE / a HIP error when
+ *     no gfx950 device is usable.
+ */
+#ifndef NANOCALL_HIP_H
+#define NANOCALL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCHMM_N_STATES 4096
+#define NCHMM_KMER_SIZE 6
+#define NCHMM_MAX_ARCS (4096 * 21)
+
+enum {
+    NCHMM_OK = 0,
+    NCHMM_E_INVALID = -1,      /* bad argument (null pointer, slot out of range, ragged offsets) */
+    NCHMM_E_NO_DEVICE = -2,    /* no usable HIP device / device id out of range */
+    NCHMM_E_HIP = -3,          /* a HIP runtime call failed; see nchmm_last_hip_error() */
+    NCHMM_E_TOPOLOGY = -4,     /* transitions are not the stay/step/skip-1 6-mer graph that
+                                  State_Transitions::compute_transitions_fast produces */
+    NCHMM_E_NOMEM = -5,        /* host or device allocation failed */
+    NCHMM_E_NUMERIC = -6       /* a read decoded to -INF/NaN everywhere (the reference reads out of
+                                  bounds there, Viterbi.hpp:125-141); per-read status says which */
+};
+
+typedef struct nchmm_ctx nchmm_ctx;
+
+const char* nchmm_strerror(int code);
+int nchmm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Host prep (no GPU).  Bit-exact with the reference's host code.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Pore_Model::load_from_vector, src/nanocall/Pore_Model.hpp:220-239.
+ * table: S x 4 {level_mean, level_stdv, sd_mean, sd_stdv}.
+ * state: S x 10 {level_mean, level_stdv, sd_mean, sd_stdv, sd_lambda, log_level_mean,
+ *                log_level_stdv, log_sd_mean, log_sd_stdv(=0, unset in the reference), log_sd_lambda}
+ * i.e. the field order of Pore_Model_State (Pore_Model.hpp:85-96). */
+int nchmm_model_load(const float* table_Sx4, float* state_Sx10);
+
+/* Pore_Model::scale, src/nanocall/Pore_Model.hpp:190-201 / Pore_Model_State::scale :126-138.
+ * params: {scale, shift, drift, var, scale_sd, var_sd} (Pore_Model_Parameters, :46-51). In place. */
+int nchmm_model_scale(float* state_Sx10, const float params[6]);
+
+/* Pack the six fields the emission reads (Pore_Model.hpp:145-149) for nchmm_put_model:
+ * S x 6 {level_mean, level_stdv, log_level_stdv, sd_mean, sd_lambda, log_sd_lambda}. */
+int nchmm_model_pack6(const float* state_Sx10, float* table_Sx6);
+
+/* State_Transitions::compute_transitions_fast(p_skip, p_stay), State_Transitions.hpp:181-224, then
+ * update_fields :79-104.  Output is the from_v view as CSR by destination state: row_ptr[S+1],
+ * pred[n_arcs] ascending within a row, logw[n_arcs].  Buffers must hold NCHMM_MAX_ARCS entries. */
+int nchmm_transitions_fast(float p_skip, float p_stay, uint32_t* row_ptr, uint16_t* pred, float* logw,
+                           uint32_t* n_arcs);
+
+/* Event::update_logs (Event.hpp:35-45: stdv == 0 -> 0.01, log_stdv = log(stdv)) followed by
+ * Event_Sequence::apply_drift_correction (Event.hpp:77-84: corrected_mean = mean - drift * start).
+ * stdv is updated in place. */
+int nchmm_events_prepare(size_t n, const float* mean, float* stdv, const float* start, float drift,
+                         float* corrected_mean, float* log_stdv);
+
+/* Viterbi::fill_move_seq (Viterbi.hpp:144-150, Kmer::min_skip Kmer.hpp:51-68) and
+ * Event_Sequence::get_base_seq (Event.hpp:85-99).  seq must hold 6*n + 1 bytes; *seq_len excludes
+ * the terminating NUL.  move may be NULL. */
+int nchmm_base_seq(size_t n, const uint16_t* state, int32_t* move, char* seq, size_t* seq_len);
+
+/* write_fasta, src/nanocall/nanocall.cpp:584-591.  Returns bytes written via *written. */
+int nchmm_write_fasta(const char* name, const char* seq, unsigned line_width, char* out, size_t cap,
+                      size_t* written);
+
+/* Parameter_Trainer::init / st_train_kmers, Parameter_Trainer.hpp:30-63.  out holds <= 4096. */
+int nchmm_st_train_kmers(uint16_t* out, uint32_t* count);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context
+ * ---------------------------------------------------------------------------------------- */
+
+/* device_id: HIP device ordinal.  Creates its own non-blocking stream. */
+int nchmm_create(nchmm_ctx** out, int device_id);
+int nchmm_destroy(nchmm_ctx* ctx);
+int nchmm_last_hip_error(const nchmm_ctx* ctx); /* raw hipError_t of the last failure */
+/* run later launches on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
+ * context's own stream */
+int nchmm_set_stream(nchmm_ctx* ctx, void* hip_stream);
+int nchmm_synchronize(nchmm_ctx* ctx);
+
+/* Register a scaled pore model in `slot` (0 <= slot < 64): what basecall_strand builds with
+ * `Pore_Model_Type pm(models.at(m_name)); pm.scale(pm_params);` (nanocall.cpp:649-650).
+ * table_Sx6 as produced by nchmm_model_pack6. */
+int nchmm_put_model(nchmm_ctx* ctx, int slot, const float* table_Sx6);
+
+/* Register transitions in `slot` (0 <= slot < 64): the `*transitions_ptr` of basecall_strand
+ * (nanocall.cpp:651-661).  CSR by destination state, predecessors ascending (from_v order,
+ * State_Transitions.hpp:85-94).  Fails with NCHMM_E_TOPOLOGY unless the graph is exactly the
+ * stay/step/skip-1 graph of compute_transitions_fast and its weights factor per DESIGN.md
+ * section "Transition factorisation" (always true for compute_transitions_fast output). */
+int nchmm_put_transitions(nchmm_ctx* ctx, int slot, const uint32_t* row_ptr_S1, const uint16_t* pred,
+                          const float* logw);
+
+/* ------------------------------------------------------------------------------------------
+ * Viterbi  -- replaces `Viterbi_Type vit; vit.fill(pm, *transitions_ptr, corrected_events);
+ *             vit.path_probability()`  (src/nanocall/nanocall.cpp:687-689, Viterbi.hpp:44-99,
+ *             fill_state_seq :120-142), batched over reads.
+ *
+ * Events are SoA: corrected_mean, stdv, log_stdv (the three fields log_pr_corrected_emission
+ * reads, Pore_Model.hpp:145-149).  Read r owns events [off[r], off[r+1]).  model_slot/trans_slot
+ * give the per-read slots (NULL = slot 0 for every read).
+ * Outputs: out_state[e] = Event::model_state_idx of event e (Viterbi.hpp:136); out_path_logp[r] =
+ * path_probability(); out_status[r] = 0 or NCHMM_E_NUMERIC (may be NULL).
+ * Reads with zero events get out_path_logp = NaN and status 0.
+ * ---------------------------------------------------------------------------------------- */
+
+/* host-pointer form: copies in, runs, copies out, synchronises. */
+int nchmm_viterbi(nchmm_ctx* ctx, size_t n_reads, const uint64_t* off, const float* corrected_mean,
+                  const float* stdv, const float* log_stdv, const int32_t* model_slot,
+                  const int32_t* trans_slot, uint16_t* out_state, float* out_path_logp,
+                  int32_t* out_status);
+
+/* device-pointer form: every pointer is device memory on the context's GPU; enqueues on the
+ * context's stream and returns without synchronising.  max_events = max_r (off[r+1]-off[r]) and
+ * total_events = off[n_reads] must be supplied by the caller (they size the workspace; the offsets
+ * themselves stay on the device).  order (may be NULL) is a permutation of reads giving the
+ * processing order (longest first balances the work queue). */
+int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t total_events,
+                      const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
+                      const float* d_log_stdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
+                      const uint32_t* d_order, uint16_t* d_out_state, float* d_out_path_logp,
+                      int32_t* d_out_status);
+
+/* ------------------------------------------------------------------------------------------
+ * Forward-backward + EM sufficient statistics -- replaces Forward_Backward::fill
+ * (Forward_Backward.hpp:46-135) as called from Parameter_Trainer::fill_train_data
+ * (Parameter_Trainer.hpp:141-155), fused with the per-event inner sums of train_pm_params
+ * (:273-296) and the log-sums of train_st_params (:451-515).
+ *
+ * Windows are SoA like Viterbi reads.  For window w:
+ *   out_log_pr_data[w]            = Forward_Backward::log_pr_data()
+ *   out_pm_sums[e*6 .. e*6+5]     = {s0,s1,s2,l0,l1,l2} of event e (Parameter_Trainer.hpp:273-296),
+ *                                   taken over the UNSCALED model in unscaled_slot[w]
+ *   out_st_sums[w*3 .. w*3+2]     = {denom, stay_num, skip_num} log-sums of train_st_params over the
+ *                                   events of this window (log_p_stay / log_p_step_4 from st_params)
+ *   out_alpha / out_beta          = optional full matrices (n x S, log space), NULL to skip
+ * The host finishes the round (3x3 solve etc.) -- see nanocall_amd/Parameter_Trainer.hpp.
+ * ---------------------------------------------------------------------------------------- */
+int nchmm_fwbw(nchmm_ctx* ctx, size_t n_win, const uint64_t* off, const float* corrected_mean,
+               const float* stdv, const float* log_stdv, const int32_t* scaled_slot,
+               const int32_t* unscaled_slot, const int32_t* trans_slot,
+               const float* st_params /* n_win x 2 {p_stay, p_skip} or NULL */,
+               float* out_log_pr_data, float* out_pm_sums, float* out_st_sums,
+               float* out_alpha, float* out_beta);
+
+int nchmm_fwbw_dev(nchmm_ctx* ctx, size_t n_win, size_t max_events, size_t total_events,
+                   const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
+                   const float* d_log_stdv, const int32_t* d_scaled_slot, const int32_t* d_unscaled_slot,
+                   const int32_t* d_trans_slot, const float* d_st_params,
+                   float* d_out_log_pr_data, float* d_out_pm_sums, float* d_out_st_sums,
+                   float* d_out_alpha, float* d_out_beta);
+
+/* ------------------------------------------------------------------------------------------
+ * Counters (what the 8-GPU run gathers with one RCCL all-reduce)
+ * out[0]=reads decoded, [1]=events decoded, [2]=back-pointer bytes written, [3]=kernel launches,
+ * [4]=windows (FB), [5]=FB event-rounds, [6]=device bytes allocated, [7]=reserved
+ * ---------------------------------------------------------------------------------------- */
+int nchmm_counters(const nchmm_ctx* ctx, uint64_t out[8]);
+
+/* Time (ms, hipEvent) of the most recent Viterbi / FB kernel launched through this context,
+ * measured on the stream it ran on.  Blocks until that kernel has finished. */
+int nchmm_last_kernel_ms(nchmm_ctx* ctx, float* viterbi_ms, float* fwbw_ms);
+
+/* number of resident thread-block slots (persistent grid size) the Viterbi kernel launches */
+int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

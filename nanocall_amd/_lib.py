@@ -1,0 +1,76 @@
+"""ctypes loader for libnanocall_hip.so (the C-ABI in include/nanocall_hip.h).
+
+The library is the product; this module is only a binding.  There is no fallback: if the shared
+object is missing, importing any device entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnanocall_hip.so")
+
+_lib = None
+
+c_f32p = C.POINTER(C.c_float)
+c_u64p = C.POINTER(C.c_uint64)
+c_u32p = C.POINTER(C.c_uint32)
+c_u16p = C.POINTER(C.c_uint16)
+c_i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/nanocall_hip.h one to one
+SIGNATURES = {
+    "nchmm_strerror": (C.c_char_p, [C.c_int]),
+    "nchmm_abi_version": (C.c_int, []),
+    "nchmm_model_load": (C.c_int, [vp, vp]),
+    "nchmm_model_scale": (C.c_int, [vp, vp]),
+    "nchmm_model_pack6": (C.c_int, [vp, vp]),
+    "nchmm_transitions_fast": (C.c_int, [C.c_float, C.c_float, vp, vp, vp, vp]),
+    "nchmm_events_prepare": (C.c_int, [C.c_size_t, vp, vp, vp, C.c_float, vp, vp]),
+    "nchmm_base_seq": (C.c_int, [C.c_size_t, vp, vp, vp, vp]),
+    "nchmm_write_fasta": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint, vp, C.c_size_t, vp]),
+    "nchmm_st_train_kmers": (C.c_int, [vp, vp]),
+    "nchmm_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "nchmm_destroy": (C.c_int, [vp]),
+    "nchmm_last_hip_error": (C.c_int, [vp]),
+    "nchmm_set_stream": (C.c_int, [vp, vp]),
+    "nchmm_synchronize": (C.c_int, [vp]),
+    "nchmm_put_model": (C.c_int, [vp, C.c_int, vp]),
+    "nchmm_put_transitions": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "nchmm_viterbi": (C.c_int, [vp, C.c_size_t] + [vp] * 9),
+    "nchmm_viterbi_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
+    "nchmm_fwbw": (C.c_int, [vp, C.c_size_t] + [vp] * 13),
+    "nchmm_fwbw_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 13),
+    "nchmm_counters": (C.c_int, [vp, vp]),
+    "nchmm_last_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "nchmm_grid_slots": (C.c_int, [vp, vp]),
+}
+
+
+class NchmmError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().nchmm_strerror(code).decode()
+        super().__init__(f"{where}: {msg} (code {code})")
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C nanocall_amd/csrc). nanocall_amd has no CPU/PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the ABI and this table ever diverge
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, where):
+    if code != 0:
+        raise NchmmError(code, where)

@@ -1,0 +1,230 @@
+"""numpy / torch level wrappers over the C ABI (include/nanocall_hip.h).
+
+Host-prep wrappers take and return numpy arrays.  `Context` owns an nchmm_ctx; its `viterbi` /
+`fwbw` methods take host (numpy) buffers, its `*_dev` methods take torch CUDA tensors that are
+already resident in HBM (what bench.py times).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, check, NchmmError  # noqa: F401
+
+S = 4096
+MAX_ARCS = S * 21
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# host prep
+# ------------------------------------------------------------------------------------------------
+def model_load(table_Sx4):
+    """Pore_Model::load_from_vector -> S x 10 state array (field order of Pore_Model_State)."""
+    t = _f32(table_Sx4).reshape(S, 4)
+    st = np.empty((S, 10), np.float32)
+    check(lib().nchmm_model_load(_p(t), _p(st)), "nchmm_model_load")
+    return st
+
+
+def model_scale(state_Sx10, params):
+    """Pore_Model::scale; params = (scale, shift, drift, var, scale_sd, var_sd). Returns a new array."""
+    st = _f32(state_Sx10).reshape(S, 10).copy()
+    p = _f32(params).reshape(6)
+    check(lib().nchmm_model_scale(_p(st), _p(p)), "nchmm_model_scale")
+    return st
+
+
+def model_pack6(state_Sx10):
+    st = _f32(state_Sx10).reshape(S, 10)
+    t6 = np.empty((S, 6), np.float32)
+    check(lib().nchmm_model_pack6(_p(st), _p(t6)), "nchmm_model_pack6")
+    return t6
+
+
+def scaled_model_table(table_Sx4, params=(1.0, 0.0, 0.0, 1.0, 1.0, 1.0)):
+    """load_from_vector + scale + pack6: the S x 6 table nchmm_put_model takes."""
+    return model_pack6(model_scale(model_load(table_Sx4), params))
+
+
+def transitions_fast(p_skip, p_stay):
+    """State_Transitions::compute_transitions_fast -> (row_ptr[S+1] u32, pred[n] u16, logw[n] f32)."""
+    rp = np.empty(S + 1, np.uint32)
+    pred = np.empty(MAX_ARCS, np.uint16)
+    w = np.empty(MAX_ARCS, np.float32)
+    n = C.c_uint32(0)
+    check(lib().nchmm_transitions_fast(C.c_float(p_skip), C.c_float(p_stay), _p(rp), _p(pred), _p(w), C.byref(n)),
+          "nchmm_transitions_fast")
+    return rp, pred[: n.value].copy(), w[: n.value].copy()
+
+
+def events_prepare(mean, stdv, start=None, drift=0.0):
+    """Event::update_logs + apply_drift_correction -> (corrected_mean, stdv, log_stdv)."""
+    mean = _f32(mean)
+    stdv = _f32(stdv).copy()
+    start = None if start is None else _f32(start)
+    n = mean.shape[0]
+    cm = np.empty(n, np.float32)
+    ls = np.empty(n, np.float32)
+    check(lib().nchmm_events_prepare(n, _p(mean), _p(stdv), _p(start), C.c_float(drift), _p(cm), _p(ls)),
+          "nchmm_events_prepare")
+    return cm, stdv, ls
+
+
+def base_seq(states):
+    """fill_move_seq + get_base_seq -> (moves int32[n], sequence str)."""
+    st = np.ascontiguousarray(states, dtype=np.uint16)
+    n = st.shape[0]
+    mv = np.empty(n, np.int32)
+    buf = C.create_string_buffer(6 * max(n, 1) + 1)
+    ln = C.c_size_t(0)
+    check(lib().nchmm_base_seq(n, _p(st), _p(mv), buf, C.byref(ln)), "nchmm_base_seq")
+    return mv, buf.raw[: ln.value].decode()
+
+
+def write_fasta(name, seq, line_width=80):
+    cap = len(name) + len(seq) + len(seq) // max(line_width, 1) + 16
+    buf = C.create_string_buffer(cap)
+    wr = C.c_size_t(0)
+    check(lib().nchmm_write_fasta(name.encode(), seq.encode(), line_width, buf, cap, C.byref(wr)), "nchmm_write_fasta")
+    return buf.raw[: wr.value].decode()
+
+
+def st_train_kmers():
+    out = np.empty(S, np.uint16)
+    n = C.c_uint32(0)
+    check(lib().nchmm_st_train_kmers(_p(out), C.byref(n)), "nchmm_st_train_kmers")
+    return out[: n.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# device context
+# ------------------------------------------------------------------------------------------------
+def _dp(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """Owns one nchmm_ctx (one GPU).  Raises NchmmError when there is no usable device."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().nchmm_create(C.byref(self._h), int(device)), "nchmm_create")
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().nchmm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- tables --
+    def put_model(self, slot, table_Sx6):
+        t = _f32(table_Sx6).reshape(S, 6)
+        check(lib().nchmm_put_model(self._h, slot, _p(t)), "nchmm_put_model")
+
+    def put_transitions(self, slot, row_ptr, pred, logw):
+        rp = np.ascontiguousarray(row_ptr, np.uint32)
+        pr = np.ascontiguousarray(pred, np.uint16)
+        w = _f32(logw)
+        check(lib().nchmm_put_transitions(self._h, slot, _p(rp), _p(pr), _p(w)), "nchmm_put_transitions")
+
+    def set_stream(self, hip_stream_ptr):
+        check(lib().nchmm_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)), "nchmm_set_stream")
+
+    def synchronize(self):
+        check(lib().nchmm_synchronize(self._h), "nchmm_synchronize")
+
+    # -- Viterbi --
+    def viterbi(self, off, cmean, stdv, log_stdv, model_slot=None, trans_slot=None, raise_on_numeric=True):
+        """Host-buffer batch Viterbi.  Returns (states u16[total], path_logp f32[n_reads], status i32[n_reads])."""
+        off = np.ascontiguousarray(off, np.uint64)
+        n = off.shape[0] - 1
+        total = int(off[-1]) if n > 0 else 0
+        cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
+        assert cm.shape[0] >= total and sd.shape[0] >= total and ls.shape[0] >= total
+        ms = None if model_slot is None else np.ascontiguousarray(model_slot, np.int32)
+        ts = None if trans_slot is None else np.ascontiguousarray(trans_slot, np.int32)
+        states = np.empty(total, np.uint16)
+        logp = np.empty(max(n, 0), np.float32)
+        status = np.zeros(max(n, 0), np.int32)
+        rc = lib().nchmm_viterbi(self._h, n, _p(off), _p(cm), _p(sd), _p(ls), _p(ms), _p(ts),
+                                 _p(states), _p(logp), _p(status))
+        if rc != 0 and not (rc == -6 and not raise_on_numeric):
+            check(rc, "nchmm_viterbi")
+        return states, logp, status
+
+    def viterbi_dev(self, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_out_state,
+                    d_out_logp, d_out_status=None, d_model_slot=None, d_trans_slot=None, d_order=None):
+        """Device-resident batch Viterbi on torch CUDA tensors; asynchronous on the context's stream."""
+        check(lib().nchmm_viterbi_dev(self._h, n_reads, max_events, total_events, _dp(d_off), _dp(d_cmean),
+                                      _dp(d_stdv), _dp(d_lstdv), _dp(d_model_slot), _dp(d_trans_slot),
+                                      _dp(d_order), _dp(d_out_state), _dp(d_out_logp), _dp(d_out_status)),
+              "nchmm_viterbi_dev")
+
+    # -- forward-backward --
+    def fwbw(self, off, cmean, stdv, log_stdv, scaled_slot=None, unscaled_slot=None, trans_slot=None,
+             st_params=None, want_matrices=False):
+        """Host-buffer batch forward-backward + EM sums.
+        Returns dict(log_pr_data[n_win], pm_sums[total,6], st_sums[n_win,3], alpha, beta)."""
+        off = np.ascontiguousarray(off, np.uint64)
+        n = off.shape[0] - 1
+        total = int(off[-1]) if n > 0 else 0
+        cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
+        ss = None if scaled_slot is None else np.ascontiguousarray(scaled_slot, np.int32)
+        us = None if unscaled_slot is None else np.ascontiguousarray(unscaled_slot, np.int32)
+        ts = None if trans_slot is None else np.ascontiguousarray(trans_slot, np.int32)
+        sp = None if st_params is None else _f32(st_params).reshape(n, 2)
+        lpd = np.empty(n, np.float32)
+        pm = np.empty((total, 6), np.float32)
+        stt = np.empty((n, 3), np.float32)
+        al = np.empty((total, S), np.float32) if want_matrices else None
+        be = np.empty((total, S), np.float32) if want_matrices else None
+        check(lib().nchmm_fwbw(self._h, n, _p(off), _p(cm), _p(sd), _p(ls), _p(ss), _p(us), _p(ts), _p(sp),
+                               _p(lpd), _p(pm), _p(stt), _p(al), _p(be)), "nchmm_fwbw")
+        return dict(log_pr_data=lpd, pm_sums=pm, st_sums=stt, alpha=al, beta=be)
+
+    def fwbw_dev(self, n_win, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_out_lpd, d_out_pm,
+                 d_out_st, d_scaled_slot=None, d_unscaled_slot=None, d_trans_slot=None, d_st_params=None,
+                 d_out_alpha=None, d_out_beta=None):
+        check(lib().nchmm_fwbw_dev(self._h, n_win, max_events, total_events, _dp(d_off), _dp(d_cmean), _dp(d_stdv),
+                                   _dp(d_lstdv), _dp(d_scaled_slot), _dp(d_unscaled_slot), _dp(d_trans_slot),
+                                   _dp(d_st_params), _dp(d_out_lpd), _dp(d_out_pm), _dp(d_out_st),
+                                   _dp(d_out_alpha), _dp(d_out_beta)), "nchmm_fwbw_dev")
+
+    # -- introspection --
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        check(lib().nchmm_counters(self._h, _p(out)), "nchmm_counters")
+        return out
+
+    def last_kernel_ms(self):
+        v, f = C.c_float(0), C.c_float(0)
+        check(lib().nchmm_last_kernel_ms(self._h, C.byref(v), C.byref(f)), "nchmm_last_kernel_ms")
+        return v.value, f.value
+
+    def grid_slots(self):
+        v = C.c_int(0)
+        check(lib().nchmm_grid_slots(self._h, C.byref(v)), "nchmm_grid_slots")
+        return v.value

@@ -1,0 +1,397 @@
+// nchmm_api.cpp -- C-ABI device layer: context, model/transition upload, batched launches.
+// Compiled with hipcc; see include/nanocall_hip.h for the contract of every entry point.
+#include "nanocall_hip.h"
+#include "nchmm_device.h"
+#include "nchmm_kmer.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+using namespace nchmm;
+
+struct nchmm_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    int n_cu = 0;
+    int vit_slots = 0;
+    int fb_slots = 0;
+    float* d_models = nullptr;      // [kMaxSlots][kModelFloats]
+    float* d_trans = nullptr;       // [kMaxSlots][kTransFloats]   log-space w0|w1|w2
+    float* d_trans_lin = nullptr;   // [kMaxSlots][kTransFloats]   exp() of the above (host libm), FB only
+    unsigned* d_queue = nullptr;    // [2] work-queue heads (viterbi, fwbw)
+    uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace
+    size_t ws_bytes = 0;
+    float* d_fb_ws = nullptr;       // FB alpha workspace
+    size_t fb_ws_floats = 0;
+    // staging buffers of the host-pointer entry points
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
+    bool vit_timed = false, fb_timed = false;
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool model_set[kMaxSlots] = {false};
+    bool trans_set[kMaxSlots] = {false};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                  \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            (ctx)->last_hip = (int)e_;                      \
+            return e_ == hipErrorOutOfMemory ? NCHMM_E_NOMEM : NCHMM_E_HIP; \
+        }                                                   \
+    } while (0)
+
+int dev_alloc(nchmm_ctx* c, void** p, size_t bytes)
+{
+    HIP_TRY(c, hipMalloc(p, bytes));
+    c->counters[6] += bytes;
+    return NCHMM_OK;
+}
+
+int ensure(nchmm_ctx* c, void** p, size_t* have, size_t need)
+{
+    if (*have >= need) return NCHMM_OK;
+    if (*p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(*p));
+        c->counters[6] -= *have;
+        *p = nullptr; *have = 0;
+    }
+    need = need + need / 8;  // head-room so slowly growing batches do not reallocate every call
+    int rc = dev_alloc(c, p, need);
+    if (rc != NCHMM_OK) return rc;
+    *have = need;
+    return NCHMM_OK;
+}
+
+// Split the from_v CSR of compute_transitions_fast into w0[j] (stay), w1[r] (step group r = low 10
+// bits of the predecessor) and w2[q] (skip group q = low 8 bits of the predecessor).
+//
+// Why this is exact: get_trans_prob (State_Transitions.hpp:125-144) is a function of the overlap
+// mask m(p,j) = [p==j] | sum_l [suffix(p,6-l)==prefix(j,6-l)] << l.  For a skip arc bits 3..5 of m
+// depend only on q, for a step arc bits 2..5 depend only on r; bit 0 (p==j) and bit 1 (p is also a
+// step predecessor) are the only per-arc extras, and an arc that has them is ALSO a member of the
+// more specific class (stay, or step) where it carries its full weight.  In the looser class it is
+// evaluated with a weight that is <= its true weight, so it can never win there with a larger
+// value, and on an exact tie it names the same predecessor index.  We verify all of this on the
+// actual numbers instead of trusting the algebra; anything else is NCHMM_E_TOPOLOGY.
+int factor_transitions(const uint32_t* row_ptr, const uint16_t* pred, const float* logw, float* out)
+{
+    float* w0 = out; float* w1 = out + kStates; float* w2 = out + kStates + 1024;
+    std::vector<char> have1(1024, 0), have2(256, 0);
+    if (row_ptr[0] != 0) return NCHMM_E_TOPOLOGY;
+    for (unsigned j = 0; j < (unsigned)kStates; ++j) {
+        unsigned cand[21], m = 0;
+        cand[m++] = j;
+        for (unsigned x = 0; x < 4; ++x) cand[m++] = Kmer6::step_pred(j, x);
+        for (unsigned xy = 0; xy < 16; ++xy) cand[m++] = Kmer6::skip_pred(j, xy);
+        std::sort(cand, cand + m);
+        m = (unsigned)(std::unique(cand, cand + m) - cand);
+        const uint32_t b = row_ptr[j], e = row_ptr[j + 1];
+        if (e < b || e - b != m || e > (uint32_t)NCHMM_MAX_ARCS) return NCHMM_E_TOPOLOGY;
+        for (unsigned k = 0; k < m; ++k) {
+            if (pred[b + k] != cand[k]) return NCHMM_E_TOPOLOGY;
+            const unsigned p = cand[k];
+            const float w = logw[b + k];
+            if (std::isnan(w)) return NCHMM_E_TOPOLOGY;
+            const bool is_stay = p == j;
+            const bool is_step = (p & 1023u) == (j >> 2);
+            if (is_stay) { w0[j] = w; continue; }
+            if (is_step) {
+                const unsigned r = p & 1023u;
+                if (!have1[r]) { w1[r] = w; have1[r] = 1; }
+                else if (std::memcmp(&w1[r], &w, 4) != 0) return NCHMM_E_TOPOLOGY;
+                continue;
+            }
+            const unsigned q = p & 255u;
+            if (!have2[q]) { w2[q] = w; have2[q] = 1; }
+            else if (std::memcmp(&w2[q], &w, 4) != 0) return NCHMM_E_TOPOLOGY;
+        }
+    }
+    for (unsigned r = 0; r < 1024; ++r) if (!have1[r]) return NCHMM_E_TOPOLOGY;
+    for (unsigned q = 0; q < 256; ++q) if (!have2[q]) return NCHMM_E_TOPOLOGY;
+    // arcs evaluated in a looser class must not be over-weighted there
+    for (unsigned j = 0; j < (unsigned)kStates; ++j) {
+        const uint32_t b = row_ptr[j], e = row_ptr[j + 1];
+        for (uint32_t a = b; a < e; ++a) {
+            const unsigned p = pred[a];
+            const float w = logw[a];
+            const bool is_stay = p == j;
+            const bool in_step = (p & 1023u) == (j >> 2);
+            const bool in_skip = (p & 255u) == (j >> 4);
+            if (is_stay && in_step && !(w1[p & 1023u] <= w)) return NCHMM_E_TOPOLOGY;
+            if ((is_stay || in_step) && in_skip && !(w2[p & 255u] <= w)) return NCHMM_E_TOPOLOGY;
+        }
+    }
+    return NCHMM_OK;
+}
+
+int check_offsets(size_t n, const uint64_t* off, size_t* max_events, size_t* total)
+{
+    size_t mx = 0;
+    if (n && !off) return NCHMM_E_INVALID;
+    for (size_t r = 0; r < n; ++r) {
+        if (off[r + 1] < off[r]) return NCHMM_E_INVALID;
+        mx = std::max<size_t>(mx, off[r + 1] - off[r]);
+    }
+    *max_events = mx;
+    *total = n ? (size_t)(off[n] - off[0]) : 0;
+    if (n && off[0] != 0) return NCHMM_E_INVALID;
+    return NCHMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nchmm_create(nchmm_ctx** out, int device_id)
+{
+    if (!out) return NCHMM_E_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return NCHMM_E_NO_DEVICE;
+    if (device_id < 0 || device_id >= n_dev) return NCHMM_E_NO_DEVICE;
+    nchmm_ctx* c = new (std::nothrow) nchmm_ctx();
+    if (!c) return NCHMM_E_NOMEM;
+    c->device = device_id;
+    int rc = NCHMM_OK;
+    auto fail = [&](int code) { nchmm_destroy(c); return code; };
+    if (hipSetDevice(device_id) != hipSuccess) return fail(NCHMM_E_NO_DEVICE);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(NCHMM_E_NO_DEVICE);
+    c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NCHMM_E_HIP);
+    c->stream = c->own_stream;
+    if ((rc = dev_alloc(c, (void**)&c->d_models, sizeof(float) * kMaxSlots * kModelFloats))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_trans, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_trans_lin, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * 4))) return fail(rc);
+    if (hipEventCreate(&c->ev_vit0) != hipSuccess || hipEventCreate(&c->ev_vit1) != hipSuccess
+        || hipEventCreate(&c->ev_fb0) != hipSuccess || hipEventCreate(&c->ev_fb1) != hipSuccess)
+        return fail(NCHMM_E_HIP);
+    c->vit_slots = c->n_cu * viterbi_blocks_per_cu();
+    c->fb_slots = c->n_cu * fwbw_blocks_per_cu();
+    *out = c;
+    return NCHMM_OK;
+}
+
+int nchmm_destroy(nchmm_ctx* c)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_models) (void)hipFree(c->d_models);
+    if (c->d_trans) (void)hipFree(c->d_trans);
+    if (c->d_trans_lin) (void)hipFree(c->d_trans_lin);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->ev_vit0) (void)hipEventDestroy(c->ev_vit0);
+    if (c->ev_vit1) (void)hipEventDestroy(c->ev_vit1);
+    if (c->ev_fb0) (void)hipEventDestroy(c->ev_fb0);
+    if (c->ev_fb1) (void)hipEventDestroy(c->ev_fb1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return NCHMM_OK;
+}
+
+int nchmm_last_hip_error(const nchmm_ctx* c) { return c ? c->last_hip : 0; }
+
+int nchmm_set_stream(nchmm_ctx* c, void* s)
+{
+    if (!c) return NCHMM_E_INVALID;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return NCHMM_OK;
+}
+
+int nchmm_synchronize(nchmm_ctx* c)
+{
+    if (!c) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NCHMM_OK;
+}
+
+int nchmm_put_model(nchmm_ctx* c, int slot, const float* t6)
+{
+    if (!c || !t6 || slot < 0 || slot >= kMaxSlots) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float log_2pi = static_cast<float>(std::log(2.0 * M_PI));  // Pore_Model.hpp:28,37
+    std::vector<float> img(kModelFloats);
+    for (int j = 0; j < kStates; ++j) {
+        const float* s = t6 + (size_t)j * 6;
+        img[MF_MU * kStates + j] = s[0];
+        img[MF_SIGMA * kStates + j] = s[1];
+        img[MF_LOG_SIGMA * kStates + j] = s[2];
+        img[MF_ETA * kStates + j] = s[3];
+        img[MF_LAMBDA * kStates + j] = s[4];
+        img[MF_C * kStates + j] = s[5] - log_2pi;  // first subtraction of log_invgauss_pdf, Pore_Model.hpp:39
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // a running kernel may still read this slot
+    HIP_TRY(c, hipMemcpy(c->d_models + (size_t)slot * kModelFloats, img.data(), sizeof(float) * kModelFloats,
+                         hipMemcpyHostToDevice));
+    c->model_set[slot] = true;
+    return NCHMM_OK;
+}
+
+int nchmm_put_transitions(nchmm_ctx* c, int slot, const uint32_t* row_ptr, const uint16_t* pred, const float* logw)
+{
+    if (!c || !row_ptr || !pred || !logw || slot < 0 || slot >= kMaxSlots) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float> w(kTransFloats), wl(kTransFloats);
+    int rc = factor_transitions(row_ptr, pred, logw, w.data());
+    if (rc != NCHMM_OK) return rc;
+    for (int i = 0; i < kTransFloats; ++i) wl[i] = std::exp(w[i]);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_trans + (size_t)slot * kTransFloats, w.data(), sizeof(float) * kTransFloats,
+                         hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_trans_lin + (size_t)slot * kTransFloats, wl.data(), sizeof(float) * kTransFloats,
+                         hipMemcpyHostToDevice));
+    c->trans_set[slot] = true;
+    return NCHMM_OK;
+}
+
+int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
+                      const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                      const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
+                      uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_reads == 0) return NCHMM_OK;
+    if (!d_off || !d_out_logp || n_reads > 0xFFFFFFF0ull) return NCHMM_E_INVALID;
+    if (total_events && (!d_cmean || !d_stdv || !d_lstdv || !d_out_state)) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int grid = (int)std::min<size_t>((size_t)c->vit_slots, n_reads);
+    const uint64_t stride = (uint64_t)std::max<size_t>(max_events, 1) * kStates;
+    void* p = c->d_ws;
+    int rc = ensure(c, &p, &c->ws_bytes, (size_t)stride * (size_t)c->vit_slots);
+    c->d_ws = (uint8_t*)p;
+    if (rc != NCHMM_OK) return rc;
+    ViterbiArgs a;
+    a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
+    a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
+    a.models = c->d_models; a.trans = c->d_trans;
+    a.ws = c->d_ws; a.ws_stride = stride;
+    a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
+    a.queue = c->d_queue; a.n_reads = (unsigned)n_reads;
+    a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
+    a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_vit0, c->stream));
+    launch_viterbi(a, grid, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_vit1, c->stream));
+    c->vit_timed = true;
+    c->counters[0] += n_reads;
+    c->counters[1] += total_events;
+    c->counters[2] += (uint64_t)(total_events > n_reads ? total_events - n_reads : 0) * kStates;
+    c->counters[3] += 1;
+    return NCHMM_OK;
+}
+
+int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float* cmean, const float* stdv,
+                  const float* lstdv, const int32_t* model_slot, const int32_t* trans_slot,
+                  uint16_t* out_state, float* out_logp, int32_t* out_status)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_reads == 0) return NCHMM_OK;
+    size_t max_events = 0, total = 0;
+    int rc = check_offsets(n_reads, off, &max_events, &total);
+    if (rc != NCHMM_OK) return rc;
+    if (!out_logp || (total && (!cmean || !stdv || !lstdv || !out_state))) return NCHMM_E_INVALID;
+    for (size_t r = 0; r < n_reads; ++r) {
+        const int ms = model_slot ? model_slot[r] : 0, ts = trans_slot ? trans_slot[r] : 0;
+        if (ms < 0 || ms >= kMaxSlots || ts < 0 || ts >= kMaxSlots || !c->model_set[ms] || !c->trans_set[ts])
+            return NCHMM_E_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    // longest-first processing order (LPT) for the device work queue
+    std::vector<uint32_t> order(n_reads);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return off[a + 1] - off[a] > off[b + 1] - off[b];
+    });
+    // one staging allocation: [off | cmean | stdv | lstdv | mslot | tslot | order | state | logp | status]
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_off = 0, o_cm = o_off + al(8 * (n_reads + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total);
+    size_t o_ms = o_ls + al(4 * total), o_ts = o_ms + al(4 * n_reads), o_or = o_ts + al(4 * n_reads);
+    size_t o_st = o_or + al(4 * n_reads), o_lp = o_st + al(2 * total), o_ss = o_lp + al(4 * n_reads);
+    size_t need = o_ss + al(4 * n_reads);
+    rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
+    if (rc != NCHMM_OK) return rc;
+    char* d = (char*)c->d_stage;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(d + o_off, off, 8 * (n_reads + 1), hipMemcpyHostToDevice, s));
+    if (total) {
+        HIP_TRY(c, hipMemcpyAsync(d + o_cm, cmean, 4 * total, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_sd, stdv, 4 * total, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_ls, lstdv, 4 * total, hipMemcpyHostToDevice, s));
+    }
+    if (model_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ms, model_slot, 4 * n_reads, hipMemcpyHostToDevice, s));
+    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_reads, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d + o_or, order.data(), 4 * n_reads, hipMemcpyHostToDevice, s));
+    rc = nchmm_viterbi_dev(c, n_reads, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm),
+                           (const float*)(d + o_sd), (const float*)(d + o_ls),
+                           model_slot ? (const int32_t*)(d + o_ms) : nullptr,
+                           trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or),
+                           (uint16_t*)(d + o_st), (float*)(d + o_lp), (int32_t*)(d + o_ss));
+    if (rc != NCHMM_OK) return rc;
+    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(out_logp, d + o_lp, 4 * n_reads, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> status(n_reads);
+    HIP_TRY(c, hipMemcpyAsync(status.data(), d + o_ss, 4 * n_reads, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    int worst = NCHMM_OK;
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (out_status) out_status[r] = status[r];
+        if (status[r] != 0) worst = NCHMM_E_NUMERIC;
+    }
+    return worst;
+}
+
+int nchmm_counters(const nchmm_ctx* c, uint64_t out[8])
+{
+    if (!c || !out) return NCHMM_E_INVALID;
+    std::memcpy(out, c->counters, sizeof(c->counters));
+    return NCHMM_OK;
+}
+
+int nchmm_last_kernel_ms(nchmm_ctx* c, float* vit_ms, float* fb_ms)
+{
+    if (!c) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (vit_ms) {
+        *vit_ms = 0;
+        if (c->vit_timed) {
+            HIP_TRY(c, hipEventSynchronize(c->ev_vit1));
+            HIP_TRY(c, hipEventElapsedTime(vit_ms, c->ev_vit0, c->ev_vit1));
+        }
+    }
+    if (fb_ms) {
+        *fb_ms = 0;
+        if (c->fb_timed) {
+            HIP_TRY(c, hipEventSynchronize(c->ev_fb1));
+            HIP_TRY(c, hipEventElapsedTime(fb_ms, c->ev_fb0, c->ev_fb1));
+        }
+    }
+    return NCHMM_OK;
+}
+
+int nchmm_grid_slots(const nchmm_ctx* c, int* v)
+{
+    if (!c || !v) return NCHMM_E_INVALID;
+    *v = c->vit_slots;
+    return NCHMM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// nchmm_device.h -- shared declarations between the HIP kernels and the C-ABI host layer.
+#ifndef NCHMM_DEVICE_H
+#define NCHMM_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nchmm {
+
+constexpr int kStates = 4096;
+constexpr int kThreads = 256;         // one wave per SIMD; thread t owns the 16 states whose low 8 bits == t
+constexpr int kStatesPerThread = 16;
+constexpr int kModelFloats = 6 * kStates;               // SoA [field][state]
+constexpr int kTransFloats = kStates + 1024 + 256;      // w0[4096] | w1[1024] | w2[256]
+constexpr int kMaxSlots = 64;
+constexpr unsigned kNoState = 0xFFFFu;
+
+// device image of a pore model: field-major so thread t reads field f of state t+256k at [f][t+256k]
+enum ModelField { MF_MU = 0, MF_SIGMA, MF_LOG_SIGMA, MF_ETA, MF_LAMBDA, MF_C /* log_lambda - log_2pi */ };
+
+struct ViterbiArgs {
+    const float* cmean;        // SoA events
+    const float* stdv;
+    const float* lstdv;
+    const uint64_t* off;       // n_reads + 1
+    const int32_t* model_slot; // per read or null
+    const int32_t* trans_slot; // per read or null
+    const uint32_t* order;     // processing order or null
+    const float* models;       // [kMaxSlots][kModelFloats]
+    const float* trans;        // [kMaxSlots][kTransFloats]
+    uint8_t* ws;               // back-pointer workspace, one region per block slot
+    uint64_t ws_stride;        // bytes per block slot (>= max_events * 4096)
+    uint16_t* out_state;
+    float* out_logp;
+    int32_t* out_status;
+    unsigned* queue;           // work-queue head, zeroed before launch
+    unsigned n_reads;
+    float log_n_states;        // std::log(4096.f) from the host libm (Viterbi.hpp:51)
+    float log_2pi;             // (float)std::log(2.0 * M_PI) (Pore_Model.hpp:28,37)
+};
+
+void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream);
+int viterbi_blocks_per_cu();
+
+struct FwbwArgs {
+    const float* cmean;
+    const float* stdv;
+    const float* lstdv;
+    const uint64_t* off;
+    const int32_t* scaled_slot;
+    const int32_t* unscaled_slot;
+    const int32_t* trans_slot;
+    const float* st_params;     // n_win x 2 or null
+    const float* models;
+    const float* trans;
+    const float* trans_lin;     // [kMaxSlots][kTransFloats] linear-space weights for FB (exp of trans)
+    float* ws_alpha;            // per block slot: max_events x 4096 floats (scaled alpha)
+    uint64_t ws_stride;         // floats per block slot
+    float* out_log_pr_data;
+    float* out_pm_sums;
+    float* out_st_sums;
+    float* out_alpha;
+    float* out_beta;
+    unsigned* queue;
+    unsigned n_win;
+    float log_n_states;
+    float log_2pi;
+};
+
+void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream);
+int fwbw_blocks_per_cu();
+
+}  // namespace nchmm
+#endif

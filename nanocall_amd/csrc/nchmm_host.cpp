@@ -1,0 +1,216 @@
+// nchmm_host.cpp -- host-side prep of the HMM tables (pure CPU; compiled into libnanocall_hip.so).
+//
+// These are the pieces of the reference's hot path that must stay on the host because they go
+// through libm (std::log / pow) and the called k-mer path has to be bit-exact: device logf is not
+// glibc logf.  Each function names the reference code it reproduces; nothing here is shared with
+// oracle/ (the oracle is an independent C restatement used only by the tests).
+//
+// Build flags matter: -ffp-contract=off (no FMA fusion), no -ffast-math.
+#include "nanocall_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nchmm_kmer.hpp"
+
+namespace {
+
+enum Field {  // order of Pore_Model_State, src/nanocall/Pore_Model.hpp:85-96
+    F_LEVEL_MEAN, F_LEVEL_STDV, F_SD_MEAN, F_SD_STDV, F_SD_LAMBDA,
+    F_LOG_LEVEL_MEAN, F_LOG_LEVEL_STDV, F_LOG_SD_MEAN, F_LOG_SD_STDV, F_LOG_SD_LAMBDA, F_COUNT
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* nchmm_strerror(int code)
+{
+    switch (code) {
+    case NCHMM_OK: return "ok";
+    case NCHMM_E_INVALID: return "invalid argument";
+    case NCHMM_E_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case NCHMM_E_HIP: return "HIP runtime error";
+    case NCHMM_E_TOPOLOGY: return "transitions are not the stay/step/skip-1 graph of compute_transitions_fast";
+    case NCHMM_E_NOMEM: return "out of memory";
+    case NCHMM_E_NUMERIC: return "read decoded to -INF/NaN in every state";
+    default: return "unknown error";
+    }
+}
+
+int nchmm_abi_version(void) { return 1; }
+
+// Pore_Model::load_from_vector, Pore_Model.hpp:220-239 (+ update_sd_lambda :112, update_logs :118-124)
+int nchmm_model_load(const float* table, float* state)
+{
+    if (!table || !state) return NCHMM_E_INVALID;
+    for (unsigned i = 0; i < NCHMM_N_STATES; ++i) {
+        float* s = state + (size_t)i * F_COUNT;
+        s[F_LEVEL_MEAN] = table[4 * i + 0];
+        s[F_LEVEL_STDV] = table[4 * i + 1];
+        s[F_SD_MEAN] = table[4 * i + 2];
+        s[F_SD_STDV] = table[4 * i + 3];
+        // pow() on (float, double) promotes to double; the quotient is rounded once to float
+        s[F_SD_LAMBDA] = static_cast<float>(std::pow(static_cast<double>(s[F_SD_MEAN]), 3.0)
+                                            / std::pow(static_cast<double>(s[F_SD_STDV]), 2.0));
+        s[F_LOG_LEVEL_MEAN] = std::log(s[F_LEVEL_MEAN]);
+        s[F_LOG_LEVEL_STDV] = std::log(s[F_LEVEL_STDV]);
+        s[F_LOG_SD_MEAN] = std::log(s[F_SD_MEAN]);
+        s[F_LOG_SD_STDV] = 0.0f;
+        s[F_LOG_SD_LAMBDA] = std::log(s[F_SD_LAMBDA]);
+    }
+    return NCHMM_OK;
+}
+
+// Pore_Model::scale :190-201 and Pore_Model_State::scale :126-138
+int nchmm_model_scale(float* state, const float params[6])
+{
+    if (!state || !params) return NCHMM_E_INVALID;
+    const float scale = params[0], shift = params[1], var = params[3], scale_sd = params[4], var_sd = params[5];
+    const float log_var = std::log(var), log_scale_sd = std::log(scale_sd), log_var_sd = std::log(var_sd);
+    for (unsigned i = 0; i < NCHMM_N_STATES; ++i) {
+        float* s = state + (size_t)i * F_COUNT;
+        s[F_LEVEL_MEAN] = s[F_LEVEL_MEAN] * scale + shift;
+        s[F_LEVEL_STDV] = s[F_LEVEL_STDV] * var;
+        s[F_SD_MEAN] = s[F_SD_MEAN] * scale_sd;
+        s[F_SD_LAMBDA] = s[F_SD_LAMBDA] * var_sd;
+        s[F_SD_STDV] = static_cast<float>(std::pow(std::pow(static_cast<double>(s[F_SD_MEAN]), 3.0)
+                                                   / static_cast<double>(s[F_SD_LAMBDA]), .5));
+        s[F_LOG_LEVEL_MEAN] = std::log(s[F_LEVEL_MEAN]);
+        s[F_LOG_LEVEL_STDV] += log_var;
+        s[F_LOG_SD_MEAN] += log_scale_sd;
+        s[F_LOG_SD_LAMBDA] += log_var_sd;
+    }
+    return NCHMM_OK;
+}
+
+int nchmm_model_pack6(const float* state, float* t6)
+{
+    if (!state || !t6) return NCHMM_E_INVALID;
+    for (unsigned i = 0; i < NCHMM_N_STATES; ++i) {
+        const float* s = state + (size_t)i * F_COUNT;
+        float* o = t6 + (size_t)i * 6;
+        o[0] = s[F_LEVEL_MEAN]; o[1] = s[F_LEVEL_STDV]; o[2] = s[F_LOG_LEVEL_STDV];
+        o[3] = s[F_SD_MEAN]; o[4] = s[F_SD_LAMBDA]; o[5] = s[F_LOG_SD_LAMBDA];
+    }
+    return NCHMM_OK;
+}
+
+// State_Transitions::compute_transitions_fast :181-224 + update_fields :79-104
+int nchmm_transitions_fast(float p_skip, float p_stay, uint32_t* row_ptr, uint16_t* pred, float* logw,
+                           uint32_t* n_arcs)
+{
+    if (!row_ptr || !pred || !logw) return NCHMM_E_INVALID;
+    using nchmm::Kmer6;
+    const float p_step = static_cast<float>(1.0 - p_stay - p_skip);        // :198
+    const float p_skip_1 = static_cast<float>(p_skip / (p_skip + 1.0));   // :200
+    // get_trans_prob :125-144 -- float accumulator, double pow terms
+    auto trans_prob = [&](unsigned i, unsigned j) {
+        float p = 0;
+        if (i == j) p += p_stay;
+        if (Kmer6::suffix(i, 5) == Kmer6::prefix(j, 5)) p += p_step / 4;
+        for (unsigned l = 2; l < 6; ++l)
+            if (Kmer6::suffix(i, 6 - l) == Kmer6::prefix(j, 6 - l))
+                p += std::pow(static_cast<double>(p_skip_1), static_cast<double>(l - 1)) / (1u << (2 * l));
+        p += (std::pow(static_cast<double>(p_skip_1), 5.0) / (1.0f - p_skip_1)) / 4096u;
+        return p;
+    };
+    // destination-major build: the predecessors of j are j, (x<<10)|(j>>2), (xy<<8)|(j>>4)
+    uint32_t n = 0;
+    for (unsigned j = 0; j < NCHMM_N_STATES; ++j) {
+        unsigned cand[21]; unsigned m = 0;
+        cand[m++] = j;
+        for (unsigned x = 0; x < 4; ++x) cand[m++] = (x << 10) | (j >> 2);
+        for (unsigned xy = 0; xy < 16; ++xy) cand[m++] = (xy << 8) | (j >> 4);
+        std::sort(cand, cand + m);
+        m = static_cast<unsigned>(std::unique(cand, cand + m) - cand);
+        row_ptr[j] = n;
+        for (unsigned k = 0; k < m; ++k) {
+            pred[n] = static_cast<uint16_t>(cand[k]);
+            logw[n] = std::log(trans_prob(cand[k], j));  // std::log(float) :216
+            ++n;
+        }
+    }
+    row_ptr[NCHMM_N_STATES] = n;
+    if (n_arcs) *n_arcs = n;
+    return NCHMM_OK;
+}
+
+// Event::update_logs :35-45 and Event_Sequence::apply_drift_correction :77-84
+int nchmm_events_prepare(size_t n, const float* mean, float* stdv, const float* start, float drift,
+                         float* corrected_mean, float* log_stdv)
+{
+    if (n && (!mean || !stdv || !corrected_mean || !log_stdv)) return NCHMM_E_INVALID;
+    if (n && drift != 0.0f && !start) return NCHMM_E_INVALID;
+    for (size_t i = 0; i < n; ++i) {
+        if (stdv[i] == 0.0) stdv[i] = static_cast<float>(0.01);
+        log_stdv[i] = std::log(stdv[i]);
+        float cm = mean[i];
+        if (start) cm -= drift * start[i];
+        corrected_mean[i] = cm;
+    }
+    return NCHMM_OK;
+}
+
+// Viterbi::fill_move_seq :144-150, Event_Sequence::get_base_seq Event.hpp:85-99
+int nchmm_base_seq(size_t n, const uint16_t* state, int32_t* move, char* seq, size_t* seq_len)
+{
+    using nchmm::Kmer6;
+    if (n && (!state || !seq)) return NCHMM_E_INVALID;
+    size_t len = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (state[i] >= NCHMM_N_STATES) return NCHMM_E_INVALID;
+        unsigned mv = i > 0 ? Kmer6::min_skip(state[i - 1], state[i]) : 0u;
+        if (move) move[i] = static_cast<int32_t>(mv);
+        char km[6];
+        Kmer6::to_chars(state[i], km);
+        if (i == 0) { std::memcpy(seq, km, 6); len = 6; continue; }
+        unsigned a = std::min(mv, 6u), b = 6 - a;
+        std::memcpy(seq + len, km + b, a);
+        len += a;
+    }
+    if (seq) seq[len] = 0;
+    if (seq_len) *seq_len = len;
+    return NCHMM_OK;
+}
+
+// write_fasta, nanocall.cpp:584-591
+int nchmm_write_fasta(const char* name, const char* seq, unsigned line_width, char* out, size_t cap,
+                      size_t* written)
+{
+    if (!name || !seq || !out || line_width == 0) return NCHMM_E_INVALID;
+    const size_t L = std::strlen(seq), nl = std::strlen(name);
+    const size_t need = 1 + nl + 1 + L + (L + line_width - 1) / line_width + 1;
+    if (cap < need) return NCHMM_E_NOMEM;
+    size_t n = 0;
+    out[n++] = '>'; std::memcpy(out + n, name, nl); n += nl; out[n++] = '\n';
+    for (size_t pos = 0; pos < L; pos += line_width) {
+        size_t c = std::min<size_t>(line_width, L - pos);
+        std::memcpy(out + n, seq + pos, c); n += c; out[n++] = '\n';
+    }
+    out[n] = 0;
+    if (written) *written = n;
+    return NCHMM_OK;
+}
+
+// Parameter_Trainer::init, Parameter_Trainer.hpp:30-57
+int nchmm_st_train_kmers(uint16_t* out, uint32_t* count)
+{
+    using nchmm::Kmer6;
+    if (!out || !count) return NCHMM_E_INVALID;
+    uint32_t n = 0;
+    for (unsigned i = 0; i < NCHMM_N_STATES; ++i) {
+        if (Kmer6::max_self_overlap(i) > 0) continue;
+        bool all_good = true;
+        for (unsigned b1 = 0; b1 < 4 && all_good; ++b1)
+            if (Kmer6::max_self_overlap((Kmer6::suffix(i, 5) << 2) + b1) > 1) all_good = false;
+        if (all_good) out[n++] = static_cast<uint16_t>(i);
+    }
+    *count = n;
+    return NCHMM_OK;
+}
+
+}  // extern "C"

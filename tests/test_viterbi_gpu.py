@@ -1,0 +1,142 @@
+"""GPU parity: the HIP Viterbi (through the C ABI) against the CPU oracle, bit-exact.
+
+Contract (BASELINE.json north_star): called k-mer path bit-exact; Viterbi log-likelihood within
+1e-4 relative -- we hold it to bit-identical, which is stronger."""
+import numpy as np
+import pytest
+
+import nanocall_amd as na
+from helpers import IDENT, ragged_batch, oracle_viterbi_batch, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, table, params, p_skip, p_stay, off, cm, sd, ls, slot=0):
+    ctx.put_model(slot, na.scaled_model_table(table, params))
+    ctx.put_transitions(slot, *na.transitions_fast(p_skip, p_stay))
+    ms = np.full(len(off) - 1, slot, np.int32)
+    return ctx.viterbi(off, cm, sd, ls, model_slot=ms, trans_slot=ms)
+
+
+@pytest.mark.parametrize("lens", [[1], [2], [3], [4], [5, 6, 7], [64, 257, 400], [1000, 1, 37, 0, 512]])
+def test_small_ragged_reads_bit_exact(gpu_ctx, r73t, lens):
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens)
+    states, logp, status = _run(gpu_ctx, r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    nz = np.diff(off.astype(np.int64)) > 0
+    assert_bits_equal(logp[nz], ologp[nz], "path probability")
+    assert np.isnan(logp[~nz]).all()
+    assert (status == 0).all()
+
+
+def test_scaled_model_custom_transitions_drift(gpu_ctx, r73t):
+    params = (1.05, 2.5, 0.002, 1.1, 0.9, 1.2)
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [700, 300], first_read=11, drift=params[2])
+    states, logp, status = _run(gpu_ctx, r73t, params, 0.17, 0.12, off, cm, sd, ls, slot=3)
+    ostates, ologp = oracle_viterbi_batch(r73t, params, 0.17, 0.12, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+
+
+def test_r9_model_2000_events(gpu_ctx, r9t):
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r9t, [2000], first_read=5)
+    states, logp, status = _run(gpu_ctx, r9t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(r9t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+
+
+def test_exact_ties_lowest_predecessor_wins(gpu_ctx, r73t):
+    """Repeated identical events and a model with duplicated states force exact float ties; the
+    reference resolves them to the lowest predecessor index (Viterbi.hpp:84 strict >)."""
+    t = r73t.copy()
+    t[:, :] = t[0, :]            # every state identical -> every comparison is a tie
+    n = 50
+    mean = np.full(n, t[0, 0], np.float32)
+    stdv = np.full(n, t[0, 2], np.float32)
+    cm, sd, ls = na.events_prepare(mean, stdv, None, 0.0)
+    off = np.array([0, n], np.uint64)
+    states, logp, _ = _run(gpu_ctx, t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+    # half the states identical, second half shifted: ties inside groups, not across
+    t2 = r73t.copy()
+    t2[1::2] = t2[0::2]
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(t2, [300], first_read=3)
+    states, logp, _ = _run(gpu_ctx, t2, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(t2, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+
+
+def test_zero_stdv_events(gpu_ctx, r73t):
+    off, mean, stdv, start, _, _, _ = ragged_batch(r73t, [200], first_read=9)
+    stdv[::7] = 0.0              # Event::update_logs turns these into 0.01 (Event.hpp:39-42)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    assert (sd[::7] == np.float32(0.01)).all()
+    states, logp, _ = _run(gpu_ctx, r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+
+
+def test_many_reads_work_queue_and_mixed_slots(gpu_ctx, r73t, r9t):
+    """More reads than resident blocks, two models/transition tables selected per read."""
+    n_reads = gpu_ctx.grid_slots() + 37
+    rng = np.random.default_rng(7)
+    lens = rng.integers(3, 40, size=n_reads).tolist()
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=100)
+    gpu_ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+    gpu_ctx.put_model(1, na.scaled_model_table(r9t, (0.7, -2.0, 0.0, 1.0, 1.0, 1.0)))
+    gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    gpu_ctx.put_transitions(1, *na.transitions_fast(0.28, 0.09))
+    slot = (np.arange(n_reads) % 2).astype(np.int32)
+    states, logp, status = gpu_ctx.viterbi(off, cm, sd, ls, model_slot=slot, trans_slot=slot)
+    for s, (tab, par, pk, ps) in enumerate([(r73t, IDENT, 0.3, 0.1), (r9t, (0.7, -2.0, 0.0, 1.0, 1.0, 1.0), 0.28, 0.09)]):
+        idx = np.nonzero(slot == s)[0][:40]
+        for r in idx:
+            a, b = int(off[r]), int(off[r + 1])
+            o_off = np.array([0, b - a], np.uint64)
+            os_, ol = oracle_viterbi_batch(tab, par, pk, ps, o_off, cm[a:b], sd[a:b], ls[a:b])
+            assert np.array_equal(states[a:b], os_), f"read {r}"
+            assert_bits_equal(logp[r:r + 1], ol, f"read {r} path probability")
+
+
+def test_full_size_read_5000_events(gpu_ctx, r73t):
+    """BASELINE config-2 read length (5 000 events): two reads against the oracle, plus base sequence
+    and FASTA text byte-identical."""
+    import nc_oracle as oracle
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [5000, 5000], first_read=0)
+    states, logp, _ = _run(gpu_ctx, r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+    for r in range(2):
+        a, b = int(off[r]), int(off[r + 1])
+        mv, seq = na.base_seq(states[a:b])
+        omv = np.array([0] + [oracle.lib().nco_kmer_min_skip(int(x), int(y)) for x, y in zip(ostates[a:b - 1], ostates[a + 1:b])])
+        assert np.array_equal(mv, omv)
+        oseq = oracle.base_seq(ostates[a:b], omv)
+        assert seq == oseq
+        assert na.write_fasta(f"read{r}:f:0", seq) == oracle.write_fasta(f"read{r}:f:0", oseq)
+
+
+def test_put_transitions_rejects_other_graphs(gpu_ctx):
+    rp, pred, w = na.transitions_fast(0.3, 0.1)
+    bad = pred.copy()
+    bad[5] ^= 1
+    with pytest.raises(na.api.NchmmError) as e:
+        gpu_ctx.put_transitions(5, rp, bad, w)
+    assert e.value.code == -4
+    w2 = w.copy()
+    w2[100] += 0.5               # breaks the group factorisation
+    with pytest.raises(na.api.NchmmError):
+        gpu_ctx.put_transitions(5, rp, pred, w2)
+
+
+def test_unset_slot_is_an_error(gpu_ctx, r73t):
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [10])
+    with pytest.raises(na.api.NchmmError):
+        gpu_ctx.viterbi(off, cm, sd, ls, model_slot=np.array([63], np.int32), trans_slot=np.array([63], np.int32))
