@@ -124,6 +124,10 @@ def main():
     dt = shard.max_over_ranks(dt, dev if world > 1 else None)
     counters = shard.gather_counters(ctx.counters(), dev if world > 1 else None)
 
+    if os.environ.get("NCHMM_PROFILE") == "1" and rank == 0:
+        tk = ctx.profile_ticks()
+        sys.stderr.write(f"[phase ticks, 100 MHz, summed over blocks] forward={tk[0]} traceback={tk[1]} block={tk[2]} "
+                         f"blocks={tk[3]} traceback/forward={float(tk[1]) / max(float(tk[0]), 1):.3f}\n")
     status = d_status.cpu().numpy()
     assert (status == 0).all(), "a read failed to decode"
 

@@ -190,6 +190,11 @@ int nchmm_counters(const nchmm_ctx* ctx, uint64_t out[8]);
  * measured on the stream it ran on.  Blocks until that kernel has finished. */
 int nchmm_last_kernel_ms(nchmm_ctx* ctx, float* viterbi_ms, float* fwbw_ms);
 
+/* Phase counters of the Viterbi kernel, accumulated over launches while the environment variable
+ * NCHMM_PROFILE=1 was set at nchmm_create time: out[0] = forward-sweep ticks summed over blocks,
+ * [1] = traceback ticks, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks). */
+int nchmm_profile_ticks(nchmm_ctx* ctx, uint64_t out[4], int reset);
+
 /* number of resident thread-block slots (persistent grid size) the Viterbi kernel launches */
 int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
 

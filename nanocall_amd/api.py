@@ -224,6 +224,11 @@ class Context:
         check(lib().nchmm_last_kernel_ms(self._h, C.byref(v), C.byref(f)), "nchmm_last_kernel_ms")
         return v.value, f.value
 
+    def profile_ticks(self, reset=True):
+        out = np.zeros(4, np.uint64)
+        check(lib().nchmm_profile_ticks(self._h, _p(out), int(reset)), "nchmm_profile_ticks")
+        return out
+
     def grid_slots(self):
         v = C.c_int(0)
         check(lib().nchmm_grid_slots(self._h, C.byref(v)), "nchmm_grid_slots")

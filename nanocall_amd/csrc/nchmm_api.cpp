@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -25,6 +26,9 @@ struct nchmm_ctx {
     float* d_trans = nullptr;       // [kMaxSlots][kTransFloats]   log-space w0|w1|w2
     float* d_trans_lin = nullptr;   // [kMaxSlots][kTransFloats]   exp() of the above (host libm), FB only
     unsigned* d_queue = nullptr;    // [2] work-queue heads (viterbi, fwbw)
+    int32_t* d_model_fast = nullptr; // [kMaxSlots]
+    unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
+    bool profile = false;
     uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace
     size_t ws_bytes = 0;
     float* d_fb_ws = nullptr;       // FB alpha workspace
@@ -175,6 +179,14 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     if ((rc = dev_alloc(c, (void**)&c->d_trans, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_trans_lin, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * 4))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_model_fast, sizeof(int32_t) * kMaxSlots))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 4))) return fail(rc);
+    if (hipMemset(c->d_model_fast, 0, sizeof(int32_t) * kMaxSlots) != hipSuccess) return fail(NCHMM_E_HIP);
+    if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 4) != hipSuccess) return fail(NCHMM_E_HIP);
+    {
+        const char* e = std::getenv("NCHMM_PROFILE");
+        c->profile = e && e[0] == '1';
+    }
     if (hipEventCreate(&c->ev_vit0) != hipSuccess || hipEventCreate(&c->ev_vit1) != hipSuccess
         || hipEventCreate(&c->ev_fb0) != hipSuccess || hipEventCreate(&c->ev_fb1) != hipSuccess)
         return fail(NCHMM_E_HIP);
@@ -193,6 +205,8 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_trans) (void)hipFree(c->d_trans);
     if (c->d_trans_lin) (void)hipFree(c->d_trans_lin);
     if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_model_fast) (void)hipFree(c->d_model_fast);
+    if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_stage) (void)hipFree(c->d_stage);
@@ -228,18 +242,30 @@ int nchmm_put_model(nchmm_ctx* c, int slot, const float* t6)
     HIP_TRY(c, hipSetDevice(c->device));
     const float log_2pi = static_cast<float>(std::log(2.0 * M_PI));  // Pore_Model.hpp:28,37
     std::vector<float> img(kModelFloats);
+    // The kernel divides by sigma, eta (per state) and stdv (per event) through correctly rounded
+    // reciprocals + two FMA residual steps; that equals IEEE division when no intermediate leaves
+    // the normal range, which holds for parameters inside these (very wide) bounds.  A model outside
+    // them is still decoded, with true divisions.
+    auto in = [](float v, float lo, float hi) { return std::isfinite(v) && v >= lo && v <= hi; };
+    int32_t fast = 1;
     for (int j = 0; j < kStates; ++j) {
         const float* s = t6 + (size_t)j * 6;
         img[MF_MU * kStates + j] = s[0];
         img[MF_SIGMA * kStates + j] = s[1];
-        img[MF_LOG_SIGMA * kStates + j] = s[2];
+        img[MF_RSIGMA * kStates + j] = static_cast<float>(1.0 / static_cast<double>(s[1]));
+        img[MF_NEG_LOG_SIGMA * kStates + j] = -s[2];
         img[MF_ETA * kStates + j] = s[3];
+        img[MF_RETA * kStates + j] = static_cast<float>(1.0 / static_cast<double>(s[3]));
         img[MF_LAMBDA * kStates + j] = s[4];
         img[MF_C * kStates + j] = s[5] - log_2pi;  // first subtraction of log_invgauss_pdf, Pore_Model.hpp:39
+        if (!(in(std::fabs(s[0]), 0x1p-10f, 0x1p20f) && in(s[1], 0x1p-10f, 0x1p10f) && in(s[3], 0x1p-6f, 0x1p10f)
+              && in(s[4], 0x1p-10f, 0x1p14f)))
+            fast = 0;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // a running kernel may still read this slot
     HIP_TRY(c, hipMemcpy(c->d_models + (size_t)slot * kModelFloats, img.data(), sizeof(float) * kModelFloats,
                          hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_model_fast + slot, &fast, sizeof(int32_t), hipMemcpyHostToDevice));
     c->model_set[slot] = true;
     return NCHMM_OK;
 }
@@ -280,7 +306,8 @@ int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t to
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
-    a.models = c->d_models; a.trans = c->d_trans;
+    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
+    a.prof = c->profile ? c->d_prof : nullptr;
     a.ws = c->d_ws; a.ws_stride = stride;
     a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
     a.queue = c->d_queue; a.n_reads = (unsigned)n_reads;
@@ -384,6 +411,16 @@ int nchmm_last_kernel_ms(nchmm_ctx* c, float* vit_ms, float* fb_ms)
             HIP_TRY(c, hipEventElapsedTime(fb_ms, c->ev_fb0, c->ev_fb1));
         }
     }
+    return NCHMM_OK;
+}
+
+int nchmm_profile_ticks(nchmm_ctx* c, uint64_t out[4], int reset)
+{
+    if (!c || !out) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_prof, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(c, hipMemset(c->d_prof, 0, sizeof(uint64_t) * 4));
     return NCHMM_OK;
 }
 

@@ -8,15 +8,18 @@
 namespace nchmm {
 
 constexpr int kStates = 4096;
-constexpr int kThreads = 256;         // one wave per SIMD; thread t owns the 16 states whose low 8 bits == t
-constexpr int kStatesPerThread = 16;
-constexpr int kModelFloats = 6 * kStates;               // SoA [field][state]
+constexpr int kThreads = 512;         // 8 waves; thread 2t+h owns 8 of the 16 states whose low 8 bits == t
+constexpr int kStatesPerThread = 8;
+constexpr int kModelFloats = 8 * kStates;               // SoA [field][state]
 constexpr int kTransFloats = kStates + 1024 + 256;      // w0[4096] | w1[1024] | w2[256]
 constexpr int kMaxSlots = 64;
 constexpr unsigned kNoState = 0xFFFFu;
 
 // device image of a pore model: field-major so thread t reads field f of state t+256k at [f][t+256k]
-enum ModelField { MF_MU = 0, MF_SIGMA, MF_LOG_SIGMA, MF_ETA, MF_LAMBDA, MF_C /* log_lambda - log_2pi */ };
+enum ModelField {
+    MF_MU = 0, MF_SIGMA, MF_RSIGMA /* RN(1/sigma) */, MF_NEG_LOG_SIGMA, MF_ETA, MF_RETA /* RN(1/eta) */, MF_LAMBDA,
+    MF_C /* log_lambda - log_2pi */
+};
 
 struct ViterbiArgs {
     const float* cmean;        // SoA events
@@ -28,6 +31,8 @@ struct ViterbiArgs {
     const uint32_t* order;     // processing order or null
     const float* models;       // [kMaxSlots][kModelFloats]
     const float* trans;        // [kMaxSlots][kTransFloats]
+    const int32_t* model_fast; // [kMaxSlots] 1 = parameters inside the range the reciprocal division is proven for
+    unsigned long long* prof;  // optional [4]: forward ticks, traceback ticks, block ticks, blocks (wall_clock64)
     uint8_t* ws;               // back-pointer workspace, one region per block slot
     uint64_t ws_stride;        // bytes per block slot (>= max_events * 4096)
     uint16_t* out_state;

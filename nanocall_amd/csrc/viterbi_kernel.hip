@@ -4,28 +4,42 @@
 // reads.  One read per thread-block (persistent blocks pull reads from a work queue).
 //
 // Mapping (DESIGN.md "Viterbi kernel"):
-//   * 256 threads = 4 waves, one per SIMD.  Thread t owns the 16 states j = t + 256*k whose LOW 8
-//     bits (last four bases) are t; k = top 4 bits (first two bases).  alpha[16], the six emission
-//     parameters of each owned state and the transition weights live in VGPRs for the whole read.
+//   * 512 threads = 8 waves, two per SIMD; two blocks per CU give 4 waves/SIMD (<= 128 VGPRs).
+//     Thread tau = 2*t + h owns 8 of the 16 states whose LOW 8 bits (last four bases) are t:
+//     j = t + 256*k with k = 4x + y (top four bits = first two bases), y in {h, h+2}, x in 0..3.
+//     alpha[8] and the per-state parameters live in VGPRs for the whole read.
 //   * The predecessors of j are  j,  (x<<10)|(j>>2) x=0..3  and  (xy<<8)|(j>>4) xy=0..15
 //     (Kmer::neighbour_list inverted, Kmer.hpp:128-142).  All 16 skip-predecessors of a state
-//     share their low 8 bits, all 4 step-predecessors their low 10 bits, so thread t holds every
-//     member of skip group q=t and of step groups r=(y<<8)|t: the 21-way max of the reference
-//     (Viterbi.hpp:79-89) becomes two in-register group scans per thread + one 3-way combine per
-//     state, with the per-group results exchanged through LDS (one barrier per event).
-//   * Weights factor as w0[j] / w1[r] / w2[q] (see nchmm_api.cpp: factor_transitions) so the sums
-//     w + alpha are exactly the floats the reference forms; ties resolve to the lowest predecessor
-//     index exactly as the ascending strict-> scan of the reference does.
-//   * Back-pointers are one byte per state (0 stay, 1+x step, 5+xy skip), row i of a read at
-//     ws + i*4096, state j at byte ((j&255)<<4)|(j>>8): each thread stores its 16 bytes as ONE
-//     dwordx4 (a wave writes 1 KiB contiguous), and the 21 candidates of the next traceback step
-//     sit in three 16-byte groups.
+//     share their low 8 bits, all 4 step-predecessors their low 10 bits.  So the 21-way max of the
+//     reference (Viterbi.hpp:79-89) becomes: per thread two complete 4-member step-group scans and
+//     half of a 16-member skip-group scan (merged with the partner lane by one DPP swap), then one
+//     3-way combine per state, the per-group winners going through LDS (one barrier per event).
+//   * Weights factor as w0[j] / w1[r] / w2[q] (nchmm_api.cpp: factor_transitions), so w + alpha
+//     are exactly the floats the reference forms.  The group scans run on RAW alpha (one add per
+//     group instead of one per member); because RN(w + .) is monotone the winner is the same
+//     unless a smaller alpha rounds to the same sum, which is ruled out per group by probing the
+//     next float below the maximum -- otherwise the wave takes the exact sum-by-sum scan.  Ties
+//     resolve to the lowest predecessor index as the reference's ascending strict-> scan does.
+//   * Divisions: divisors are per-state constants (sigma, eta) or per-event constants (stdv): the
+//     quotient comes from a correctly rounded reciprocal + two FMA residual corrections
+//     (Markstein), bit-identical to IEEE division inside the validated operand range (checked per
+//     model on upload, per 512-event chunk here), true division otherwise.
+//   * Selects are written as v_cndmask_b32_e64 with an SGPR-pair mask: on gfx950 the VOP2 form
+//     reading a VCC that was not written by the immediately preceding VALU op issues ~8x slower
+//     (tools/ubench/valu_rate.hip).
+//   * Back-pointers are one byte per state (0 stay, 1+x step, 5+xy skip); row i of a read at
+//     ws + i*4096, state j at byte (t<<4) | (h<<3) | (x<<1) | (y>>1): each thread stores its 8
+//     bytes as one dwordx2 (a wave writes 512 B contiguous), and the 21 candidates of the next
+//     traceback step sit in three 16-byte groups.
 //   * Traceback: wave 0 resolves three events per memory round trip by fetching every 16-byte
 //     group that can hold the byte of rows i, i-1, i-2 (27 lanes x 16 B).
 //
-// Float contract: -ffp-contract=off, correctly rounded fp32 divide (hipcc default), denormals on,
-// no device log/exp anywhere: every log is computed by the host libm and passed in.
+// Float contract: -ffp-contract=off (the only FMAs are the explicit residual corrections and the
+// next-float probe), denormals on, no device log/exp: every log comes from the host libm.
 #include "nchmm_device.h"
+
+#include <cstdio>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -33,49 +47,259 @@ namespace nchmm {
 
 namespace {
 
-struct __attribute__((aligned(8))) ValIdx {
+typedef unsigned long long mask_t;
+constexpr unsigned kChunk = 256;   // events staged in LDS at a time
+
+struct __attribute__((aligned(8))) ValSlot {
     float v;
-    unsigned i;
+    unsigned s;   // back-pointer slot code of the group winner (1+x or 5+xy); the state index in sRed
 };
+
+// v_cndmask_b32_e64 dst, a, b, mask : mask bit set -> b, clear -> a
+__device__ __forceinline__ float selm(mask_t m, float if_set, float if_clear)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ unsigned selm(mask_t m, unsigned if_set, unsigned if_clear)
+{
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float swap1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned swap1(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
 
 __device__ __forceinline__ unsigned pred_of(unsigned j, unsigned slot)
 {
-    // slot 0: stay; 1..4: step with first base x = slot-1; 5..20: skip with first two bases xy = slot-5
     if (slot == 0) return j;
     if (slot < 5) return ((slot - 1) << 10) | (j >> 2);
     return ((slot - 5) << 8) | (j >> 4);
 }
 
-__device__ __forceinline__ unsigned bp_byte_offset(unsigned j) { return ((j & 255u) << 4) | (j >> 8); }
+// byte of state j inside its 16-byte group: k = j >> 8 = 4x + y  ->  ((y&1)<<3) | (x<<1) | (y>>1)
+__device__ __forceinline__ unsigned bp_pos(unsigned k) { return ((k & 1u) << 3) | ((k >> 2) << 1) | ((k >> 1) & 1u); }
+
+// n / d with r = RN(1/d) precomputed.  q0 = RN(n r) is within 2 ulp; the first residual step makes
+// it faithful, the second (Markstein: faithful q, correctly rounded r, exact residual) makes it
+// the correctly rounded quotient.  Needs n == 0 or 2^-100 <= |n| <= 2^100 and d, r normal.
+template <bool FAST>
+__device__ __forceinline__ float quot(float n, float d, float r)
+{
+    if constexpr (FAST) {
+        float q = n * r;
+        float e = __builtin_fmaf(-q, d, n);
+        q = __builtin_fmaf(e, r, q);
+        e = __builtin_fmaf(-q, d, n);
+        return __builtin_fmaf(e, r, q);
+    } else {
+        return n / d;
+    }
+}
 
 // Pore_Model_State::log_pr_corrected_emission, Pore_Model.hpp:145-149 with log_normal_pdf :24-31
-// and log_invgauss_pdf :33-40, operation for operation.  c = log_lambda - log_2pi is the first
-// subtraction of the reference's left-to-right expression, ly3 = 3.0f * log_x its second operand.
-__device__ __forceinline__ float emission(float x, float y, float ly3, float mu, float sigma, float lsigma,
-                                          float eta, float lambda, float c, float log_2pi)
+// and log_invgauss_pdf :33-40, operation for operation:
+//   a = (x - mu) / sigma;            N  = -log_sigma - (log_2pi + a*a) / 2
+//   b = (y - eta) / eta;             IG = (log_lambda - log_2pi - 3*log_y - lambda*b*b / y) / 2
+// nls = -log_sigma (exact negation), c = log_lambda - log_2pi (first subtraction of the reference's
+// left-to-right expression), ly3 = 3.0f * log_y.
+template <bool FAST>
+__device__ __forceinline__ float emission(float x, float y, float ry, float ly3, float log_2pi, float mu, float sg,
+                                          float rsg, float nls, float eta, float reta, float lam, float c)
 {
-    float a = (x - mu) / sigma;
-    float n = -lsigma - (log_2pi + a * a) / 2.0f;
-    float b = (y - eta) / eta;
-    float ig = (c - ly3 - lambda * b * b / y) / 2.0f;
+    const float a = quot<FAST>(x - mu, sg, rsg);
+    const float n = nls - (log_2pi + a * a) / 2.0f;
+    const float b = quot<FAST>(y - eta, eta, reta);
+    const float ig = (c - ly3 - quot<FAST>(lam * b * b, y, ry)) / 2.0f;
     return n + ig;
+}
+
+struct State {
+    // index i = (x<<1) | (y>>1), state j = t + 256*(4x + y), y = 2*(i&1) + h
+    float mu[8], sg[8], rsg[8], eta[8], reta[8], lam[8], alpha[8];
+    float w1[2];   // step groups r = (y<<8)|t for y = h, h+2
+    float w2;      // skip group q = t
+};
+
+// Three per-state tables that are touched once per cell (-log sigma, log lambda - log 2pi, stay weight)
+// live in LDS, thread-major: thread tau's 8 floats of table f at sTab[f][tau*8 ..], the two 16-byte
+// chunks XOR-swizzled by bit 3 of tau so the ds_read_b128 lane groups hit distinct banks.
+__device__ __forceinline__ unsigned tab_off(unsigned tau, unsigned chunk)
+{
+    return tau * 8u + ((chunk ^ ((tau >> 3) & 1u)) << 2);
+}
+
+// (value, index) merge: take b if b.v > a.v, or equal and lower index
+__device__ __forceinline__ void merge_lower(float& av, unsigned& ai, float bv, unsigned bi)
+{
+    const mask_t m = ballot(bv > av || (bv == av && bi < ai));
+    av = selm(m, bv, av);
+    ai = selm(m, bi, ai);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], ValSlot* sV1, ValSlot* sV2,
+                                       uint8_t* bp_row, unsigned tau, float x, float y, float ry, float ly3,
+                                       float log_2pi)
+{
+    const float NEG_INF = -__builtin_inff();
+    const unsigned t = tau >> 1, h = tau & 1u;
+
+    // ---------------- group scans over the previous column ----------------
+    // raw maxima first (strict >, ascending index => first maximum), sums once per group
+    float m4[2]; unsigned x4[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {            // y = 2g + h, members i = 2x + g
+        float bv = NEG_INF; unsigned bx = 0;
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+            const float v = S.alpha[2 * xx + g];
+            const mask_t m = ballot(v > bv);
+            bv = selm(m, v, bv);
+            bx = selm(m, (unsigned)xx, bx);
+        }
+        m4[g] = bv; x4[g] = bx;
+    }
+    // own half of the skip group: k = 4x + y
+    float m8 = m4[0]; unsigned k8 = 4u * x4[0] + h;
+    merge_lower(m8, k8, m4[1], 4u * x4[1] + 2u + h);
+    // partner half
+    float m16 = m8; unsigned k16 = k8;
+    merge_lower(m16, k16, swap1(m8), swap1(k8));
+
+    float s1[2] = {S.w1[0] + m4[0], S.w1[1] + m4[1]};
+    float s2 = S.w2 + m16;
+    unsigned sl1[2] = {1u + x4[0], 1u + x4[1]};
+    unsigned sl2 = 5u + k16;
+    // Is any smaller alpha rounded to the same sum?  probe the next float below the maximum
+    // (exact for negative normal maxima; anything else reports "unsafe").
+    {
+        const float c = 0x1.8p-24f;   // 0.75 ulp relative: RN(m + m*c) is the next float below a negative m
+        const float p0 = __builtin_fmaf(m4[0], c, m4[0]), p1 = __builtin_fmaf(m4[1], c, m4[1]);
+        const float p2 = __builtin_fmaf(m16, c, m16);
+        const bool unsafe = (S.w1[0] + p0 >= s1[0]) || (S.w1[1] + p1 >= s1[1]) || (S.w2 + p2 >= s2);
+        if (ballot(unsafe) != 0) {
+            // exact scan on the sums themselves (Viterbi.hpp:79-89 restricted to one class)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float bv = NEG_INF; unsigned bx = 0;
+#pragma unroll
+                for (int xx = 0; xx < 4; ++xx) {
+                    const float v = S.w1[g] + S.alpha[2 * xx + g];
+                    const mask_t m = ballot(v > bv);
+                    bv = selm(m, v, bv);
+                    bx = selm(m, (unsigned)xx, bx);
+                }
+                s1[g] = bv; sl1[g] = 1u + bx;
+            }
+            float bv = NEG_INF; unsigned bk = h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {   // ascending i == ascending k for this thread
+                const float v = S.w2 + S.alpha[i];
+                const mask_t m = ballot(v > bv);
+                bv = selm(m, v, bv);
+                bk = selm(m, 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h, bk);
+            }
+            merge_lower(bv, bk, swap1(bv), swap1(bk));
+            s2 = bv; sl2 = 5u + bk;
+        }
+    }
+    sV1[(h << 8) | t] = ValSlot{s1[0], sl1[0]};
+    sV1[((2u + h) << 8) | t] = ValSlot{s1[1], sl1[1]};
+    if (h == 0) sV2[t] = ValSlot{s2, sl2};
+    __syncthreads();
+
+    // ---------------- 3-way combine per state ----------------
+    const mask_t all = ballot(true);
+    const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
+    unsigned bpw[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float4 nls4 = *reinterpret_cast<const float4*>(&sTab[0][tab_off(tau, c)]);
+        const float4 cc4 = *reinterpret_cast<const float4*>(&sTab[1][tab_off(tau, c)]);
+        const float4 w04 = *reinterpret_cast<const float4*>(&sTab[2][tab_off(tau, c)]);
+        const float nls_[4] = {nls4.x, nls4.y, nls4.z, nls4.w};
+        const float cc_[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+        const float w0_[4] = {w04.x, w04.y, w04.z, w04.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * c + u;
+            // k = kc + h with kc a compile-time constant: the LDS addresses are one per-thread base
+            // (r1_base, q_base) plus an immediate offset
+            const unsigned kc = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1);
+            const unsigned k = kc + h;
+            const unsigned r1 = r1_base + (kc << 6), q = q_base + (kc << 4);
+            const ValSlot a = sV1[r1];
+            const ValSlot b = sV2[q];
+            const float s0 = w0_[u] + S.alpha[i];
+            // fast path: the winner is unique unless two class values are equal
+            float best = __builtin_fmaxf(__builtin_fmaxf(s0, a.v), b.v);
+            const mask_t e0 = ballot(s0 == best), e1 = ballot(a.v == best), e2 = ballot(b.v == best);
+            unsigned slot = selm(e0, 0u, selm(e1, a.s, b.s));
+            const mask_t tie = (e0 & e1) | ((e0 | e1) & e2) | (all & ~(e0 | e1 | e2));
+            if (tie != 0) {
+                // exact rule: first maximum in ascending predecessor order (strict >, NaN never wins)
+                const unsigned j = t + 256u * k;
+                const unsigned p1 = ((a.s - 1u) << 10) | r1;
+                const unsigned p2 = ((b.s - 5u) << 8) | q;
+                float bb = NEG_INF; unsigned bp = (unsigned)kStates, sl = 255u;
+                if (s0 > bb) { bb = s0; bp = j; sl = 0; }
+                if (a.v > bb || (a.v == bb && p1 < bp)) { bb = a.v; bp = p1; sl = a.s; }
+                if (b.v > bb || (b.v == bb && p2 < bp)) { bb = b.v; bp = p2; sl = b.s; }
+                best = bb; slot = sl;
+            }
+            const float e = emission<FAST>(x, y, ry, ly3, log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls_[u], S.eta[i],
+                                           S.reta[i], S.lam[i], cc_[u]);
+            S.alpha[i] = best + e;
+            bpw[c] |= slot << (8 * u);
+#ifdef NCHMM_SCHED_FENCE
+            if ((u & (NCHMM_SCHED_FENCE - 1)) == NCHMM_SCHED_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+    const unsigned w_lo = bpw[0], w_hi = bpw[1];
+    *reinterpret_cast<uint2*>(bp_row + tau * 8u) = make_uint2(w_lo, w_hi);
+}
+
+__device__ __forceinline__ bool event_in_fast_range(float x, float y)
+{
+    // see quot(): keeps every dividend either 0 or within [2^-100, 2^100] given a validated model
+    return __builtin_fabsf(x) <= 1048576.0f && y >= 0.0078125f && y <= 1024.0f;
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(kThreads) void viterbi_kernel(ViterbiArgs P)
+#ifndef NCHMM_MIN_WAVES
+#define NCHMM_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(ViterbiArgs P)
 {
-    __shared__ ValIdx sV1[2][1024];   // step-group winners  (value, x)
-    __shared__ ValIdx sV2[2][256];    // skip-group winners  (value, xy)
-    __shared__ ValIdx sRed[kThreads];
+    __shared__ __attribute__((aligned(16))) float sTab[3][kStates];   // -log sigma | log lambda - log 2pi | w0
+    __shared__ ValSlot sV1[2][1024];   // step-group winners
+    __shared__ ValSlot sV2[2][256];    // skip-group winners
+    __shared__ __attribute__((aligned(16))) float4 sEv[kChunk];     // per event: x, y, 3*log y, 1/y
+    ValSlot* const sRed = &sV1[0][0];  // the final arg-max reduction reuses the exchange buffer
     __shared__ __attribute__((aligned(16))) uint8_t sStage[32][16];
     __shared__ unsigned sWork;
 
-    const unsigned t = threadIdx.x;
+    const unsigned tau = threadIdx.x;
+    const unsigned t = tau >> 1, h = tau & 1u;
     uint8_t* const ws = P.ws + (uint64_t)blockIdx.x * P.ws_stride;
+    unsigned long long t_fwd = 0, t_tb = 0, t_all0 = 0;
+    if (P.prof) t_all0 = wall_clock64();
 
     for (;;) {
-        if (t == 0) sWork = atomicAdd(P.queue, 1u);
+        if (tau == 0) sWork = atomicAdd(P.queue, 1u);
         __syncthreads();
         const unsigned widx = sWork;
         __syncthreads();
@@ -84,94 +308,87 @@ __global__ __launch_bounds__(kThreads) void viterbi_kernel(ViterbiArgs P)
         const uint64_t e0 = P.off[r];
         const unsigned n = (unsigned)(P.off[r + 1] - e0);
         if (n == 0) {
-            if (t == 0) {
+            if (tau == 0) {
                 P.out_logp[r] = __builtin_nanf("");
                 if (P.out_status) P.out_status[r] = 0;
             }
             continue;
         }
+        unsigned long long c0 = 0;
+        if (P.prof) c0 = wall_clock64();
         const int ms = P.model_slot ? P.model_slot[r] : 0;
         const int ts = P.trans_slot ? P.trans_slot[r] : 0;
         const float* __restrict__ M = P.models + (size_t)ms * kModelFloats;
         const float* __restrict__ W = P.trans + (size_t)ts * kTransFloats;
+        const bool model_fast = P.model_fast[ms] != 0;
         const float* __restrict__ ex = P.cmean + e0;
         const float* __restrict__ ey = P.stdv + e0;
         const float* __restrict__ el = P.lstdv + e0;
 
-        float mu[16], sg[16], lsg[16], eta[16], lam[16], cc[16], w0[16], alpha[16];
+        State S;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int i = 0; i < 8; ++i) {
+            const unsigned k = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h;
             const unsigned j = t + 256u * k;
-            mu[k] = M[MF_MU * kStates + j];
-            sg[k] = M[MF_SIGMA * kStates + j];
-            lsg[k] = M[MF_LOG_SIGMA * kStates + j];
-            eta[k] = M[MF_ETA * kStates + j];
-            lam[k] = M[MF_LAMBDA * kStates + j];
-            cc[k] = M[MF_C * kStates + j];
-            w0[k] = W[j];
+            S.mu[i] = M[MF_MU * kStates + j];
+            S.sg[i] = M[MF_SIGMA * kStates + j];
+            S.rsg[i] = M[MF_RSIGMA * kStates + j];
+            S.eta[i] = M[MF_ETA * kStates + j];
+            S.reta[i] = M[MF_RETA * kStates + j];
+            S.lam[i] = M[MF_LAMBDA * kStates + j];
+            const unsigned o = tab_off(tau, (unsigned)i >> 2) + ((unsigned)i & 3u);
+            sTab[0][o] = M[MF_NEG_LOG_SIGMA * kStates + j];
+            sTab[1][o] = M[MF_C * kStates + j];
+            sTab[2][o] = W[j];   // (each thread reads back only what it wrote: no barrier needed)
         }
-        float w1[4];
-#pragma unroll
-        for (int y = 0; y < 4; ++y) w1[y] = W[kStates + (y << 8) + t];
-        const float w2 = W[kStates + 1024 + t];
+        S.w1[0] = W[kStates + (h << 8) + t];
+        S.w1[1] = W[kStates + ((2u + h) << 8) + t];
+        S.w2 = W[kStates + 1024 + t];
 
-        // ---- column 0 (Viterbi.hpp:55-68) ----
-        {
-            const float x = ex[0], y = ey[0], ly3 = 3.0f * el[0];
+        for (unsigned base = 0; base < n; base += kChunk) {
+            // stage the next kChunk events: x, y, 3 log y, 1/y (one correctly rounded divide per event)
+            const unsigned ie = base + tau;
+            bool ok = true;
+            if (tau < kChunk && ie < n) {
+                const float x = ex[ie], y = ey[ie];
+                sEv[tau] = make_float4(x, y, 3.0f * el[ie], 1.0f / y);
+                ok = event_in_fast_range(x, y);
+            }
+            const bool fast = __syncthreads_and(ok) && model_fast;
+            const unsigned hi = (n - base < kChunk) ? n - base : kChunk;
+            unsigned lo = 0;
+            if (base == 0) {
+                // ---- column 0 (Viterbi.hpp:55-68) ----
+                const float4 ev = sEv[0];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                alpha[k] = emission(x, y, ly3, mu[k], sg[k], lsg[k], eta[k], lam[k], cc[k], P.log_2pi) - P.log_n_states;
-        }
-
-        // ---- columns 1..n-1 (Viterbi.hpp:72-96) ----
-        for (unsigned i = 1; i < n; ++i) {
-            const unsigned buf = i & 1u;
-            const float x = ex[i], y = ey[i], ly3 = 3.0f * el[i];
-            // in-register group scans over the previous column, ascending predecessor index,
-            // strict > from -INF exactly like the reference loop
-            {
-                float bv = -__builtin_inff();
-                unsigned bi = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float v = w2 + alpha[k];
-                    if (v > bv) { bv = v; bi = k; }
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned o = tab_off(tau, (unsigned)i >> 2) + ((unsigned)i & 3u);
+                    const float nls = sTab[0][o], cc = sTab[1][o];
+                    const float e = fast ? emission<true>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i],
+                                                          nls, S.eta[i], S.reta[i], S.lam[i], cc)
+                                         : emission<false>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i],
+                                                           nls, S.eta[i], S.reta[i], S.lam[i], cc);
+                    S.alpha[i] = e - P.log_n_states;
                 }
-                sV2[buf][t] = ValIdx{bv, bi};
+                lo = 1;
             }
-#pragma unroll
-            for (int yy = 0; yy < 4; ++yy) {
-                float bv = -__builtin_inff();
-                unsigned bi = 0;
-#pragma unroll
-                for (int xx = 0; xx < 4; ++xx) {
-                    const float v = w1[yy] + alpha[4 * xx + yy];
-                    if (v > bv) { bv = v; bi = xx; }
+            // ---- columns (Viterbi.hpp:72-96) ----
+            if (fast) {
+                for (unsigned c = lo; c < hi; ++c) {
+                    const float4 ev = sEv[c];
+                    const unsigned i = base + c;
+                    column<true>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, ev.x, ev.y, ev.w, ev.z,
+                                 P.log_2pi);
                 }
-                sV1[buf][(yy << 8) | t] = ValIdx{bv, bi};
+            } else {
+                for (unsigned c = lo; c < hi; ++c) {
+                    const float4 ev = sEv[c];
+                    const unsigned i = base + c;
+                    column<false>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, ev.x, ev.y, ev.w, ev.z,
+                                  P.log_2pi);
+                }
             }
-            __syncthreads();
-            unsigned bpw[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const unsigned j = t + 256u * k;
-                const unsigned r1 = ((unsigned)k << 6) | (t >> 2);
-                const unsigned q = ((unsigned)k << 4) | (t >> 4);
-                const ValIdx a = sV1[buf][r1];
-                const ValIdx b = sV2[buf][q];
-                const unsigned p1 = (a.i << 10) | r1;
-                const unsigned p2 = (b.i << 8) | q;
-                float best = -__builtin_inff();
-                unsigned bp = kStates, slot = 255u;
-                const float s0 = w0[k] + alpha[k];
-                if (s0 > best) { best = s0; bp = j; slot = 0; }
-                if (a.v > best || (a.v == best && p1 < bp)) { best = a.v; bp = p1; slot = 1u + a.i; }
-                if (b.v > best || (b.v == best && p2 < bp)) { best = b.v; bp = p2; slot = 5u + b.i; }
-                const float e = emission(x, y, ly3, mu[k], sg[k], lsg[k], eta[k], lam[k], cc[k], P.log_2pi);
-                alpha[k] = best + e;
-                bpw[k >> 2] |= slot << (8 * (k & 3));
-            }
-            *reinterpret_cast<uint4*>(ws + (uint64_t)i * kStates + t * 16u) = make_uint4(bpw[0], bpw[1], bpw[2], bpw[3]);
+            __syncthreads();   // sEv is rewritten by the next chunk
         }
 
         // ---- fill_state_seq: arg-max of the last column, lowest index on ties (Viterbi.hpp:125-133) ----
@@ -179,71 +396,77 @@ __global__ __launch_bounds__(kThreads) void viterbi_kernel(ViterbiArgs P)
             float bv = -__builtin_inff();
             unsigned bi = kStates;
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (alpha[k] > bv) { bv = alpha[k]; bi = t + 256u * k; }
-            sRed[t] = ValIdx{bv, bi};
+            for (int i = 0; i < 8; ++i) {   // ascending i == ascending j for this thread
+                const unsigned k = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h;
+                const bool g = S.alpha[i] > bv;
+                bv = g ? S.alpha[i] : bv;
+                bi = g ? t + 256u * k : bi;
+            }
+            sRed[tau] = ValSlot{bv, bi};
         }
         __syncthreads();   // also publishes every back-pointer store of this block (vmcnt(0) + barrier)
-        if (t < 64) {
-            ValIdx m = sRed[t];
+        unsigned long long c1 = 0;
+        if (P.prof) c1 = wall_clock64();
+        if (tau < 64) {
+            ValSlot m = sRed[tau];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const ValIdx o = sRed[t + 64 * w];
-                if (o.v > m.v || (o.v == m.v && o.i < m.i)) m = o;
+            for (int w = 1; w < kThreads / 64; ++w) {
+                const ValSlot o = sRed[tau + 64 * w];
+                if (o.v > m.v || (o.v == m.v && o.s < m.s)) m = o;
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
-                ValIdx o;
+                ValSlot o;
                 o.v = __shfl_xor(m.v, d, 64);
-                o.i = __shfl_xor(m.i, d, 64);
-                if (o.v > m.v || (o.v == m.v && o.i < m.i)) m = o;
+                o.s = __shfl_xor(m.s, d, 64);
+                if (o.v > m.v || (o.v == m.v && o.s < m.s)) m = o;
             }
             // every lane of wave 0 now holds (path probability, last state)
             uint16_t* __restrict__ os = P.out_state + e0;
-            if (t == 0) {
-                P.out_logp[r] = m.v;
-                if (P.out_status) P.out_status[r] = (m.i >= (unsigned)kStates) ? -6 : 0;
-            }
-            if (m.i < (unsigned)kStates) {
+            int status = (m.s >= (unsigned)kStates) ? -6 : 0;
+            if (status == 0) {
                 // this CU may still cache rows of the previous read that used this workspace
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                unsigned s = m.i;
+                unsigned s = m.s;
                 int cur = (int)n - 1;
-                if (t == 0) os[cur] = (uint16_t)s;
+                if (tau == 0) os[cur] = (uint16_t)s;
                 while (cur >= 1) {
                     // rows cur, cur-1, cur-2: fetch every 16-byte group that can hold the needed byte
                     int row; unsigned grp; bool act = true;
-                    if (t == 0) { row = cur; grp = s & 255u; }
-                    else if (t < 4) { row = cur - 1; grp = (s >> (2 * (t - 1))) & 255u; }
-                    else if (t < 7) { row = cur - 2; grp = (s >> (2 * (t - 4))) & 255u; }
-                    else if (t < 11) { row = cur - 2; grp = ((t - 7) << 6) | ((s >> 6) & 63u); }
-                    else if (t < 27) { row = cur - 2; grp = ((t - 11) << 4) | ((s >> 8) & 15u); }
+                    if (tau == 0) { row = cur; grp = s & 255u; }
+                    else if (tau < 4) { row = cur - 1; grp = (s >> (2 * (tau - 1))) & 255u; }
+                    else if (tau < 7) { row = cur - 2; grp = (s >> (2 * (tau - 4))) & 255u; }
+                    else if (tau < 11) { row = cur - 2; grp = ((tau - 7) << 6) | ((s >> 6) & 63u); }
+                    else if (tau < 27) { row = cur - 2; grp = ((tau - 11) << 4) | ((s >> 8) & 15u); }
                     else { row = 0; grp = 0; act = false; }
                     if (act && row >= 1)
-                        *reinterpret_cast<uint4*>(&sStage[t][0]) =
+                        *reinterpret_cast<uint4*>(&sStage[tau][0]) =
                             *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_s_waitcnt(0);   // LDS stage visible to the whole wave
                     __builtin_amdgcn_wave_barrier();
                     // resolve up to three steps (all lanes redundantly; uniform control flow)
-                    unsigned slot = sStage[0][s >> 8];
+                    unsigned slot = sStage[0][bp_pos(s >> 8)];
+                    if (slot > 20u) { status = -6; break; }
                     unsigned sh0 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
                     s = pred_of(s, slot);
-                    if (t == 0) os[cur - 1] = (uint16_t)s;
+                    if (tau == 0) os[cur - 1] = (uint16_t)s;
                     int done = 1;
                     if (cur - 1 >= 1) {
-                        slot = sStage[1 + sh0][s >> 8];
+                        slot = sStage[1 + sh0][bp_pos(s >> 8)];
+                        if (slot > 20u) { status = -6; break; }
                         unsigned sh1 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
                         s = pred_of(s, slot);
-                        if (t == 0) os[cur - 2] = (uint16_t)s;
+                        if (tau == 0) os[cur - 2] = (uint16_t)s;
                         done = 2;
                         if (cur - 2 >= 1) {
                             const unsigned tot = sh0 + sh1;
                             const unsigned lane = tot <= 2 ? 4u + tot
                                                 : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
-                            slot = sStage[lane][s >> 8];
+                            slot = sStage[lane][bp_pos(s >> 8)];
+                            if (slot > 20u) { status = -6; break; }
                             s = pred_of(s, slot);
-                            if (t == 0) os[cur - 3] = (uint16_t)s;
+                            if (tau == 0) os[cur - 3] = (uint16_t)s;
                             done = 3;
                         }
                     }
@@ -251,8 +474,23 @@ __global__ __launch_bounds__(kThreads) void viterbi_kernel(ViterbiArgs P)
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+            if (tau == 0) {
+                P.out_logp[r] = m.v;
+                if (P.out_status) P.out_status[r] = status;
+            }
         }
-        // waves 1..3 wait for the traceback at the top-of-loop barrier; the workspace is reused
+        if (P.prof) {
+            const unsigned long long c2 = wall_clock64();
+            t_fwd += c1 - c0;
+            t_tb += c2 - c1;
+        }
+        // the other waves wait for the traceback at the top-of-loop barrier; the workspace is reused
+    }
+    if (P.prof && tau == 0) {
+        atomicAdd(&P.prof[0], t_fwd);
+        atomicAdd(&P.prof[1], t_tb);
+        atomicAdd(&P.prof[2], wall_clock64() - t_all0);
+        atomicAdd(&P.prof[3], 1ull);
     }
 }
 
@@ -263,8 +501,22 @@ void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream)
 
 int viterbi_blocks_per_cu()
 {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, viterbi_kernel, kThreads, 0) != hipSuccess || nb < 1) nb = 1;
+    // Persistent blocks pull reads from a queue and never wait on each other, so an over-estimate
+    // only leaves late blocks with an empty queue.  (The occupancy API prices LDS against 64 KiB;
+    // gfx950 has 160 KiB per CU and 512 VGPRs per lane per SIMD.)
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(viterbi_kernel)) != hipSuccess) return 1;
+    const int by_lds = fa.sharedSizeBytes > 0 ? (int)(163840 / fa.sharedSizeBytes) : 8;
+    const int regs = ((fa.numRegs + 7) / 8) * 8;
+    const int waves_per_simd = regs > 0 ? 512 / regs : 8;
+    const int by_vgpr = waves_per_simd * 4 / (kThreads / 64);
+    const int by_waves = 32 / (kThreads / 64);
+    int nb = by_lds < by_vgpr ? by_lds : by_vgpr;
+    if (by_waves < nb) nb = by_waves;
+    if (nb < 1) nb = 1;
+    if (getenv("NCHMM_DEBUG"))
+        fprintf(stderr, "[nchmm] viterbi_kernel: numRegs=%d lds=%zu -> %d blocks/CU\n", fa.numRegs,
+                (size_t)fa.sharedSizeBytes, nb);
     return nb;
 }
 
