@@ -49,6 +49,7 @@ namespace {
 
 typedef unsigned long long mask_t;
 constexpr unsigned kChunk = 256;   // events staged in LDS at a time
+constexpr int kTbRows = 6;         // back-pointer rows per traceback window (2 windows x 6 x 4 KiB = the sTab region)
 
 struct __attribute__((aligned(8))) ValSlot {
     float v;
@@ -289,8 +290,8 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     __shared__ ValSlot sV2[2][256];    // skip-group winners
     __shared__ __attribute__((aligned(16))) float4 sEv[kChunk];     // per event: x, y, 3*log y, 1/y
     ValSlot* const sRed = &sV1[0][0];  // the final arg-max reduction reuses the exchange buffer
-    __shared__ __attribute__((aligned(16))) uint8_t sStage[32][16];
     __shared__ unsigned sWork;
+    __shared__ unsigned sCarry[2];
 
     const unsigned tau = threadIdx.x;
     const unsigned t = tau >> 1, h = tau & 1u;
@@ -421,63 +422,58 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 o.s = __shfl_xor(m.s, d, 64);
                 if (o.v > m.v || (o.v == m.v && o.s < m.s)) m = o;
             }
-            // every lane of wave 0 now holds (path probability, last state)
-            uint16_t* __restrict__ os = P.out_state + e0;
-            int status = (m.s >= (unsigned)kStates) ? -6 : 0;
-            if (status == 0) {
+            if (tau == 0) {
+                sCarry[0] = m.s;
+                sCarry[1] = 0;   // error flag
+                P.out_logp[r] = m.v;
                 // this CU may still cache rows of the previous read that used this workspace
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                unsigned s = m.s;
-                int cur = (int)n - 1;
-                if (tau == 0) os[cur] = (uint16_t)s;
-                while (cur >= 1) {
-                    // rows cur, cur-1, cur-2: fetch every 16-byte group that can hold the needed byte
-                    int row; unsigned grp; bool act = true;
-                    if (tau == 0) { row = cur; grp = s & 255u; }
-                    else if (tau < 4) { row = cur - 1; grp = (s >> (2 * (tau - 1))) & 255u; }
-                    else if (tau < 7) { row = cur - 2; grp = (s >> (2 * (tau - 4))) & 255u; }
-                    else if (tau < 11) { row = cur - 2; grp = ((tau - 7) << 6) | ((s >> 6) & 63u); }
-                    else if (tau < 27) { row = cur - 2; grp = ((tau - 11) << 4) | ((s >> 8) & 15u); }
-                    else { row = 0; grp = 0; act = false; }
-                    if (act && row >= 1)
-                        *reinterpret_cast<uint4*>(&sStage[tau][0]) =
-                            *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0);   // LDS stage visible to the whole wave
-                    __builtin_amdgcn_wave_barrier();
-                    // resolve up to three steps (all lanes redundantly; uniform control flow)
-                    unsigned slot = sStage[0][bp_pos(s >> 8)];
-                    if (slot > 20u) { status = -6; break; }
-                    unsigned sh0 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
-                    s = pred_of(s, slot);
-                    if (tau == 0) os[cur - 1] = (uint16_t)s;
-                    int done = 1;
-                    if (cur - 1 >= 1) {
-                        slot = sStage[1 + sh0][bp_pos(s >> 8)];
-                        if (slot > 20u) { status = -6; break; }
-                        unsigned sh1 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
-                        s = pred_of(s, slot);
-                        if (tau == 0) os[cur - 2] = (uint16_t)s;
-                        done = 2;
-                        if (cur - 2 >= 1) {
-                            const unsigned tot = sh0 + sh1;
-                            const unsigned lane = tot <= 2 ? 4u + tot
-                                                : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
-                            slot = sStage[lane][bp_pos(s >> 8)];
-                            if (slot > 20u) { status = -6; break; }
-                            s = pred_of(s, slot);
-                            if (tau == 0) os[cur - 3] = (uint16_t)s;
-                            done = 3;
-                        }
-                    }
-                    cur -= done;
-                    __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        // ---- traceback (Viterbi.hpp:134-141): stream the back-pointer rows back through LDS with
+        // global->LDS DMA loads (no VGPR staging), kTbRows rows per window, double-buffered: the next
+        // window is in flight while wave 0 chases the current one.  One barrier per window. ----
+        {
+            uint8_t* const sRows = reinterpret_cast<uint8_t*>(&sTab[0][0]);   // 48 KiB = 2 windows x 6 rows
+            uint16_t* __restrict__ os = P.out_state + e0;
+            unsigned s = sCarry[0];
+            const bool ok = s < (unsigned)kStates;
+            int hi = (int)n - 1;            // highest row not yet consumed; rows 1..n-1 hold back-pointers
+            if (ok && tau == 0) os[hi] = (uint16_t)s;
+            auto issue = [&](int top, unsigned buf) {
+#pragma unroll
+                for (int qq = 0; qq < kTbRows / 2; ++qq) {
+                    const unsigned idx = (unsigned)qq * kThreads + tau;   // 16-byte chunk index inside the window
+                    int row = top - (int)(idx >> 8);
+                    row = row < 1 ? 1 : row;   // rows below 1 do not exist: re-load row 1 (never chased)
+                    const uint8_t* src = ws + (uint64_t)row * kStates + (idx & 255u) * 16u;
+                    uint8_t* dst = sRows + buf * (kTbRows * kStates) + ((unsigned)qq * kThreads + (tau & ~63u)) * 16u;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                 }
+            };
+            unsigned buf = 0, bad = 0;
+            if (ok && hi >= 1) issue(hi, 0);
+            while (ok && hi >= 1) {
+                const int rows = hi < kTbRows ? hi : kTbRows;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+                __syncthreads();                                    // everyone's have; previous chase is done
+                const int next_hi = hi - rows;
+                if (next_hi >= 1) issue(next_hi, buf ^ 1u);
+                if (tau < 64) {
+                    const uint8_t* win = sRows + buf * (kTbRows * kStates);
+                    for (int rr = 0; rr < rows; ++rr) {
+                        const unsigned slot = win[(unsigned)rr * kStates + ((s & 255u) << 4) + bp_pos(s >> 8)];
+                        bad |= slot > 20u ? 1u : 0u;
+                        s = pred_of(s, slot > 20u ? 0u : slot);
+                        if (tau == 0) os[hi - rr - 1] = (uint16_t)s;
+                    }
+                }
+                hi = next_hi;
+                buf ^= 1u;
             }
-            if (tau == 0) {
-                P.out_logp[r] = m.v;
-                if (P.out_status) P.out_status[r] = status;
-            }
+            if (tau == 0 && P.out_status) P.out_status[r] = (!ok || bad) ? -6 : 0;
         }
         if (P.prof) {
             const unsigned long long c2 = wall_clock64();
