@@ -115,7 +115,7 @@ def main():
         step()
         # HIP events recorded by the library around the kernel on the launch stream; reading them
         # waits for that launch only (steps are serialised on one stream anyway)
-        kernel_ms.append(ctx.last_kernel_ms()[0])
+        kernel_ms.append(ctx.last_kernel_ms()[:2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -128,13 +128,42 @@ def main():
         tk = ctx.profile_ticks()
         sys.stderr.write(f"[phase ticks, 100 MHz, summed over blocks] forward={tk[0]} traceback={tk[1]} block={tk[2]} "
                          f"blocks={tk[3]} traceback/forward={float(tk[1]) / max(float(tk[0]), 1):.3f}\n")
+        raw = ctx.profile_blocks()
+        ng = ctx.grid_slots()
+        pb = raw[:4096].reshape(2048, 2)[:ng].astype(np.int64)
+        ids = raw[4096:4096 + ng]
+        hwid = (ids & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        xcc = (ids >> np.uint64(32)).astype(np.int64) & 15
+        dur = (pb[:, 1] - pb[:, 0]) / 1e5
+        cu = (hwid >> 8) & 15
+        sh = (hwid >> 12) & 1
+        se = (hwid >> 13) & 7
+        for x in range(8):
+            m = xcc == x
+            if m.sum():
+                sys.stderr.write(f"[xcc {x}] n={m.sum()} dur mean={dur[m].mean():.2f} min={dur[m].min():.2f} max={dur[m].max():.2f}\n")
+        key = xcc * 4096 + se * 512 + sh * 256 + cu
+        import collections
+        cnt = collections.Counter(key.tolist())
+        sys.stderr.write(f"[placement] distinct CUs={len(cnt)} blocks/CU histogram={collections.Counter(cnt.values())}\n")
+        for nb in sorted(set(cnt.values())):
+            ks = [k for k, v in cnt.items() if v == nb]
+            m = np.isin(key, ks)
+            sys.stderr.write(f"[placement] CUs with {nb} blocks: mean dur {dur[m].mean():.2f} ms\n")
+        t0b = pb[:, 0].min()
+        st, en = (pb[:, 0] - t0b) / 1e5, (pb[:, 1] - t0b) / 1e5
+        sys.stderr.write(f"[blocks] start ms min/med/max = {st.min():.2f}/{np.median(st):.2f}/{st.max():.2f}  end ms min/med/max = "
+                         f"{en.min():.2f}/{np.median(en):.2f}/{en.max():.2f}  dur ms min/med/max = {(en-st).min():.2f}/{np.median(en-st):.2f}/{(en-st).max():.2f}\n")
+        q = np.percentile(en - st, [5, 25, 75, 95])
+        sys.stderr.write(f"[blocks] dur percentiles 5/25/75/95 = {q}\n")
     status = d_status.cpu().numpy()
     assert (status == 0).all(), "a read failed to decode"
 
     result = None
     if rank == 0:
         value = world * total * args.steps / dt / 1e6
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = float(np.mean([k[0] for k in kernel_ms]))
+        tb_ms = float(np.mean([k[1] for k in kernel_ms]))
         achieved = BYTES_PER_EVENT * total / (k_ms * 1e-3) / 1e9
         result = {
             "metric": "Mevents/s Viterbi (4096-state HMM)", "value": round(value, 3), "unit": "Mevents/s",
@@ -147,7 +176,7 @@ def main():
                        "grid_slots": ctx.grid_slots()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3),
+                         "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3), "traceback_kernel_ms": round(tb_ms, 3),
                          "bytes_per_event": BYTES_PER_EVENT, "events_per_launch": total},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
         }

@@ -186,14 +186,18 @@ int nchmm_fwbw_dev(nchmm_ctx* ctx, size_t n_win, size_t max_events, size_t total
  * ---------------------------------------------------------------------------------------- */
 int nchmm_counters(const nchmm_ctx* ctx, uint64_t out[8]);
 
-/* Time (ms, hipEvent) of the most recent Viterbi / FB kernel launched through this context,
- * measured on the stream it ran on.  Blocks until that kernel has finished. */
-int nchmm_last_kernel_ms(nchmm_ctx* ctx, float* viterbi_ms, float* fwbw_ms);
+/* hipEvent times (ms) of the kernels most recently launched through this context, measured on the
+ * stream they ran on: out[0] = Viterbi forward kernel, out[1] = traceback kernel (of the last
+ * sub-batch when a call was split), out[2] = forward-backward kernel, out[3] reserved.  Blocks
+ * until those kernels have finished. */
+int nchmm_last_kernel_ms(nchmm_ctx* ctx, float out[4]);
 
 /* Phase counters of the Viterbi kernel, accumulated over launches while the environment variable
  * NCHMM_PROFILE=1 was set at nchmm_create time: out[0] = forward-sweep ticks summed over blocks,
- * [1] = traceback ticks, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks). */
+ * [1] = unused, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks). */
 int nchmm_profile_ticks(nchmm_ctx* ctx, uint64_t out[4], int reset);
+/* (start, end) wall_clock64 ticks of the first 2048 blocks of the last profiled Viterbi launch */
+int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);
 
 /* number of resident thread-block slots (persistent grid size) the Viterbi kernel launches */
 int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);

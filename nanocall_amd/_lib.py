@@ -42,8 +42,9 @@ SIGNATURES = {
     "nchmm_fwbw": (C.c_int, [vp, C.c_size_t] + [vp] * 13),
     "nchmm_fwbw_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 13),
     "nchmm_counters": (C.c_int, [vp, vp]),
-    "nchmm_last_kernel_ms": (C.c_int, [vp, vp, vp]),
+    "nchmm_last_kernel_ms": (C.c_int, [vp, vp]),
     "nchmm_profile_ticks": (C.c_int, [vp, vp, C.c_int]),
+    "nchmm_profile_blocks": (C.c_int, [vp, vp]),
     "nchmm_grid_slots": (C.c_int, [vp, vp]),
 }
 

@@ -220,13 +220,19 @@ class Context:
         return out
 
     def last_kernel_ms(self):
-        v, f = C.c_float(0), C.c_float(0)
-        check(lib().nchmm_last_kernel_ms(self._h, C.byref(v), C.byref(f)), "nchmm_last_kernel_ms")
-        return v.value, f.value
+        """(viterbi forward ms, traceback ms, fwbw ms, 0) of the most recent launches (hipEvents)."""
+        out = np.zeros(4, np.float32)
+        check(lib().nchmm_last_kernel_ms(self._h, _p(out)), "nchmm_last_kernel_ms")
+        return tuple(float(x) for x in out)
 
     def profile_ticks(self, reset=True):
         out = np.zeros(4, np.uint64)
         check(lib().nchmm_profile_ticks(self._h, _p(out), int(reset)), "nchmm_profile_ticks")
+        return out
+
+    def profile_blocks(self):
+        out = np.zeros(6144, np.uint64)
+        check(lib().nchmm_profile_blocks(self._h, _p(out)), "nchmm_profile_blocks")
         return out
 
     def grid_slots(self):

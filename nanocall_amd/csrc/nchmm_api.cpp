@@ -29,14 +29,17 @@ struct nchmm_ctx {
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
     bool profile = false;
-    uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace
+    uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace (4 KiB per event of a batch)
     size_t ws_bytes = 0;
+    size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
+    unsigned* d_last_state = nullptr; // per read: arg-max state of the last column
+    size_t last_state_bytes = 0;
     float* d_fb_ws = nullptr;       // FB alpha workspace
     size_t fb_ws_floats = 0;
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
-    hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
+    hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_vit2 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
     bool vit_timed = false, fb_timed = false;
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool model_set[kMaxSlots] = {false};
@@ -178,16 +181,17 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     if ((rc = dev_alloc(c, (void**)&c->d_models, sizeof(float) * kMaxSlots * kModelFloats))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_trans, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_trans_lin, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
-    if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * 4))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * (16 + 4096)))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_model_fast, sizeof(int32_t) * kMaxSlots))) return fail(rc);
-    if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 4))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 6200))) return fail(rc);
     if (hipMemset(c->d_model_fast, 0, sizeof(int32_t) * kMaxSlots) != hipSuccess) return fail(NCHMM_E_HIP);
-    if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 4) != hipSuccess) return fail(NCHMM_E_HIP);
+    if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 6200) != hipSuccess) return fail(NCHMM_E_HIP);
     {
         const char* e = std::getenv("NCHMM_PROFILE");
         c->profile = e && e[0] == '1';
     }
     if (hipEventCreate(&c->ev_vit0) != hipSuccess || hipEventCreate(&c->ev_vit1) != hipSuccess
+        || hipEventCreate(&c->ev_vit2) != hipSuccess
         || hipEventCreate(&c->ev_fb0) != hipSuccess || hipEventCreate(&c->ev_fb1) != hipSuccess)
         return fail(NCHMM_E_HIP);
     c->vit_slots = c->n_cu * viterbi_blocks_per_cu();
@@ -208,10 +212,12 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_model_fast) (void)hipFree(c->d_model_fast);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_last_state) (void)hipFree(c->d_last_state);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->ev_vit0) (void)hipEventDestroy(c->ev_vit0);
     if (c->ev_vit1) (void)hipEventDestroy(c->ev_vit1);
+    if (c->ev_vit2) (void)hipEventDestroy(c->ev_vit2);
     if (c->ev_fb0) (void)hipEventDestroy(c->ev_fb0);
     if (c->ev_fb1) (void)hipEventDestroy(c->ev_fb1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -287,44 +293,101 @@ int nchmm_put_transitions(nchmm_ctx* c, int slot, const uint32_t* row_ptr, const
     return NCHMM_OK;
 }
 
-int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
+}  // extern "C" (reopened below)
+
+namespace {
+
+// Launch forward + traceback for reads [first, first + count) whose events start at ev_base and
+// number ev_count.  d_order (may be null) is a permutation of exactly these reads.
+int launch_batch(nchmm_ctx* c, size_t first, size_t count, uint64_t ev_base, uint64_t ev_count, const uint64_t* d_off,
+                 const float* d_cmean, const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot,
+                 const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp,
+                 int32_t* d_out_status)
+{
+    ViterbiArgs a;
+    a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
+    a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
+    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
+    a.prof = c->profile ? c->d_prof : nullptr;
+    a.ws = c->d_ws; a.ev_base = ev_base; a.first_read = (unsigned)first; a.last_state = c->d_last_state;
+    a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
+    a.queue = c->d_queue; a.cu_progress = c->d_queue + 16; a.n_reads = (unsigned)count;
+    a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
+    a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
+    const int grid = (int)std::min<size_t>((size_t)c->vit_slots, count);
+    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (16 + 4096), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_vit0, c->stream));
+    launch_viterbi(a, grid, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_vit1, c->stream));
+    launch_traceback(a, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_vit2, c->stream));
+    c->vit_timed = true;
+    c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kStates;
+    c->counters[3] += 2;
+    return NCHMM_OK;
+}
+
+}  // namespace
+
+extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
                       const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                       const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
                       uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
 {
     if (!c) return NCHMM_E_INVALID;
     if (n_reads == 0) return NCHMM_OK;
-    if (!d_off || !d_out_logp || n_reads > 0xFFFFFFF0ull) return NCHMM_E_INVALID;
+    if (!d_off || !d_out_logp || n_reads > 0xFFFFFFF0ull || max_events > 0x7FFFFFF0ull) return NCHMM_E_INVALID;
     if (total_events && (!d_cmean || !d_stdv || !d_lstdv || !d_out_state)) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    const int grid = (int)std::min<size_t>((size_t)c->vit_slots, n_reads);
-    const uint64_t stride = (uint64_t)std::max<size_t>(max_events, 1) * kStates;
-    void* p = c->d_ws;
-    int rc = ensure(c, &p, &c->ws_bytes, (size_t)stride * (size_t)c->vit_slots);
-    c->d_ws = (uint8_t*)p;
+    void* p = c->d_last_state;
+    int rc = ensure(c, &p, &c->last_state_bytes, sizeof(unsigned) * n_reads);
+    c->d_last_state = (unsigned*)p;
     if (rc != NCHMM_OK) return rc;
-    ViterbiArgs a;
-    a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
-    a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
-    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
-    a.prof = c->profile ? c->d_prof : nullptr;
-    a.ws = c->d_ws; a.ws_stride = stride;
-    a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
-    a.queue = c->d_queue; a.n_reads = (unsigned)n_reads;
-    a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
-    a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
-    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_vit0, c->stream));
-    launch_viterbi(a, grid, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_vit1, c->stream));
-    c->vit_timed = true;
+    // Back-pointer workspace: 4 KiB per event.  When the whole batch fits the budget it is one
+    // forward + one traceback launch; otherwise the batch is cut into contiguous read ranges.
+    if (c->ws_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        const char* e = std::getenv("NCHMM_WS_BUDGET_MB");
+        c->ws_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : (free_b / 10) * 7;
+        if (c->ws_budget < ((size_t)64 << 20)) c->ws_budget = (size_t)64 << 20;
+    }
+    const size_t need_all = std::max<size_t>(total_events, 1) * (size_t)kStates;
     c->counters[0] += n_reads;
     c->counters[1] += total_events;
-    c->counters[2] += (uint64_t)(total_events > n_reads ? total_events - n_reads : 0) * kStates;
-    c->counters[3] += 1;
+    if (need_all <= std::max(c->ws_budget, c->ws_bytes)) {
+        p = c->d_ws;
+        rc = ensure(c, &p, &c->ws_bytes, need_all);
+        c->d_ws = (uint8_t*)p;
+        if (rc != NCHMM_OK) return rc;
+        return launch_batch(c, 0, n_reads, 0, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
+                            d_order, d_out_state, d_out_logp, d_out_status);
+    }
+    // split: needs the offsets on the host (small copy), reads are taken in input order
+    std::vector<uint64_t> off(n_reads + 1);
+    HIP_TRY(c, hipMemcpyAsync(off.data(), d_off, sizeof(uint64_t) * (n_reads + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t budget_events = std::max<uint64_t>(c->ws_budget / kStates, max_events);
+    p = c->d_ws;
+    rc = ensure(c, &p, &c->ws_bytes, (size_t)budget_events * kStates);
+    c->d_ws = (uint8_t*)p;
+    if (rc != NCHMM_OK) return rc;
+    size_t first = 0;
+    while (first < n_reads) {
+        size_t last = first;
+        while (last < n_reads && off[last + 1] - off[first] <= budget_events) ++last;
+        if (last == first) return NCHMM_E_NOMEM;   // a single read larger than the workspace
+        rc = launch_batch(c, first, last - first, off[first], off[last] - off[first], d_off, d_cmean, d_stdv, d_lstdv,
+                          d_model_slot, d_trans_slot, nullptr, d_out_state, d_out_logp, d_out_status);
+        if (rc != NCHMM_OK) return rc;
+        first = last;
+    }
     return NCHMM_OK;
 }
+
+extern "C" {
 
 int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float* cmean, const float* stdv,
                   const float* lstdv, const int32_t* model_slot, const int32_t* trans_slot,
@@ -393,24 +456,29 @@ int nchmm_counters(const nchmm_ctx* c, uint64_t out[8])
     return NCHMM_OK;
 }
 
-int nchmm_last_kernel_ms(nchmm_ctx* c, float* vit_ms, float* fb_ms)
+int nchmm_last_kernel_ms(nchmm_ctx* c, float out[4])
 {
-    if (!c) return NCHMM_E_INVALID;
+    if (!c || !out) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (vit_ms) {
-        *vit_ms = 0;
-        if (c->vit_timed) {
-            HIP_TRY(c, hipEventSynchronize(c->ev_vit1));
-            HIP_TRY(c, hipEventElapsedTime(vit_ms, c->ev_vit0, c->ev_vit1));
-        }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (c->vit_timed) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_vit2));
+        HIP_TRY(c, hipEventElapsedTime(&out[0], c->ev_vit0, c->ev_vit1));
+        HIP_TRY(c, hipEventElapsedTime(&out[1], c->ev_vit1, c->ev_vit2));
     }
-    if (fb_ms) {
-        *fb_ms = 0;
-        if (c->fb_timed) {
-            HIP_TRY(c, hipEventSynchronize(c->ev_fb1));
-            HIP_TRY(c, hipEventElapsedTime(fb_ms, c->ev_fb0, c->ev_fb1));
-        }
+    if (c->fb_timed) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_fb1));
+        HIP_TRY(c, hipEventElapsedTime(&out[2], c->ev_fb0, c->ev_fb1));
     }
+    return NCHMM_OK;
+}
+
+int nchmm_profile_blocks(nchmm_ctx* c, uint64_t* out /* 6144: 2048 x (start, end) ticks, then 2048 x (xcc << 32 | hw_id) */)
+{
+    if (!c || !out) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_prof + 8, sizeof(uint64_t) * 6144, hipMemcpyDeviceToHost));
     return NCHMM_OK;
 }
 

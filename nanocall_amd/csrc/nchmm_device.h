@@ -33,8 +33,11 @@ struct ViterbiArgs {
     const float* trans;        // [kMaxSlots][kTransFloats]
     const int32_t* model_fast; // [kMaxSlots] 1 = parameters inside the range the reciprocal division is proven for
     unsigned long long* prof;  // optional [4]: forward ticks, traceback ticks, block ticks, blocks (wall_clock64)
-    uint8_t* ws;               // back-pointer workspace, one region per block slot
-    uint64_t ws_stride;        // bytes per block slot (>= max_events * 4096)
+    uint8_t* ws;               // back-pointer workspace: one 4 KiB row per event of the (sub-)batch
+    uint64_t ev_base;          // off[first_read]: event index of the first row of the workspace
+    unsigned first_read;       // reads [first_read, first_read + n_reads) form this (sub-)batch
+    unsigned* cu_progress;     // [4096] per (CU, block slot) events done in this launch; zeroed before launch
+    unsigned* last_state;      // [n_reads_total] arg-max state of the last column (forward -> traceback)
     uint16_t* out_state;
     float* out_logp;
     int32_t* out_status;
@@ -45,6 +48,7 @@ struct ViterbiArgs {
 };
 
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream);
+void launch_traceback(const ViterbiArgs& a, hipStream_t stream);
 int viterbi_blocks_per_cu();
 
 struct FwbwArgs {

@@ -31,8 +31,10 @@
 //     ws + i*4096, state j at byte (t<<4) | (h<<3) | (x<<1) | (y>>1): each thread stores its 8
 //     bytes as one dwordx2 (a wave writes 512 B contiguous), and the 21 candidates of the next
 //     traceback step sit in three 16-byte groups.
-//   * Traceback: wave 0 resolves three events per memory round trip by fetching every 16-byte
-//     group that can hold the byte of rows i, i-1, i-2 (27 lanes x 16 B).
+//   * Traceback is a second kernel (traceback_kernel, one wave per read, every read of the batch
+//     at once): the chase is a dependent pointer walk, so it is latency-bound and wants many reads
+//     in flight rather than CUs parked behind a barrier.  Each round trip fetches every 16-byte
+//     group that can hold the byte of rows i, i-1, i-2 (27 lanes x 16 B) and resolves three events.
 //
 // Float contract: -ffp-contract=off (the only FMAs are the explicit residual corrections and the
 // next-float probe), denormals on, no device log/exp: every log comes from the host libm.
@@ -49,7 +51,6 @@ namespace {
 
 typedef unsigned long long mask_t;
 constexpr unsigned kChunk = 256;   // events staged in LDS at a time
-constexpr int kTbRows = 6;         // back-pointer rows per traceback window (2 windows x 6 x 4 KiB = the sTab region)
 
 struct __attribute__((aligned(8))) ValSlot {
     float v;
@@ -291,13 +292,26 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     __shared__ __attribute__((aligned(16))) float4 sEv[kChunk];     // per event: x, y, 3*log y, 1/y
     ValSlot* const sRed = &sV1[0][0];  // the final arg-max reduction reuses the exchange buffer
     __shared__ unsigned sWork;
-    __shared__ unsigned sCarry[2];
 
     const unsigned tau = threadIdx.x;
     const unsigned t = tau >> 1, h = tau & 1u;
-    uint8_t* const ws = P.ws + (uint64_t)blockIdx.x * P.ws_stride;
     unsigned long long t_fwd = 0, t_tb = 0, t_all0 = 0;
     if (P.prof) t_all0 = wall_clock64();
+    // Two blocks share a CU and the older block's waves win issue arbitration (age), which makes one
+    // block ~25 % faster than its neighbour; with two reads per block that idles half of every CU at
+    // the end.  Priority outranks age, so every 256 events each block publishes how many events it
+    // has done (one word per CU slot) and the one that is behind raises its priority.
+    unsigned* my_progress = nullptr;
+    const unsigned* other_progress = nullptr;
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+        const unsigned cu = ((xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u)) & 2047u;
+        const unsigned upper = ((hw & 15u) >> 1) & 1u;   // this block sits in wave slots 2,3 of each SIMD
+        my_progress = P.cu_progress + 2u * cu + upper;
+        other_progress = P.cu_progress + 2u * cu + (upper ^ 1u);
+    }
+    unsigned done_events = 0;
 
     for (;;) {
         if (tau == 0) sWork = atomicAdd(P.queue, 1u);
@@ -305,13 +319,13 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         const unsigned widx = sWork;
         __syncthreads();
         if (widx >= P.n_reads) break;
-        const unsigned r = __builtin_amdgcn_readfirstlane(P.order ? P.order[widx] : widx);
+        const unsigned r = __builtin_amdgcn_readfirstlane(P.order ? P.order[widx] : P.first_read + widx);
         const uint64_t e0 = P.off[r];
         const unsigned n = (unsigned)(P.off[r + 1] - e0);
         if (n == 0) {
             if (tau == 0) {
                 P.out_logp[r] = __builtin_nanf("");
-                if (P.out_status) P.out_status[r] = 0;
+                P.last_state[r] = kNoState;
             }
             continue;
         }
@@ -325,6 +339,8 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         const float* __restrict__ ex = P.cmean + e0;
         const float* __restrict__ ey = P.stdv + e0;
         const float* __restrict__ el = P.lstdv + e0;
+        // back-pointer row i of this read: one 4 KiB row per event of the batch, in event order
+        uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
 
         State S;
 #pragma unroll
@@ -347,6 +363,14 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         S.w2 = W[kStates + 1024 + t];
 
         for (unsigned base = 0; base < n; base += kChunk) {
+            {
+                // wave-uniform: every wave of the block reads the same two words
+                if ((tau & 63u) == 0) __hip_atomic_store(my_progress, done_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned other = __hip_atomic_load(other_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(other) > done_events) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+                done_events += kChunk;
+            }
             // stage the next kChunk events: x, y, 3 log y, 1/y (one correctly rounded divide per event)
             const unsigned ie = base + tau;
             bool ok = true;
@@ -423,57 +447,9 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 if (o.v > m.v || (o.v == m.v && o.s < m.s)) m = o;
             }
             if (tau == 0) {
-                sCarry[0] = m.s;
-                sCarry[1] = 0;   // error flag
-                P.out_logp[r] = m.v;
-                // this CU may still cache rows of the previous read that used this workspace
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                P.out_logp[r] = m.v;                  // Viterbi::path_probability(), Viterbi.hpp:133
+                P.last_state[r] = m.s;                // kStates when every state is -INF/NaN
             }
-        }
-        __syncthreads();
-        // ---- traceback (Viterbi.hpp:134-141): stream the back-pointer rows back through LDS with
-        // global->LDS DMA loads (no VGPR staging), kTbRows rows per window, double-buffered: the next
-        // window is in flight while wave 0 chases the current one.  One barrier per window. ----
-        {
-            uint8_t* const sRows = reinterpret_cast<uint8_t*>(&sTab[0][0]);   // 48 KiB = 2 windows x 6 rows
-            uint16_t* __restrict__ os = P.out_state + e0;
-            unsigned s = sCarry[0];
-            const bool ok = s < (unsigned)kStates;
-            int hi = (int)n - 1;            // highest row not yet consumed; rows 1..n-1 hold back-pointers
-            if (ok && tau == 0) os[hi] = (uint16_t)s;
-            auto issue = [&](int top, unsigned buf) {
-#pragma unroll
-                for (int qq = 0; qq < kTbRows / 2; ++qq) {
-                    const unsigned idx = (unsigned)qq * kThreads + tau;   // 16-byte chunk index inside the window
-                    int row = top - (int)(idx >> 8);
-                    row = row < 1 ? 1 : row;   // rows below 1 do not exist: re-load row 1 (never chased)
-                    const uint8_t* src = ws + (uint64_t)row * kStates + (idx & 255u) * 16u;
-                    uint8_t* dst = sRows + buf * (kTbRows * kStates) + ((unsigned)qq * kThreads + (tau & ~63u)) * 16u;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                }
-            };
-            unsigned buf = 0, bad = 0;
-            if (ok && hi >= 1) issue(hi, 0);
-            while (ok && hi >= 1) {
-                const int rows = hi < kTbRows ? hi : kTbRows;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-                __syncthreads();                                    // everyone's have; previous chase is done
-                const int next_hi = hi - rows;
-                if (next_hi >= 1) issue(next_hi, buf ^ 1u);
-                if (tau < 64) {
-                    const uint8_t* win = sRows + buf * (kTbRows * kStates);
-                    for (int rr = 0; rr < rows; ++rr) {
-                        const unsigned slot = win[(unsigned)rr * kStates + ((s & 255u) << 4) + bp_pos(s >> 8)];
-                        bad |= slot > 20u ? 1u : 0u;
-                        s = pred_of(s, slot > 20u ? 0u : slot);
-                        if (tau == 0) os[hi - rr - 1] = (uint16_t)s;
-                    }
-                }
-                hi = next_hi;
-                buf ^= 1u;
-            }
-            if (tau == 0 && P.out_status) P.out_status[r] = (!ok || bad) ? -6 : 0;
         }
         if (P.prof) {
             const unsigned long long c2 = wall_clock64();
@@ -487,12 +463,90 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         atomicAdd(&P.prof[1], t_tb);
         atomicAdd(&P.prof[2], wall_clock64() - t_all0);
         atomicAdd(&P.prof[3], 1ull);
+        if (blockIdx.x < 2048) {
+            const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            P.prof[8 + 2 * blockIdx.x] = t_all0;
+            P.prof[8 + 4096 + blockIdx.x] = ((unsigned long long)xcc << 32) | hwid;
+            P.prof[9 + 2 * blockIdx.x] = wall_clock64();
+        }
     }
+}
+
+// Viterbi::fill_state_seq, Viterbi.hpp:134-141: follow the back-pointers from the last state.
+// One wave per read.  Per round trip the wave fetches every 16-byte group that can hold the byte it
+// will need in rows cur, cur-1, cur-2 (1 + 3 + 23 groups) and then resolves three events from LDS.
+__global__ __launch_bounds__(64) void traceback_kernel(ViterbiArgs P)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sStage[32][16];
+    const unsigned tau = threadIdx.x;
+    const unsigned r = P.first_read + blockIdx.x;
+    const uint64_t e0 = P.off[r];
+    const unsigned n = (unsigned)(P.off[r + 1] - e0);
+    if (n == 0) {
+        if (tau == 0 && P.out_status) P.out_status[r] = 0;
+        return;
+    }
+    const uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
+    uint16_t* __restrict__ os = P.out_state + e0;
+    unsigned s = P.last_state[r];
+    int status = (s >= (unsigned)kStates) ? -6 : 0;
+    if (status == 0) {
+        int cur = (int)n - 1;
+        if (tau == 0) os[cur] = (uint16_t)s;
+        while (cur >= 1) {
+            int row; unsigned grp; bool act = true;
+            if (tau == 0) { row = cur; grp = s & 255u; }
+            else if (tau < 4) { row = cur - 1; grp = (s >> (2 * (tau - 1))) & 255u; }
+            else if (tau < 7) { row = cur - 2; grp = (s >> (2 * (tau - 4))) & 255u; }
+            else if (tau < 11) { row = cur - 2; grp = ((tau - 7) << 6) | ((s >> 6) & 63u); }
+            else if (tau < 27) { row = cur - 2; grp = ((tau - 11) << 4) | ((s >> 8) & 15u); }
+            else { row = 0; grp = 0; act = false; }
+            if (act && row >= 1)
+                *reinterpret_cast<uint4*>(&sStage[tau][0]) =
+                    *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0);   // LDS stage visible to the whole wave
+            __builtin_amdgcn_wave_barrier();
+            // resolve up to three steps (all lanes redundantly; uniform control flow)
+            unsigned slot = sStage[0][bp_pos(s >> 8)];
+            if (slot > 20u) { status = -6; break; }
+            const unsigned sh0 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
+            s = pred_of(s, slot);
+            if (tau == 0) os[cur - 1] = (uint16_t)s;
+            int done = 1;
+            if (cur - 1 >= 1) {
+                slot = sStage[1 + sh0][bp_pos(s >> 8)];
+                if (slot > 20u) { status = -6; break; }
+                const unsigned sh1 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
+                s = pred_of(s, slot);
+                if (tau == 0) os[cur - 2] = (uint16_t)s;
+                done = 2;
+                if (cur - 2 >= 1) {
+                    const unsigned tot = sh0 + sh1;
+                    const unsigned lane = tot <= 2 ? 4u + tot
+                                        : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
+                    slot = sStage[lane][bp_pos(s >> 8)];
+                    if (slot > 20u) { status = -6; break; }
+                    s = pred_of(s, slot);
+                    if (tau == 0) os[cur - 3] = (uint16_t)s;
+                    done = 3;
+                }
+            }
+            cur -= done;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (tau == 0 && P.out_status) P.out_status[r] = status;
 }
 
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(viterbi_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
+}
+
+void launch_traceback(const ViterbiArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(traceback_kernel, dim3(a.n_reads), dim3(64), 0, stream, a);
 }
 
 int viterbi_blocks_per_cu()
