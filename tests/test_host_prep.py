@@ -1,0 +1,91 @@
+"""The product's host-side prep (C++ in libnanocall_hip.so, no GPU) against the CPU oracle: bit-exact."""
+import numpy as np
+import pytest
+
+import nanocall_amd as na
+from nanocall_amd import synth
+import nc_oracle as oracle
+
+PARAM_SETS = [(1.0, 0.0, 0.0, 1.0, 1.0, 1.0), (1.05, 2.5, 0.002, 1.1, 0.9, 1.2), (0.93, -4.0, -0.001, 0.8, 1.3, 0.7)]
+
+
+@pytest.mark.parametrize("model", range(6))
+def test_model_load_and_scale_bit_exact(model):
+    t = na.builtin_model(model)
+    st = na.model_load(t)
+    assert np.array_equal(st.view(np.uint32), oracle.Model(t).states().view(np.uint32))
+    for p in PARAM_SETS:
+        a = na.model_scale(st, p)
+        b = oracle.Model(t, p)
+        assert np.array_equal(a.view(np.uint32), b.states().view(np.uint32))
+        assert np.array_equal(na.model_pack6(a).view(np.uint32), b.table6().view(np.uint32))
+    # scaling twice composes like the reference (logs are added, not recomputed)
+    a2 = na.model_scale(na.model_scale(st, PARAM_SETS[1]), PARAM_SETS[2])
+    b2 = oracle.Model(t, PARAM_SETS[1]); b2.scale(PARAM_SETS[2])
+    assert np.array_equal(a2.view(np.uint32), b2.states().view(np.uint32))
+
+
+@pytest.mark.parametrize("pp", [(0.3, 0.1), (0.28, 0.09), (0.17, 0.12), (0.05, 0.4), (0.4, 0.05)])
+def test_transitions_fast_bit_exact(pp):
+    rp, pred, w = na.transitions_fast(*pp)
+    rp2, idx2, w2 = oracle.Transitions(*pp).from_csr()
+    assert np.array_equal(rp, rp2) and np.array_equal(pred, idx2.astype(np.uint16))
+    assert np.array_equal(w.view(np.uint32), w2.view(np.uint32))
+
+
+def test_events_prepare_bit_exact(r73t):
+    ev = synth.generate(r73t, 1, 500, first_read=3)
+    mean, stdv, start = ev["mean"][0], ev["stdv"][0].copy(), ev["start"][0]
+    stdv[::9] = 0.0
+    for drift in (0.0, 0.002, -0.01):
+        a = na.events_prepare(mean, stdv, start, drift)
+        b = oracle.events_prepare(mean, stdv, start, drift)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    cm, sd, ls = na.events_prepare(mean, stdv, None, 0.0)
+    assert np.array_equal(cm, mean) and (sd[::9] == np.float32(0.01)).all()
+
+
+def test_empty_and_single_event_inputs():
+    cm, sd, ls = na.events_prepare(np.zeros(0, np.float32), np.zeros(0, np.float32))
+    assert cm.size == sd.size == ls.size == 0
+    mv, seq = na.base_seq(np.zeros(0, np.uint16))
+    assert mv.size == 0 and seq == ""
+    mv, seq = na.base_seq(np.array([0b000110110001], np.uint16))
+    assert mv.tolist() == [0] and seq == "ACGTAC"
+
+
+def test_base_seq_and_fasta_match_oracle():
+    rng = np.random.default_rng(5)
+    # a plausible path: stay / step / skip moves plus a few arbitrary jumps (move 6)
+    k = int(rng.integers(4096)); path = [k]
+    for _ in range(3000):
+        u = rng.random()
+        if u < 0.1: pass
+        elif u < 0.7: k = ((k << 2) | int(rng.integers(4))) & 4095
+        elif u < 0.97: k = ((k << 4) | int(rng.integers(16))) & 4095
+        else: k = int(rng.integers(4096))
+        path.append(k)
+    path = np.array(path, np.uint16)
+    mv, seq = na.base_seq(path)
+    omv = np.array([0] + [oracle.lib().nco_kmer_min_skip(int(a), int(b)) for a, b in zip(path[:-1], path[1:])], np.int32)
+    assert np.array_equal(mv, omv)
+    assert seq == oracle.base_seq(path, omv)
+    for width in (80, 60, 1, 10000):
+        assert na.write_fasta("read:file:0", seq, width) == oracle.write_fasta("read:file:0", seq, width)
+    assert na.write_fasta("x", "", 80) == ">x\n"
+
+
+def test_st_train_kmers_match_oracle():
+    a, b = na.st_train_kmers(), oracle.st_train_kmers()
+    assert np.array_equal(a.astype(np.uint32), b)
+    assert 0 < len(a) < 4096
+
+
+def test_error_codes_not_exceptions():
+    from nanocall_amd._lib import lib
+    L = lib()
+    assert L.nchmm_model_load(None, None) == -1
+    assert L.nchmm_transitions_fast(0.3, 0.1, None, None, None, None) == -1
+    assert b"invalid" in L.nchmm_strerror(-1)
+    assert L.nchmm_abi_version() >= 1

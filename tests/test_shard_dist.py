@@ -1,0 +1,60 @@
+"""Multi-GPU path on CPU: read sharding + the one counter all-reduce, world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nanocall_amd import shard
+
+
+def test_lpt_partition_balances_and_covers():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(10, 50000, size=1000)
+    for ws in (1, 2, 4, 8):
+        parts = shard.lpt_partition(lens, ws)
+        allidx = np.concatenate(parts)
+        assert sorted(allidx.tolist()) == list(range(1000))
+        loads = np.array([lens[p].sum() for p in parts])
+        assert loads.max() - loads.min() <= lens.max()
+    # equal lengths (BASELINE config 4): contiguous slices
+    parts = shard.lpt_partition(np.full(100000, 5000), 8)
+    assert [len(p) for p in parts] == [12500] * 8 and all((np.diff(p) == 1).all() for p in parts)
+    assert shard.lpt_partition([], 2)[0].size == 0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = np.arange(1, 41) * 100
+    mine = shard.lpt_partition(lens, world)[rank]
+    local = np.array([len(mine), int(lens[mine].sum()), 0, 1, 0, 0, 0, 0], np.uint64)
+    tot = shard.gather_counters(local)
+    mx = shard.max_over_ranks(1.0 + rank)
+    q.put((rank, tot.tolist(), mx, mine.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_counter_gather():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    lens = np.arange(1, 41) * 100
+    seen = []
+    for rank, tot, mx, mine in res:
+        assert tot[0] == 40 and tot[1] == int(lens.sum()) and tot[3] == world
+        assert mx == 2.0
+        seen += mine
+    assert sorted(seen) == list(range(40))

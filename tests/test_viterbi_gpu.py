@@ -140,3 +140,65 @@ def test_unset_slot_is_an_error(gpu_ctx, r73t):
     off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [10])
     with pytest.raises(na.api.NchmmError):
         gpu_ctx.viterbi(off, cm, sd, ls, model_slot=np.array([63], np.int32), trans_slot=np.array([63], np.int32))
+
+
+def test_committed_golden_fixtures(gpu_ctx):
+    """tests/golden/viterbi_*.npz (inputs + expected states / moves / sequence / FASTA / log-prob bits)."""
+    import glob
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    files = sorted(glob.glob(os.path.join(G, "viterbi_*.npz")))
+    assert len(files) >= 6
+    for slot, path in enumerate(files):
+        z = np.load(path)
+        table = na.builtin_model(str(z["model"]))
+        params = z["params"]
+        cm, sd, ls = na.events_prepare(z["mean"], z["stdv"], z["start"], float(params[2]))
+        off = np.array([0, len(cm)], np.uint64)
+        states, logp, status = _run(gpu_ctx, table, params, float(z["p_skip"]), float(z["p_stay"]), off, cm, sd, ls, slot=slot)
+        assert np.array_equal(states, z["states"]), path
+        assert logp.view(np.uint32)[0] == z["path_logp_bits"], path
+        mv, seq = na.base_seq(states)
+        assert np.array_equal(mv, z["moves"]) and seq == str(z["seq"])
+        name = os.path.basename(path)[8:-4]
+        assert na.write_fasta(name + ":synthetic:0", seq, 80) == str(z["fasta"])
+
+
+def test_out_of_range_model_takes_true_division_path(gpu_ctx, r73t):
+    """A model outside the validated range of the reciprocal division (tiny sigma) must still be
+    bit-exact: the kernel switches to IEEE division for it."""
+    t = r73t.copy()
+    t[:, 1] *= np.float32(2.0 ** -12)      # level_stdv ~ 2e-4 < 2^-10
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [120], first_read=2)
+    states, logp, _ = _run(gpu_ctx, t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+    # and an event outside the per-event range (huge stdv) in an otherwise normal read
+    sd2 = sd.copy(); sd2[57] = np.float32(5000.0)
+    ls2 = ls.copy(); ls2[57] = np.float32(np.log(np.float32(5000.0)))
+    states, logp, _ = _run(gpu_ctx, r73t, IDENT, 0.3, 0.1, off, cm, sd2, ls2)
+    ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd2, ls2)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+
+
+def test_workspace_split_into_sub_batches(r73t):
+    """With a tiny workspace budget a call is cut into several forward+traceback launches."""
+    import os
+    os.environ["NCHMM_WS_BUDGET_MB"] = "64"       # 16 384 events per launch
+    try:
+        ctx = na.Context(0)
+    finally:
+        del os.environ["NCHMM_WS_BUDGET_MB"]
+    lens = [9000, 5000, 7000, 3, 12000, 800]
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=40)
+    ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+    ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    states, logp, status = ctx.viterbi(off, cm, sd, ls)
+    assert ctx.counters()[3] >= 6                   # at least three (forward, traceback) pairs
+    ctx.close()
+    for r in (0, 3, 4, 5):
+        a, b = int(off[r]), int(off[r + 1])
+        os_, ol = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, np.array([0, b - a], np.uint64), cm[a:b], sd[a:b], ls[a:b])
+        assert np.array_equal(states[a:b], os_) and logp[r].tobytes() == ol[0].tobytes()
