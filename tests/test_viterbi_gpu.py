@@ -186,16 +186,16 @@ def test_out_of_range_model_takes_true_division_path(gpu_ctx, r73t):
 def test_workspace_split_into_sub_batches(r73t):
     """With a tiny workspace budget a call is cut into several forward+traceback launches."""
     import os
-    os.environ["NCHMM_WS_BUDGET_MB"] = "64"       # 16 384 events per launch
-    try:
-        ctx = na.Context(0)
-    finally:
-        del os.environ["NCHMM_WS_BUDGET_MB"]
+    os.environ["NCHMM_WS_BUDGET_MB"] = "64"       # 16 384 events per launch (read at the first Viterbi call)
     lens = [9000, 5000, 7000, 3, 12000, 800]
     off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=40)
-    ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
-    ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
-    states, logp, status = ctx.viterbi(off, cm, sd, ls)
+    try:
+        ctx = na.Context(0)
+        ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        states, logp, status = ctx.viterbi(off, cm, sd, ls)
+    finally:
+        del os.environ["NCHMM_WS_BUDGET_MB"]
     assert ctx.counters()[3] >= 6                   # at least three (forward, traceback) pairs
     ctx.close()
     for r in (0, 3, 4, 5):
