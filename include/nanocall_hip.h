@@ -94,6 +94,17 @@ int nchmm_write_fasta(const char* name, const char* seq, unsigned line_width, ch
 /* Parameter_Trainer::init / st_train_kmers, Parameter_Trainer.hpp:30-63.  out holds <= 4096. */
 int nchmm_st_train_kmers(uint16_t* out, uint32_t* count);
 
+/* Parameter_Trainer::train_pm_params, Parameter_Trainer.hpp:297-427, from the per-event inner sums
+ * {s0,s1,s2,l0,l1,l2} that nchmm_fwbw produces (concatenated over the training windows of a round, in
+ * window order) and the UNCORRECTED events of those windows.  new_pm = {scale, shift, drift, var,
+ * scale_sd, var_sd}; *done = 1 when the normal matrix is singular (new_pm = crt_pm, :355-360). */
+int nchmm_train_pm_finish(size_t n_events, const float* pm_sums_nx6, const float* mean, const float* stdv,
+                          const float* start, int train_drift, const float crt_pm[6], float new_pm[6], int* done);
+
+/* Parameter_Trainer::train_st_params, Parameter_Trainer.hpp:516-530, for one strand: combines the
+ * {denom, stay_num, skip_num} log-sums of that strand's windows and applies the [.05, .4] reset. */
+int nchmm_train_st_finish(size_t n_win, const float* st_sums_nx3, float* p_stay, float* p_skip);
+
 /* ------------------------------------------------------------------------------------------
  * Device context
  * ---------------------------------------------------------------------------------------- */

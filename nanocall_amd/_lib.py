@@ -30,6 +30,8 @@ SIGNATURES = {
     "nchmm_base_seq": (C.c_int, [C.c_size_t, vp, vp, vp, vp]),
     "nchmm_write_fasta": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint, vp, C.c_size_t, vp]),
     "nchmm_st_train_kmers": (C.c_int, [vp, vp]),
+    "nchmm_train_pm_finish": (C.c_int, [C.c_size_t, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
+    "nchmm_train_st_finish": (C.c_int, [C.c_size_t, vp, vp, vp]),
     "nchmm_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "nchmm_destroy": (C.c_int, [vp]),
     "nchmm_last_hip_error": (C.c_int, [vp]),

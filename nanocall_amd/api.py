@@ -103,6 +103,27 @@ def st_train_kmers():
     return out[: n.value].copy()
 
 
+def train_pm_finish(pm_sums, mean, stdv, start, crt_pm, train_drift=True):
+    """train_pm_params' host half -> (new_pm[6], done)."""
+    pm = _f32(pm_sums).reshape(-1, 6)
+    n = pm.shape[0]
+    mean, stdv = _f32(mean), _f32(stdv)
+    start = None if start is None else _f32(start)
+    new = np.empty(6, np.float32)
+    done = C.c_int(0)
+    check(lib().nchmm_train_pm_finish(n, _p(pm), _p(mean), _p(stdv), _p(start), int(train_drift),
+                                      _p(_f32(crt_pm).reshape(6)), _p(new), C.byref(done)), "nchmm_train_pm_finish")
+    return new, bool(done.value)
+
+
+def train_st_finish(st_sums):
+    """train_st_params' host half for one strand -> (p_stay, p_skip)."""
+    st = _f32(st_sums).reshape(-1, 3)
+    a, b = C.c_float(0), C.c_float(0)
+    check(lib().nchmm_train_st_finish(st.shape[0], _p(st), C.byref(a), C.byref(b)), "nchmm_train_st_finish")
+    return a.value, b.value
+
+
 # ------------------------------------------------------------------------------------------------
 # device context
 # ------------------------------------------------------------------------------------------------

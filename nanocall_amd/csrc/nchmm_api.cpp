@@ -24,7 +24,8 @@ struct nchmm_ctx {
     int fb_slots = 0;
     float* d_models = nullptr;      // [kMaxSlots][kModelFloats]
     float* d_trans = nullptr;       // [kMaxSlots][kTransFloats]   log-space w0|w1|w2
-    float* d_trans_lin = nullptr;   // [kMaxSlots][kTransFloats]   exp() of the above (host libm), FB only
+    float* d_trans_fb = nullptr;    // [kMaxSlots][kFbTransFloats] per-state forward/backward weights for FB
+    uint8_t* d_train_mask = nullptr; // [512] transition-training k-mers, one bit per state
     unsigned* d_queue = nullptr;    // [2] work-queue heads (viterbi, fwbw)
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
@@ -142,6 +143,40 @@ int factor_transitions(const uint32_t* row_ptr, const uint16_t* pred, const floa
     return NCHMM_OK;
 }
 
+// Per-state weights for the sum-product recursions (log space).  With the arcs factorised as
+// stay w0[j] / step group w1[r] / skip group w2[q], a state's incoming probability mass is
+//   T0 a[j] + W1 S1[j>>2] + W2 S2[j>>4]   (S1, S2 = sums over the 4 / 16 group members)
+// except that for 28 low-complexity k-mers some predecessor is a member of two classes and must be
+// counted once, with its most specific weight: fold the correction into the coefficients
+//   c2 = W2,  c1 = W1 - [step preds are skip preds] W2,
+//   c0 = T0 - [j is its own step pred] W1 - [j is its own skip pred but not step pred] W2.
+// The outgoing (backward) direction has the same form with the groups taken over successors.
+void fb_weights(const float* w, float* out)
+{
+    const float* w0 = w; const float* w1 = w + kStates; const float* w2 = w + kStates + 1024;
+    for (unsigned j = 0; j < (unsigned)kStates; ++j) {
+        const double T0 = std::exp((double)w0[j]);
+        {   // forward: groups of predecessors, indexed by the consumer's high bits
+            const double W1 = std::exp((double)w1[j >> 2]), W2 = std::exp((double)w2[j >> 4]);
+            const bool stay_in_step = (j & 1023u) == (j >> 2);
+            const bool stay_in_skip = (j & 255u) == (j >> 4);
+            const bool step_in_skip = ((j >> 2) & 255u) == (j >> 4);
+            out[0 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
+            out[1 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
+            out[2 * kStates + j] = (float)std::log(W2);
+        }
+        {   // backward: groups of successors, indexed by the source's low bits
+            const double W1 = std::exp((double)w1[j & 1023u]), W2 = std::exp((double)w2[j & 255u]);
+            const bool stay_in_step = (j >> 2) == (j & 1023u);
+            const bool stay_in_skip = (j >> 4) == (j & 255u);
+            const bool step_in_skip = ((j & 1023u) >> 2) == (j & 255u);
+            out[3 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
+            out[4 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
+            out[5 * kStates + j] = (float)std::log(W2);
+        }
+    }
+}
+
 int check_offsets(size_t n, const uint64_t* off, size_t* max_events, size_t* total)
 {
     size_t mx = 0;
@@ -180,7 +215,17 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     c->stream = c->own_stream;
     if ((rc = dev_alloc(c, (void**)&c->d_models, sizeof(float) * kMaxSlots * kModelFloats))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_trans, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
-    if ((rc = dev_alloc(c, (void**)&c->d_trans_lin, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_trans_fb, sizeof(float) * kMaxSlots * kFbTransFloats))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_train_mask, 512))) return fail(rc);
+    {
+        // Parameter_Trainer::init, Parameter_Trainer.hpp:30-57
+        std::vector<uint16_t> km(kStates);
+        uint32_t nk = 0;
+        nchmm_st_train_kmers(km.data(), &nk);
+        std::vector<uint8_t> mask(512, 0);
+        for (uint32_t i = 0; i < nk; ++i) mask[km[i] >> 3] |= (uint8_t)(1u << (km[i] & 7));
+        if (hipMemcpy(c->d_train_mask, mask.data(), 512, hipMemcpyHostToDevice) != hipSuccess) return fail(NCHMM_E_HIP);
+    }
     if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * (16 + 4096)))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_model_fast, sizeof(int32_t) * kMaxSlots))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 6200))) return fail(rc);
@@ -207,7 +252,8 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_trans) (void)hipFree(c->d_trans);
-    if (c->d_trans_lin) (void)hipFree(c->d_trans_lin);
+    if (c->d_trans_fb) (void)hipFree(c->d_trans_fb);
+    if (c->d_train_mask) (void)hipFree(c->d_train_mask);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_model_fast) (void)hipFree(c->d_model_fast);
     if (c->d_prof) (void)hipFree(c->d_prof);
@@ -280,14 +326,14 @@ int nchmm_put_transitions(nchmm_ctx* c, int slot, const uint32_t* row_ptr, const
 {
     if (!c || !row_ptr || !pred || !logw || slot < 0 || slot >= kMaxSlots) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<float> w(kTransFloats), wl(kTransFloats);
+    std::vector<float> w(kTransFloats), fb(kFbTransFloats);
     int rc = factor_transitions(row_ptr, pred, logw, w.data());
     if (rc != NCHMM_OK) return rc;
-    for (int i = 0; i < kTransFloats; ++i) wl[i] = std::exp(w[i]);
+    fb_weights(w.data(), fb.data());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_trans + (size_t)slot * kTransFloats, w.data(), sizeof(float) * kTransFloats,
                          hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_trans_lin + (size_t)slot * kTransFloats, wl.data(), sizeof(float) * kTransFloats,
+    HIP_TRY(c, hipMemcpy(c->d_trans_fb + (size_t)slot * kFbTransFloats, fb.data(), sizeof(float) * kFbTransFloats,
                          hipMemcpyHostToDevice));
     c->trans_set[slot] = true;
     return NCHMM_OK;
@@ -447,6 +493,99 @@ int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float
         if (status[r] != 0) worst = NCHMM_E_NUMERIC;
     }
     return worst;
+}
+
+int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_events, const uint64_t* d_off,
+                   const float* d_cmean, const float* d_stdv, const float* d_lstdv, const int32_t* d_scaled_slot,
+                   const int32_t* d_unscaled_slot, const int32_t* d_trans_slot, const float* d_st_params,
+                   float* d_out_lpd, float* d_out_pm, float* d_out_st, float* d_out_alpha, float* d_out_beta)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_win == 0) return NCHMM_OK;
+    if (!d_off || !d_out_lpd || n_win > 0xFFFFFFF0ull) return NCHMM_E_INVALID;
+    if (total_events && (!d_cmean || !d_stdv || !d_lstdv)) return NCHMM_E_INVALID;
+    (void)max_events;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* alpha = d_out_alpha;
+    if (!alpha) {
+        void* p = c->d_fb_ws;
+        size_t have = c->fb_ws_floats * sizeof(float);
+        int rc = ensure(c, &p, &have, std::max<size_t>(total_events, 1) * kStates * sizeof(float));
+        c->d_fb_ws = (float*)p; c->fb_ws_floats = have / sizeof(float);
+        if (rc != NCHMM_OK) return rc;
+        alpha = c->d_fb_ws;
+    }
+    FwbwArgs a;
+    a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
+    a.scaled_slot = d_scaled_slot; a.unscaled_slot = d_unscaled_slot; a.trans_slot = d_trans_slot;
+    a.st_params = d_st_params; a.models = c->d_models; a.trans_fb = c->d_trans_fb; a.train_mask = c->d_train_mask;
+    a.ws_alpha = alpha; a.out_log_pr_data = d_out_lpd; a.out_pm_sums = d_out_pm; a.out_st_sums = d_out_st;
+    a.out_beta = d_out_beta; a.queue = c->d_queue + 1; a.n_win = (unsigned)n_win;
+    a.log_n_states = std::log(static_cast<float>(kStates));           // Forward_Backward.hpp:53
+    a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
+    const int grid = (int)std::min<size_t>((size_t)c->fb_slots, n_win);
+    HIP_TRY(c, hipMemsetAsync(c->d_queue + 1, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_fb0, c->stream));
+    launch_fwbw(a, grid, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_fb1, c->stream));
+    c->fb_timed = true;
+    c->counters[3] += 1; c->counters[4] += n_win; c->counters[5] += total_events;
+    return NCHMM_OK;
+}
+
+int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cmean, const float* stdv, const float* lstdv,
+               const int32_t* scaled_slot, const int32_t* unscaled_slot, const int32_t* trans_slot, const float* st_params,
+               float* out_lpd, float* out_pm, float* out_st, float* out_alpha, float* out_beta)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_win == 0) return NCHMM_OK;
+    size_t max_events = 0, total = 0;
+    int rc = check_offsets(n_win, off, &max_events, &total);
+    if (rc != NCHMM_OK) return rc;
+    if (!out_lpd || (total && (!cmean || !stdv || !lstdv))) return NCHMM_E_INVALID;
+    for (size_t w = 0; w < n_win; ++w) {
+        const int ms = scaled_slot ? scaled_slot[w] : 0, us = unscaled_slot ? unscaled_slot[w] : ms;
+        const int ts = trans_slot ? trans_slot[w] : 0;
+        if (ms < 0 || ms >= kMaxSlots || us < 0 || us >= kMaxSlots || ts < 0 || ts >= kMaxSlots || !c->model_set[ms]
+            || !c->model_set[us] || !c->trans_set[ts])
+            return NCHMM_E_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t mat = out_alpha || out_beta ? al(4 * total * kStates) : 0;
+    size_t o_off = 0, o_cm = o_off + al(8 * (n_win + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total);
+    size_t o_ss = o_ls + al(4 * total), o_us = o_ss + al(4 * n_win), o_ts = o_us + al(4 * n_win), o_sp = o_ts + al(4 * n_win);
+    size_t o_lp = o_sp + al(8 * n_win), o_pm = o_lp + al(4 * n_win), o_st = o_pm + al(24 * total), o_al = o_st + al(12 * n_win);
+    size_t o_be = o_al + (out_alpha ? mat : 0), need = o_be + (out_beta ? mat : 0);
+    rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
+    if (rc != NCHMM_OK) return rc;
+    char* d = (char*)c->d_stage;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(d + o_off, off, 8 * (n_win + 1), hipMemcpyHostToDevice, s));
+    if (total) {
+        HIP_TRY(c, hipMemcpyAsync(d + o_cm, cmean, 4 * total, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_sd, stdv, 4 * total, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_ls, lstdv, 4 * total, hipMemcpyHostToDevice, s));
+    }
+    if (scaled_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ss, scaled_slot, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (unscaled_slot) HIP_TRY(c, hipMemcpyAsync(d + o_us, unscaled_slot, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (st_params) HIP_TRY(c, hipMemcpyAsync(d + o_sp, st_params, 8 * n_win, hipMemcpyHostToDevice, s));
+    rc = nchmm_fwbw_dev(c, n_win, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm),
+                        (const float*)(d + o_sd), (const float*)(d + o_ls), scaled_slot ? (const int32_t*)(d + o_ss) : nullptr,
+                        unscaled_slot ? (const int32_t*)(d + o_us) : nullptr, trans_slot ? (const int32_t*)(d + o_ts) : nullptr,
+                        st_params ? (const float*)(d + o_sp) : nullptr, (float*)(d + o_lp), out_pm ? (float*)(d + o_pm) : nullptr,
+                        out_st ? (float*)(d + o_st) : nullptr, out_alpha ? (float*)(d + o_al) : nullptr,
+                        out_beta ? (float*)(d + o_be) : nullptr);
+    if (rc != NCHMM_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_lpd, d + o_lp, 4 * n_win, hipMemcpyDeviceToHost, s));
+    if (out_pm && total) HIP_TRY(c, hipMemcpyAsync(out_pm, d + o_pm, 24 * total, hipMemcpyDeviceToHost, s));
+    if (out_st) HIP_TRY(c, hipMemcpyAsync(out_st, d + o_st, 12 * n_win, hipMemcpyDeviceToHost, s));
+    if (out_alpha && total) HIP_TRY(c, hipMemcpyAsync(out_alpha, d + o_al, 4 * total * kStates, hipMemcpyDeviceToHost, s));
+    if (out_beta && total) HIP_TRY(c, hipMemcpyAsync(out_beta, d + o_be, 4 * total * kStates, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return NCHMM_OK;
 }
 
 int nchmm_counters(const nchmm_ctx* c, uint64_t out[8])

@@ -51,6 +51,8 @@ void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream);
 void launch_traceback(const ViterbiArgs& a, hipStream_t stream);
 int viterbi_blocks_per_cu();
 
+constexpr int kFbTransFloats = 6 * kStates;   // forward c0|c1|c2 then backward c0b|c1b|c2b, per state, log space
+
 struct FwbwArgs {
     const float* cmean;
     const float* stdv;
@@ -59,16 +61,14 @@ struct FwbwArgs {
     const int32_t* scaled_slot;
     const int32_t* unscaled_slot;
     const int32_t* trans_slot;
-    const float* st_params;     // n_win x 2 or null
-    const float* models;
-    const float* trans;
-    const float* trans_lin;     // [kMaxSlots][kTransFloats] linear-space weights for FB (exp of trans)
-    float* ws_alpha;            // per block slot: max_events x 4096 floats (scaled alpha)
-    uint64_t ws_stride;         // floats per block slot
+    const float* st_params;     // n_win x 2 {p_stay, p_skip} or null
+    const float* models;        // [kMaxSlots][kModelFloats]
+    const float* trans_fb;      // [kMaxSlots][kFbTransFloats]
+    const uint8_t* train_mask;  // [512] bit u of byte tau: state 8*tau+u is a transition-training k-mer
+    float* ws_alpha;            // alpha rows, one per event of the batch (4096 floats each)
     float* out_log_pr_data;
     float* out_pm_sums;
     float* out_st_sums;
-    float* out_alpha;
     float* out_beta;
     unsigned* queue;
     unsigned n_win;

@@ -213,4 +213,90 @@ int nchmm_st_train_kmers(uint16_t* out, uint32_t* count)
     return NCHMM_OK;
 }
 
+// Parameter_Trainer::train_pm_params, Parameter_Trainer.hpp:297-427, given the per-event inner
+// sums {s0,s1,s2,l0,l1,l2} (:273-296, produced on the GPU by nchmm_fwbw).  Outer accumulation in
+// double, products in float, 3x3 solve with scaled partial pivoting -- operation for operation.
+int nchmm_train_pm_finish(size_t n_events, const float* pm_sums, const float* mean, const float* stdv,
+                          const float* start, int train_drift, const float crt_pm[6], float new_pm[6], int* done)
+{
+    if (!pm_sums || !mean || !stdv || !crt_pm || !new_pm || !done || (train_drift && !start)) return NCHMM_E_INVALID;
+    *done = 0;
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, B[3] = {0, 0, 0};
+    double D = 0, V_numer = 0, V_denom = 0, U_pos = 0;
+    for (size_t i = 0; i < n_events; ++i) {
+        const float* s = pm_sums + 6 * i;
+        const float* l = s + 3;
+        const float x_i = mean[i], y_i = stdv[i], t_i = start ? start[i] : 0.0f;
+        A[0][0] += s[0];
+        A[0][1] += s[1];
+        A[1][1] += s[2];
+        B[0] += s[0] * x_i;
+        B[1] += s[1] * x_i;
+        if (train_drift) {
+            A[0][2] += s[0] * t_i;
+            A[1][2] += s[1] * t_i;
+            A[2][2] += s[0] * t_i * t_i;
+            B[2] += s[0] * x_i * t_i;
+        }
+        D += s[0] * x_i * x_i;
+        V_numer += l[2] * y_i;
+        V_denom += l[1];
+        U_pos += l[0] / y_i;
+    }
+    A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+    if (!train_drift) A[2][2] = 1.0;
+    double Ac[3][3], Bc[3], C[3];
+    std::memcpy(Ac, A, sizeof(A)); std::memcpy(Bc, B, sizeof(B));
+    for (unsigned i = 0; i < 3; ++i) C[i] = std::max(A[i][0], std::max(A[i][1], A[i][2]));   // alg::max_value_of :328
+    for (unsigned i = 0; i < 3; ++i) {   // :340-386
+        unsigned p = i;
+        double p_val = std::abs(A[i][i]) / C[p];
+        for (unsigned i2 = i + 1; i2 < 3; ++i2) {
+            const double v = std::abs(A[i2][i]) / C[i2];
+            if (v > p_val) { p = i2; p_val = v; }
+        }
+        if (p_val < 1e-7) {   // singular: keep the current parameters (:355-360)
+            *done = 1;
+            std::memcpy(new_pm, crt_pm, 6 * sizeof(float));
+            return NCHMM_OK;
+        }
+        if (p > i) { std::swap(A[i], A[p]); std::swap(B[i], B[p]); std::swap(C[i], C[p]); }
+        for (p = i + 1; p < 3; ++p) {
+            const double m = A[p][i] / A[i][i];
+            A[p][i] = 0;
+            for (unsigned j = i + 1; j < 3; ++j) A[p][j] -= m * A[i][j];
+            B[p] -= m * B[i];
+        }
+    }
+    // each unknown is stored as float before the next one reads it (:388-390)
+    const float c_hat = static_cast<float>(B[2] / A[2][2]);
+    const float b_hat = static_cast<float>((B[1] - A[1][2] * c_hat) / A[1][1]);
+    const float a_hat = static_cast<float>((B[0] - A[0][1] * b_hat - A[0][2] * c_hat) / A[0][0]);
+    const double d_numer = (D + a_hat * a_hat * Ac[0][0] + b_hat * b_hat * Ac[1][1] + c_hat * c_hat * Ac[2][2]
+                            + 2.0 * a_hat * b_hat * Ac[0][1] + 2.0 * a_hat * c_hat * Ac[0][2]
+                            + 2.0 * b_hat * c_hat * Ac[1][2] - 2.0 * (a_hat * Bc[0] + b_hat * Bc[1] + c_hat * Bc[2]));
+    const float d_hat = static_cast<float>(std::sqrt(d_numer / static_cast<double>(n_events)));        // :417
+    const float v_hat = static_cast<float>(V_numer / V_denom);                                          // :422
+    const float u_hat = static_cast<float>(static_cast<double>(n_events) / (U_pos - V_denom / v_hat));  // :426
+    new_pm[0] = b_hat; new_pm[1] = a_hat; new_pm[2] = c_hat; new_pm[3] = d_hat; new_pm[4] = v_hat; new_pm[5] = u_hat;
+    return NCHMM_OK;
+}
+
+// Parameter_Trainer::train_st_params, Parameter_Trainer.hpp:516-530: combine the per-window log-sums
+// {denom, stay_num, skip_num} of one strand into (p_stay, p_skip), with the [.05, .4] reset.
+int nchmm_train_st_finish(size_t n_win, const float* st_sums, float* p_stay, float* p_skip)
+{
+    if ((n_win && !st_sums) || !p_stay || !p_skip) return NCHMM_E_INVALID;
+    double acc[3] = {0, 0, 0};
+    for (size_t w = 0; w < n_win; ++w)
+        for (int k = 0; k < 3; ++k) acc[k] += std::exp(static_cast<double>(st_sums[3 * w + k]));
+    float ps = static_cast<float>(acc[1] / acc[0]), pk = static_cast<float>(acc[2] / acc[0]);   // NaN for an empty strand, as in the reference
+    if (ps < .05 || ps > .4 || pk < .05 || pk > .4) {
+        ps = std::min(std::max(ps, .05f), .4f);
+        pk = std::min(std::max(pk, .05f), .4f);
+    }
+    *p_stay = ps; *p_skip = pk;
+    return NCHMM_OK;
+}
+
 }  // extern "C"
