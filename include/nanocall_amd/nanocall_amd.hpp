@@ -1,0 +1,490 @@
+// nanocall_amd.hpp -- C++ host layer over the C ABI (nanocall_hip.h): drop-in counterparts of the
+// reference's hot-path classes, same names, same member functions, same argument meaning.
+//
+//   reference (src/nanocall/)                      here (namespace nanocall_amd)
+//   Kmer<6>                    Kmer.hpp            Kmer<6>
+//   Event / Event_Sequence     Event.hpp           Event / Event_Sequence
+//   Pore_Model_Parameters,
+//   Pore_Model_State, Pore_Model   Pore_Model.hpp  same (load_from_vector, scale, state(i), ...)
+//   State_Transition_Parameters,
+//   State_Transitions          State_Transitions.hpp   same (compute_transitions_fast, neighbours(i).from_v)
+//   Viterbi                    Viterbi.hpp         Viterbi::fill(pm, st, ev) / path_probability()
+//   Forward_Backward           Forward_Backward.hpp    fill(pm, st, ev) / cell(i,j) / log_posterior / log_pr_data
+//   Parameter_Trainer          Parameter_Trainer.hpp   init() / train_one_round(...)
+//
+// The DP itself runs on the GPU through libnanocall_hip.so; everything that goes through libm (model
+// logs, transition weights, event logs) is computed by the library's host functions so that it is
+// bit-identical to the reference.  A nanocall maintainer switches by including this header instead
+// of the reference headers and adding `using namespace nanocall_amd;`.
+//
+// Throughput note: the reference calls fill() once per strand from a pfor worker thread.  That works
+// here too (one context per thread), but a GPU wants many reads per launch: Viterbi::fill_batch and
+// Parameter_Trainer::train_one_round (which already batches its 2-4 windows) are the efficient forms.
+#ifndef NANOCALL_AMD_HPP
+#define NANOCALL_AMD_HPP
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "nanocall_hip.h"
+
+namespace nanocall_amd {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const char* where) : std::runtime_error(std::string(where) + ": " + nchmm_strerror(c)), code(c) {}
+};
+inline void check(int rc, const char* where) { if (rc != NCHMM_OK) throw Error(rc, where); }
+
+// One device context per host thread (the reference has one DP object per pfor worker,
+// nanocall.cpp:611-621).  Slots 0..63 are managed by the classes below.
+class Device {
+public:
+    static Device& instance()
+    {
+        static thread_local Device d;
+        return d;
+    }
+    static int& device_id() { static int id = 0; return id; }
+    nchmm_ctx* ctx()
+    {
+        if (!_ctx) check(nchmm_create(&_ctx, device_id()), "nchmm_create");
+        return _ctx;
+    }
+    ~Device() { if (_ctx) nchmm_destroy(_ctx); }
+private:
+    nchmm_ctx* _ctx = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Kmer (Kmer.hpp)
+// ---------------------------------------------------------------------------------------------
+template <unsigned Kmer_Size = 6>
+class Kmer {
+    static_assert(Kmer_Size == 6, "the pore HMM is a 6-mer model (Kmer.hpp:119 hard-codes 4096 too)");
+public:
+    static const unsigned n_states = 1u << (2 * Kmer_Size);
+    static size_t to_int(const std::string& s)
+    {
+        size_t r = 0;
+        for (char c : s) { r <<= 2; r += (c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : size_t(-1)); }
+        return r;
+    }
+    static std::string to_string(size_t k)
+    {
+        std::string r(Kmer_Size, 'A');
+        for (unsigned j = 0; j < Kmer_Size; ++j) r[j] = "ACGT"[(k >> (2 * (Kmer_Size - j - 1))) & 3];
+        return r;
+    }
+    static unsigned prefix(unsigned i, unsigned k) { return i >> (2 * (Kmer_Size - k)); }
+    static unsigned suffix(unsigned i, unsigned k) { return i & ((1u << (2 * k)) - 1); }
+    static unsigned min_skip(unsigned k1, unsigned k2)
+    {
+        if (k1 == k2) return 0;
+        for (unsigned d = 1; d < Kmer_Size; ++d)
+            if (suffix(k1, Kmer_Size - d) == prefix(k2, Kmer_Size - d)) return d;
+        return Kmer_Size;
+    }
+    static unsigned max_self_overlap(unsigned i)
+    {
+        for (unsigned k = Kmer_Size - 1; k >= 1; --k)
+            if (suffix(i, k) == prefix(i, k)) return k;
+        return 0;
+    }
+    static std::vector<unsigned> neighbour_list(unsigned i, unsigned d)
+    {
+        std::vector<unsigned> v;
+        for (unsigned b1 = 0; b1 < 4; ++b1) {
+            unsigned i1 = (suffix(i, Kmer_Size - 1) << 2) + b1;
+            if (d == 1) { v.push_back(i1); continue; }
+            for (unsigned b2 = 0; b2 < 4; ++b2) v.push_back((suffix(i1, Kmer_Size - 1) << 2) + b2);
+        }
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Event / Event_Sequence (Event.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+class Event {
+public:
+    Float_Type mean = 0, corrected_mean = 0, stdv = 0, start = 0, length = 0;
+    Float_Type log_mean = 0, log_corrected_mean = 0, log_stdv = 0;
+    Float_Type orig_mean = 0, p_model_state = 0;
+    std::array<char, Kmer_Size> model_state{};
+    unsigned model_state_idx = 0;
+    int move = 0;
+    void update_logs()   // Event.hpp:35-45
+    {
+        log_mean = std::log(mean);
+        log_corrected_mean = std::log(corrected_mean);
+        if (stdv == 0.0) stdv = static_cast<Float_Type>(0.01);
+        log_stdv = std::log(stdv);
+    }
+    void set_model_state(const std::string& s) { std::copy_n(s.begin(), Kmer_Size, model_state.begin()); }
+};
+
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+struct Event_Sequence : std::vector<Event<Float_Type, Kmer_Size>> {
+    typedef std::vector<Event<Float_Type, Kmer_Size>> Base;
+    using Base::Base;
+    void apply_drift_correction(Float_Type drift)   // Event.hpp:77-84
+    {
+        for (auto& e : *this) {
+            e.corrected_mean -= drift * e.start;
+            e.log_corrected_mean = std::log(e.corrected_mean);
+        }
+    }
+    std::string get_base_seq() const   // Event.hpp:85-99
+    {
+        const Base& v = *this;
+        if (v.empty()) return std::string();
+        std::string res(v[0].model_state.begin(), v[0].model_state.end());
+        for (size_t i = 1; i < v.size(); ++i) {
+            unsigned a = std::min<unsigned>((unsigned)v[i].move, Kmer_Size), b = Kmer_Size - a;
+            res.append(v[i].model_state.begin() + b, v[i].model_state.end());
+        }
+        return res;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Pore_Model (Pore_Model.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename Float_Type = float>
+struct Pore_Model_Parameters {
+    Float_Type scale = 1, shift = 0, drift = 0, var = 1, scale_sd = 1, var_sd = 1;
+};
+
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+struct Pore_Model_State {   // field order is the library's S x 10 layout (= Pore_Model.hpp:85-96)
+    Float_Type level_mean, level_stdv, sd_mean, sd_stdv, sd_lambda;
+    Float_Type log_level_mean, log_level_stdv, log_sd_mean, log_sd_stdv, log_sd_lambda;
+};
+
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+class Pore_Model {
+    static_assert(std::is_same<Float_Type, float>::value, "FLOAT_TYPE is float (nanocall.cpp:33-35)");
+public:
+    typedef Pore_Model_State<Float_Type, Kmer_Size> Pore_Model_State_Type;
+    typedef Pore_Model_Parameters<Float_Type> Pore_Model_Parameters_Type;
+    typedef Event<Float_Type, Kmer_Size> Event_Type;
+    static const unsigned n_states = 1u << (2 * Kmer_Size);
+
+    Pore_Model() : _strand(2) {}
+    void clear() { _state.clear(); }
+    const Pore_Model_State_Type& state(unsigned i) const { return _state.at(i); }
+    Pore_Model_State_Type& state(unsigned i) { return _state.at(i); }
+    const unsigned& strand() const { return _strand; }
+    unsigned& strand() { return _strand; }
+    Float_Type mean() const { return _mean; }
+    Float_Type stdv() const { return _stdv; }
+
+    template <typename V_Float_Type>
+    void load_from_vector(const std::vector<V_Float_Type>& v)   // Pore_Model.hpp:220-239
+    {
+        if (v.size() != n_states * 4) throw Error(NCHMM_E_INVALID, "Pore_Model::load_from_vector");
+        std::vector<float> t(v.begin(), v.end());
+        _state.resize(n_states);
+        check(nchmm_model_load(t.data(), reinterpret_cast<float*>(_state.data())), "nchmm_model_load");
+        update_statistics();
+    }
+    void scale(const Pore_Model_Parameters_Type& p)   // Pore_Model.hpp:190-201
+    {
+        const float par[6] = {p.scale, p.shift, p.drift, p.var, p.scale_sd, p.var_sd};
+        check(nchmm_model_scale(reinterpret_cast<float*>(_state.data()), par), "nchmm_model_scale");
+        update_statistics();
+    }
+    // Pore_Model.hpp:295-299 (host evaluation, for callers outside the DP such as debug dumps)
+    Float_Type log_pr_corrected_emission(unsigned i, const Event_Type& e) const
+    {
+        const auto& s = state(i);
+        static const Float_Type log_2pi = std::log(2.0 * M_PI);
+        Float_Type a = (e.corrected_mean - s.level_mean) / s.level_stdv;
+        Float_Type n = -s.log_level_stdv - (log_2pi + a * a) / static_cast<Float_Type>(2.0);
+        Float_Type b = (e.stdv - s.sd_mean) / s.sd_mean;
+        Float_Type ig = (s.log_sd_lambda - log_2pi - static_cast<Float_Type>(3.0) * e.log_stdv - s.sd_lambda * b * b / e.stdv)
+                        / static_cast<Float_Type>(2.0);
+        return n + ig;
+    }
+    // upload as the library's S x 6 table into `slot`
+    void put(int slot) const
+    {
+        std::vector<float> t6(n_states * 6);
+        check(nchmm_model_pack6(reinterpret_cast<const float*>(_state.data()), t6.data()), "nchmm_model_pack6");
+        check(nchmm_put_model(Device::instance().ctx(), slot, t6.data()), "nchmm_put_model");
+    }
+private:
+    std::vector<Pore_Model_State_Type> _state;
+    Float_Type _mean = 0, _stdv = 0;
+    unsigned _strand;
+    void update_statistics()   // Pore_Model.hpp:307-313; alg::mean_stdv_of is hpptools (absent): mean + sample stdv
+    {
+        double s = 0, s2 = 0;
+        for (const auto& st : _state) { s += st.level_mean; s2 += (double)st.level_mean * st.level_mean; }
+        const double n = (double)_state.size();
+        _mean = (Float_Type)(s / n);
+        _stdv = (Float_Type)std::sqrt(std::max(0.0, (s2 - s * s / n) / (n - 1)));
+    }
+};
+template <typename Float_Type, unsigned Kmer_Size>
+using Pore_Model_Dict = std::map<std::string, Pore_Model<Float_Type, Kmer_Size>>;
+
+// ---------------------------------------------------------------------------------------------
+// State_Transitions (State_Transitions.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename Float_Type = float>
+struct State_Transition_Parameters {
+    Float_Type p_stay, p_skip;
+    static Float_Type& default_p_stay() { static Float_Type v = .09; return v; }
+    static Float_Type& default_p_skip() { static Float_Type v = .28; return v; }
+    State_Transition_Parameters() : p_stay(default_p_stay()), p_skip(default_p_skip()) {}
+    bool is_default() const { return p_stay == default_p_stay() && p_skip == default_p_skip(); }
+};
+
+template <typename Float_Type = float>
+struct State_Neighbours {
+    std::vector<std::pair<unsigned, Float_Type>> from_v, to_v;
+};
+
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+class State_Transitions {
+public:
+    typedef State_Neighbours<Float_Type> State_Neighbours_Type;
+    typedef State_Transition_Parameters<Float_Type> State_Transition_Parameters_Type;
+    static const unsigned n_states = 1u << (2 * Kmer_Size);
+    void clear() { _row_ptr.clear(); _pred.clear(); _logw.clear(); _nb.clear(); }
+    bool empty() const { return _row_ptr.empty(); }
+
+    void compute_transitions_fast(Float_Type p_skip_default, Float_Type p_stay)   // State_Transitions.hpp:181-224
+    {
+        _row_ptr.resize(n_states + 1); _pred.resize(NCHMM_MAX_ARCS); _logw.resize(NCHMM_MAX_ARCS);
+        uint32_t n = 0;
+        check(nchmm_transitions_fast(p_skip_default, p_stay, _row_ptr.data(), _pred.data(), _logw.data(), &n),
+              "nchmm_transitions_fast");
+        _pred.resize(n); _logw.resize(n); _nb.clear();
+    }
+    void compute_transitions_fast(const State_Transition_Parameters_Type& stp) { compute_transitions_fast(stp.p_skip, stp.p_stay); }
+
+    // neighbours(i).from_v / .to_v, built on first use
+    const State_Neighbours_Type& neighbours(unsigned i) const
+    {
+        if (_nb.empty()) {
+            _nb.resize(n_states);
+            for (unsigned j = 0; j < n_states; ++j)
+                for (uint32_t a = _row_ptr[j]; a < _row_ptr[j + 1]; ++a) {
+                    _nb[j].from_v.emplace_back(_pred[a], _logw[a]);
+                    _nb[_pred[a]].to_v.emplace_back(j, _logw[a]);
+                }
+        }
+        return _nb.at(i);
+    }
+    void put(int slot) const
+    {
+        check(nchmm_put_transitions(Device::instance().ctx(), slot, _row_ptr.data(), _pred.data(), _logw.data()),
+              "nchmm_put_transitions");
+    }
+private:
+    std::vector<uint32_t> _row_ptr;
+    std::vector<uint16_t> _pred;
+    std::vector<float> _logw;
+    mutable std::vector<State_Neighbours_Type> _nb;
+};
+
+namespace detail {
+template <typename ES>
+inline void soa(const ES& ev, std::vector<float>& cm, std::vector<float>& sd, std::vector<float>& ls)
+{
+    for (const auto& e : ev) { cm.push_back(e.corrected_mean); sd.push_back(e.stdv); ls.push_back(e.log_stdv); }
+}
+}  // namespace detail
+
+// ---------------------------------------------------------------------------------------------
+// Viterbi (Viterbi.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+class Viterbi {
+public:
+    typedef Kmer<Kmer_Size> Kmer_Type;
+    typedef Pore_Model<Float_Type, Kmer_Size> Pore_Model_Type;
+    typedef State_Transitions<Float_Type, Kmer_Size> State_Transitions_Type;
+    typedef Event_Sequence<Float_Type, Kmer_Size> Event_Sequence_Type;
+    static const unsigned n_states = Pore_Model_Type::n_states;
+
+    unsigned n_events() const { return _n_events; }
+    Float_Type path_probability() const { return _path_probability; }
+
+    // Viterbi.hpp:44-99: fills ev[i].model_state_idx / model_state / move
+    void fill(const Pore_Model_Type& pm, const State_Transitions_Type& st, Event_Sequence_Type& ev)
+    {
+        std::vector<Event_Sequence_Type*> evs{&ev};
+        std::vector<Float_Type> pp = fill_batch(pm, st, evs);
+        _n_events = (unsigned)ev.size();
+        _path_probability = pp[0];
+    }
+    // many strands that share one scaled model and one transition table, one launch
+    static std::vector<Float_Type> fill_batch(const Pore_Model_Type& pm, const State_Transitions_Type& st,
+                                              const std::vector<Event_Sequence_Type*>& evs, int slot = 0)
+    {
+        pm.put(slot); st.put(slot);
+        std::vector<uint64_t> off{0};
+        std::vector<float> cm, sd, ls;
+        for (auto* e : evs) { detail::soa(*e, cm, sd, ls); off.push_back(cm.size()); }
+        std::vector<int32_t> slots(evs.size(), slot), status(evs.size());
+        std::vector<uint16_t> states(cm.size());
+        std::vector<Float_Type> pp(evs.size());
+        int rc = nchmm_viterbi(Device::instance().ctx(), evs.size(), off.data(), cm.data(), sd.data(), ls.data(), slots.data(),
+                               slots.data(), states.data(), pp.data(), status.data());
+        if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) check(rc, "nchmm_viterbi");
+        for (size_t r = 0; r < evs.size(); ++r) {
+            auto& ev = *evs[r];
+            if (status[r] != 0) continue;   // reference has undefined behaviour here (Viterbi.hpp:125-141); leave events untouched
+            for (size_t i = 0; i < ev.size(); ++i) {
+                ev[i].model_state_idx = states[off[r] + i];
+                ev[i].set_model_state(Kmer_Type::to_string(ev[i].model_state_idx));
+                ev[i].move = i > 0 ? (int)Kmer_Type::min_skip(ev[i - 1].model_state_idx, ev[i].model_state_idx) : 0;
+            }
+        }
+        return pp;
+    }
+private:
+    Float_Type _path_probability = 0;
+    unsigned _n_events = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Forward_Backward (Forward_Backward.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+class Forward_Backward {
+public:
+    typedef Pore_Model<Float_Type, Kmer_Size> Pore_Model_Type;
+    typedef State_Transitions<Float_Type, Kmer_Size> State_Transitions_Type;
+    typedef Event_Sequence<Float_Type, Kmer_Size> Event_Sequence_Type;
+    struct Matrix_Entry { Float_Type alpha, beta; };
+    static const unsigned n_states = Pore_Model_Type::n_states;
+
+    void clear() { _alpha.clear(); _beta.clear(); }
+    unsigned n_events() const { return (unsigned)(_alpha.size() / n_states); }
+    Matrix_Entry cell(unsigned i, unsigned j) const { return Matrix_Entry{_alpha[(size_t)i * n_states + j], _beta[(size_t)i * n_states + j]}; }
+    Float_Type log_posterior(unsigned i, unsigned j) const { return _alpha[(size_t)i * n_states + j] + _beta[(size_t)i * n_states + j] - _log_pr_data; }
+    Float_Type log_pr_data() const { return _log_pr_data; }
+
+    void fill(const Pore_Model_Type& pm, const State_Transitions_Type& st, const Event_Sequence_Type& ev, int slot = 0)
+    {
+        pm.put(slot); st.put(slot);
+        std::vector<float> cm, sd, ls;
+        detail::soa(ev, cm, sd, ls);
+        const uint64_t off[2] = {0, cm.size()};
+        const int32_t s = slot;
+        _alpha.assign(cm.size() * n_states, 0); _beta.assign(cm.size() * n_states, 0);
+        check(nchmm_fwbw(Device::instance().ctx(), 1, off, cm.data(), sd.data(), ls.data(), &s, &s, &s, nullptr, &_log_pr_data,
+                         nullptr, nullptr, _alpha.data(), _beta.data()), "nchmm_fwbw");
+    }
+private:
+    std::vector<Float_Type> _alpha, _beta;
+    Float_Type _log_pr_data = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Parameter_Trainer (Parameter_Trainer.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename Float_Type = float, unsigned Kmer_Size = 6>
+struct Parameter_Trainer {
+    typedef Pore_Model<Float_Type, Kmer_Size> Pore_Model_Type;
+    typedef Pore_Model_Parameters<Float_Type> Pore_Model_Parameters_Type;
+    typedef State_Transitions<Float_Type, Kmer_Size> State_Transitions_Type;
+    typedef State_Transition_Parameters<Float_Type> State_Transition_Parameters_Type;
+    typedef Event_Sequence<Float_Type, Kmer_Size> Event_Sequence_Type;
+
+    static void init()   // Parameter_Trainer.hpp:30-57
+    {
+        std::vector<uint16_t> k(4096); uint32_t n = 0;
+        check(nchmm_st_train_kmers(k.data(), &n), "nchmm_st_train_kmers");
+        st_train_kmers().assign(k.begin(), k.begin() + n);
+    }
+    static std::vector<unsigned>& st_train_kmers() { static std::vector<unsigned> v; return v; }
+    static unsigned& pm_train_drift() { static unsigned v = 1; return v; }
+
+    // Parameter_Trainer.hpp:541-579.  Device slots used: 60/61 unscaled models, 62/63 scaled models + transitions.
+    static void train_one_round(const std::vector<std::pair<const Event_Sequence_Type*, unsigned>>& event_seq_ptrs,
+                                const std::array<const Pore_Model_Type*, 2>& model_ptrs,
+                                const State_Transitions_Type& default_transitions,
+                                const Pore_Model_Parameters_Type& crt_pm_params,
+                                const std::array<State_Transition_Parameters_Type, 2>& crt_st_params,
+                                Pore_Model_Parameters_Type& new_pm_params,
+                                std::array<State_Transition_Parameters_Type, 2>& new_st_params, Float_Type& fit, bool& done,
+                                bool train_scaling, bool train_transitions)
+    {
+        nchmm_ctx* ctx = Device::instance().ctx();
+        done = false;
+        // fill_train_data :99-155
+        bool have[2] = {false, false};
+        for (const auto& p : event_seq_ptrs) have[p.second] = true;
+        for (unsigned st = 0; st < 2; ++st) {
+            if (!have[st]) continue;
+            model_ptrs[st]->put(60 + st);
+            Pore_Model_Type scaled(*model_ptrs[st]);
+            scaled.scale(crt_pm_params);
+            scaled.put(62 + st);
+            if (!crt_st_params[st].is_default()) {
+                State_Transitions_Type custom;
+                custom.compute_transitions_fast(crt_st_params[st]);
+                custom.put(62 + st);
+            } else {
+                default_transitions.put(62 + st);
+            }
+        }
+        std::vector<uint64_t> off{0};
+        std::vector<float> cm, sd, ls, mean, start;
+        std::vector<int32_t> s_slot, u_slot;
+        std::vector<float> stp;
+        for (const auto& p : event_seq_ptrs) {
+            Event_Sequence_Type corrected(*p.first);
+            corrected.apply_drift_correction(crt_pm_params.drift);
+            detail::soa(corrected, cm, sd, ls);
+            for (const auto& e : *p.first) { mean.push_back(e.mean); start.push_back(e.start); }
+            off.push_back(cm.size());
+            s_slot.push_back(62 + (int)p.second); u_slot.push_back(60 + (int)p.second);
+            stp.push_back(crt_st_params[p.second].p_stay); stp.push_back(crt_st_params[p.second].p_skip);
+        }
+        const size_t n_win = event_seq_ptrs.size(), total = cm.size();
+        std::vector<float> lpd(n_win), pm_sums(6 * total), st_sums(3 * n_win);
+        check(nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), u_slot.data(), s_slot.data(),
+                         stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr), "nchmm_fwbw");
+        fit = 0;
+        for (float v : lpd) fit += v;   // :154
+        if (train_scaling) {
+            const float crt[6] = {crt_pm_params.scale, crt_pm_params.shift, crt_pm_params.drift, crt_pm_params.var,
+                                  crt_pm_params.scale_sd, crt_pm_params.var_sd};
+            float np[6]; int d = 0;
+            check(nchmm_train_pm_finish(total, pm_sums.data(), mean.data(), sd.data(), start.data(), (int)pm_train_drift(), crt,
+                                        np, &d), "nchmm_train_pm_finish");
+            new_pm_params.scale = np[0]; new_pm_params.shift = np[1]; new_pm_params.drift = np[2];
+            new_pm_params.var = np[3]; new_pm_params.scale_sd = np[4]; new_pm_params.var_sd = np[5];
+            if (d) { done = true; new_st_params = crt_st_params; return; }
+        }
+        if (train_transitions) {
+            for (unsigned st = 0; st < 2; ++st) {
+                std::vector<float> mine;
+                for (size_t w = 0; w < n_win; ++w)
+                    if (event_seq_ptrs[w].second == st) mine.insert(mine.end(), st_sums.begin() + 3 * w, st_sums.begin() + 3 * w + 3);
+                check(nchmm_train_st_finish(mine.size() / 3, mine.data(), &new_st_params[st].p_stay, &new_st_params[st].p_skip),
+                      "nchmm_train_st_finish");
+            }
+        }
+    }
+};
+
+}  // namespace nanocall_amd
+#endif

@@ -1,0 +1,69 @@
+"""The C++ host layer (include/nanocall_amd/nanocall_amd.hpp) through tools/run-viterbi -- the reference's
+own debug harness shape (src/nanocall/run-viterbi.cpp): model / transitions / events text files in,
+base sequence out.  Must equal the oracle's sequence byte for byte."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import nanocall_amd as na
+import nc_oracle as oracle
+from helpers import ragged_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "run-viterbi")
+
+
+def _kmer(j):
+    return "".join("ACGT"[(j >> (2 * (5 - i))) & 3] for i in range(6))
+
+
+@pytest.fixture(scope="module")
+def tool():
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True, capture_output=True)
+    return TOOL
+
+
+def test_run_viterbi_text_formats(tool, tmp_path, r73t):
+    params = (1.03, 1.5, 0.0, 1.1, 0.95, 1.2)
+    scaled = na.model_scale(na.model_load(r73t), params)
+    # model file rows in shuffled order with a header and a comment, as Pore_Model operator>> accepts
+    order = np.random.default_rng(0).permutation(4096)
+    with open(tmp_path / "model.tsv", "w") as f:
+        f.write("#comment\nkmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+        for j in order:
+            # 9 significant digits round-trip a float32 exactly
+            f.write(_kmer(int(j)) + "\t" + "\t".join(f"{v:.9g}" for v in scaled[j, :4]) + "\n")
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [700], first_read=77)
+    with open(tmp_path / "events.tsv", "w") as f:
+        for m, s, t in zip(mean, stdv, start):
+            f.write(f"{m:.9g}\t{s:.9g}\t{t:.9g}\t0.01\n")
+    # expected: the oracle on a model LOADED from those four columns (the tool does load_from_vector on the file)
+    om = oracle.Model(scaled[:, :4].copy())
+    ot = oracle.Transitions(0.3, 0.1)
+    st, mv, lp = oracle.viterbi(om, ot, cm, sd, ls)
+    exp_seq = oracle.base_seq(st, mv)
+    r = subprocess.run([tool, "-p", str(tmp_path / "model.tsv"), "-e", str(tmp_path / "events.tsv"),
+                        "--pr-skip", "0.3", "--pr-stay", "0.1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == exp_seq
+    # same through a transitions FILE (to_v order, i.e. by source state) and FASTA output
+    rp, idx, w = ot.to_csr()
+    with open(tmp_path / "trans.tsv", "w") as f:
+        for i in range(4096):
+            for a in range(rp[i], rp[i + 1]):
+                f.write(f"{_kmer(i)}\t{_kmer(int(idx[a]))}\t{w[a]:.9g}\n")
+    r = subprocess.run([tool, "-p", str(tmp_path / "model.tsv"), "-e", str(tmp_path / "events.tsv"),
+                        "-s", str(tmp_path / "trans.tsv"), "--fasta", "read1:file:0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == oracle.write_fasta("read1:file:0", exp_seq, 80)
+
+
+def test_run_viterbi_reports_errors_without_crashing(tool, tmp_path):
+    (tmp_path / "m.tsv").write_text("AAAAAA\t1\t1\t1\t1\n")
+    (tmp_path / "e.tsv").write_text("60 1 0 0.01\n")
+    r = subprocess.run([tool, "-p", str(tmp_path / "m.tsv"), "-e", str(tmp_path / "e.tsv")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "unexpected number of states" in r.stderr
