@@ -55,6 +55,19 @@ def cpu_baseline(table, n_events, threads):
                        f"{threads} read-parallel threads, oracle/nc_oracle.c (reference matrix layout), {dt:.1f} s"), results, prepped
 
 
+def measured_traffic(n_reads, n_events):
+    """HBM bytes per launch of viterbi_kernel from the PMC passes committed under profiles/ (rocprofv3
+    cannot run inside this process); null when no profile of this exact workload exists."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_c2.json")))
+        if t["workload"] == {"reads": n_reads, "events": n_events}:
+            k = t["viterbi_kernel"]
+            return int((k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +188,7 @@ def main():
                        "reads_per_gpu": n_reads, "events_per_read": n_events, "parallelism": f"read-sharded x{world}",
                        "grid_slots": ctx.grid_slots()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(n_reads, n_events),
                          "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3), "traceback_kernel_ms": round(tb_ms, 3),
                          "bytes_per_event": BYTES_PER_EVENT, "events_per_launch": total},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
