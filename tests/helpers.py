@@ -40,3 +40,24 @@ def assert_bits_equal(a, b, what=""):
     b = np.asarray(b, np.float32)
     same = a.view(np.uint32) == b.view(np.uint32)
     assert same.all(), f"{what}: {np.count_nonzero(~same)} of {a.size} floats differ bitwise; first {a[~same][:3]} vs {b[~same][:3]}"
+
+
+def rescore_path(table, params, p_skip, p_stay, cm, sd, ls, states):
+    """Recompute the Viterbi score ALONG a given state path with the reference's float operations
+    (alpha_0 = e_0 - log 4096; alpha_i = (w + alpha_{i-1}) + e_i, Viterbi.hpp:59,82,90).  O(n): a
+    full-size check that needs no CPU DP.  Returns (float32 score, all_arcs_valid)."""
+    om = oracle.Model(table, params)
+    rp, idx, w = oracle.Transitions(p_skip, p_stay).from_csr()
+    a = np.float32(om.emission(int(states[0]), cm[0], sd[0], ls[0])) - np.float32(np.log(np.float32(4096.0)))
+    a = np.float32(a)
+    ok = True
+    for i in range(1, len(states)):
+        j, p = int(states[i]), int(states[i - 1])
+        row = idx[rp[j]:rp[j + 1]]
+        k = np.searchsorted(row, p)
+        if k >= len(row) or row[k] != p:
+            ok = False
+            break
+        a = np.float32(np.float32(w[rp[j] + k]) + a)
+        a = np.float32(a + np.float32(om.emission(j, cm[i], sd[i], ls[i])))
+    return a, ok

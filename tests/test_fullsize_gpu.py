@@ -1,0 +1,61 @@
+"""Full-size cases (BASELINE.json configs 2 and 5) through size-independent properties, plus one
+50 000-event read against the oracle."""
+import numpy as np
+import pytest
+
+import nanocall_amd as na
+from nanocall_amd import synth
+from helpers import IDENT, rescore_path, oracle_viterbi_batch, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_full_batch_properties(gpu_ctx, r73t):
+    """1024 reads x 5000 events: (1) deterministic across two runs, (2) every decoded transition is an arc of
+    the HMM, (3) the reported path log-probability equals the score recomputed along the decoded path with the
+    reference's float operations (bit for bit) on a sample of reads, (4) a checksum of the state array is
+    stable under splitting the batch in two calls."""
+    n_reads, n_events = 1024, 5000
+    ev = synth.generate(r73t, n_reads, n_events)
+    off, mean, stdv, start = synth.flat_batch(ev)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    gpu_ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+    gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    s1, lp1, st1 = gpu_ctx.viterbi(off, cm, sd, ls)
+    s2, lp2, st2 = gpu_ctx.viterbi(off, cm, sd, ls)
+    assert np.array_equal(s1, s2) and np.array_equal(lp1.view(np.uint32), lp2.view(np.uint32))
+    assert (st1 == 0).all() and np.isfinite(lp1).all()
+    # (2) arcs: prev -> cur is stay, step or skip-1
+    S = s1.reshape(n_reads, n_events).astype(np.int64)
+    prev, cur = S[:, :-1], S[:, 1:]
+    valid = (prev == cur) | ((prev & 1023) == (cur >> 2)) | ((prev & 255) == (cur >> 4))
+    assert valid.all()
+    # (3) rescoring
+    for r in (0, 1, 511, 1023):
+        a, b = r * n_events, (r + 1) * n_events
+        score, ok = rescore_path(r73t, IDENT, 0.3, 0.1, cm[a:b], sd[a:b], ls[a:b], s1[a:b])
+        assert ok and np.float32(score).tobytes() == lp1[r].tobytes(), (r, score, lp1[r])
+    # (4) split batch
+    h = n_reads // 2
+    oa, ob = off[: h + 1], off[h:] - off[h]
+    sa, lpa, _ = gpu_ctx.viterbi(oa, cm[: h * n_events], sd[: h * n_events], ls[: h * n_events])
+    sb, lpb, _ = gpu_ctx.viterbi(ob, cm[h * n_events:], sd[h * n_events:], ls[h * n_events:])
+    assert np.array_equal(np.concatenate([sa, sb]), s1)
+    assert np.array_equal(np.concatenate([lpa, lpb]).view(np.uint32), lp1.view(np.uint32))
+
+
+def test_config5_r9_50k_event_read_against_oracle(gpu_ctx, r9t):
+    """One 50 000-event R9 read (the reference allocates a 1.6 GB matrix for it) + short neighbours."""
+    lens = [50000, 17, 3000]
+    ev = synth.generate(r9t, 3, max(lens), first_read=300)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    cat = lambda k: np.concatenate([ev[k][r, :n] for r, n in enumerate(lens)])
+    cm, sd, ls = na.events_prepare(cat("mean"), cat("stdv"), cat("start"), 0.0)
+    gpu_ctx.put_model(0, na.scaled_model_table(r9t, IDENT))
+    gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    states, logp, status = gpu_ctx.viterbi(off, cm, sd, ls)
+    ostates, ologp = oracle_viterbi_batch(r9t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+    mv, seq = na.base_seq(states[:50000])
+    assert 45000 < len(seq) < 60000
