@@ -71,6 +71,11 @@ __device__ __forceinline__ unsigned selm(mask_t m, unsigned if_set, unsigned if_
     return r;
 }
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// a wave-uniform float held in an SGPR instead of a VGPR
+__device__ __forceinline__ float uniform(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 // swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float swap1(float v)
@@ -402,15 +407,15 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 for (unsigned c = lo; c < hi; ++c) {
                     const float4 ev = sEv[c];
                     const unsigned i = base + c;
-                    column<true>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, ev.x, ev.y, ev.w, ev.z,
-                                 P.log_2pi);
+                    column<true>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
+                                 uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
                 }
             } else {
                 for (unsigned c = lo; c < hi; ++c) {
                     const float4 ev = sEv[c];
                     const unsigned i = base + c;
-                    column<false>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, ev.x, ev.y, ev.w, ev.z,
-                                  P.log_2pi);
+                    column<false>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
+                                  uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
                 }
             }
             __syncthreads();   // sEv is rewritten by the next chunk
