@@ -70,6 +70,13 @@ __device__ __forceinline__ unsigned selm(mask_t m, unsigned if_set, unsigned if_
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
 }
+// mask bit set -> 0 (inline constant: no VGPR, no v_mov), clear -> if_clear
+__device__ __forceinline__ unsigned selm_zero(mask_t m, unsigned if_clear)
+{
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(r) : "v"(if_clear), "s"(m));
+    return r;
+}
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // a wave-uniform float held in an SGPR instead of a VGPR
 __device__ __forceinline__ float uniform(float v)
@@ -227,8 +234,10 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
     __syncthreads();
 
     // ---------------- 3-way combine per state ----------------
-    const mask_t all = ballot(true);
     const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
+    // one per-thread base pointer per exchange array; every cell is then an immediate offset
+    const ValSlot* const pa = sV1 + r1_base;
+    const ValSlot* const pb = sV2 + q_base;
     unsigned bpw[2] = {0, 0};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -246,14 +255,16 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
             const unsigned kc = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1);
             const unsigned k = kc + h;
             const unsigned r1 = r1_base + (kc << 6), q = q_base + (kc << 4);
-            const ValSlot a = sV1[r1];
-            const ValSlot b = sV2[q];
+            const ValSlot a = pa[kc << 6];
+            const ValSlot b = pb[kc << 4];
             const float s0 = w0_[u] + S.alpha[i];
             // fast path: the winner is unique unless two class values are equal
             float best = __builtin_fmaxf(__builtin_fmaxf(s0, a.v), b.v);
             const mask_t e0 = ballot(s0 == best), e1 = ballot(a.v == best), e2 = ballot(b.v == best);
-            unsigned slot = selm(e0, 0u, selm(e1, a.s, b.s));
-            const mask_t tie = (e0 & e1) | ((e0 | e1) & e2) | (all & ~(e0 | e1 | e2));
+            unsigned slot = selm_zero(e0, selm(e1, a.s, b.s));
+            // two or more of the three equal the maximum?  (all three NaN cannot happen for a cell that
+            // matters: the read is then reported NCHMM_E_NUMERIC by the final arg-max)
+            const mask_t tie = (e0 & e1) | ((e0 | e1) & e2);
             if (tie != 0) {
                 // exact rule: first maximum in ascending predecessor order (strict >, NaN never wins)
                 const unsigned j = t + 256u * k;
