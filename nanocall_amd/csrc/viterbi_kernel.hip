@@ -488,12 +488,24 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     }
 }
 
+// branch-free pred_of for the (wave-uniform) chase
+__device__ __forceinline__ unsigned pred_uniform(unsigned j, unsigned slot, unsigned& shift_class)
+{
+    const unsigned sc = slot == 0 ? 0u : (slot < 5u ? 1u : 2u);
+    const unsigned hi = (slot - (sc == 1u ? 1u : 5u)) << (12u - 2u * sc);
+    shift_class = sc;
+    return sc == 0 ? j : ((hi | (j >> (2u * sc))) & 4095u);
+}
+
 // Viterbi::fill_state_seq, Viterbi.hpp:134-141: follow the back-pointers from the last state.
 // One wave per read.  Per round trip the wave fetches every 16-byte group that can hold the byte it
-// will need in rows cur, cur-1, cur-2 (1 + 3 + 23 groups) and then resolves three events from LDS.
+// will need in rows cur, cur-1, cur-2 (1 + 3 + 23 groups, lanes 0..26) and then resolves three
+// events from LDS.  Decoded states are collected in LDS and written out 192 at a time, so no store
+// sits in the memory queue in front of the next round trip's loads.
 __global__ __launch_bounds__(64) void traceback_kernel(ViterbiArgs P)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sStage[32][16];
+    __shared__ uint16_t sOut[192];
     const unsigned tau = threadIdx.x;
     const unsigned r = P.first_read + blockIdx.x;
     const uint64_t e0 = P.off[r];
@@ -505,54 +517,71 @@ __global__ __launch_bounds__(64) void traceback_kernel(ViterbiArgs P)
     const uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
     uint16_t* __restrict__ os = P.out_state + e0;
     unsigned s = P.last_state[r];
-    int status = (s >= (unsigned)kStates) ? -6 : 0;
-    if (status == 0) {
+    unsigned bad = (s >= (unsigned)kStates) ? 1u : 0u;
+    if (!bad) {
+        // per-lane constants of the fetch pattern: which of the three rows, and the group as
+        // hi | ((s >> sh) & msk)
+        unsigned rowoff, sh, msk, hi;
+        if (tau == 0) { rowoff = 0; sh = 0; msk = 255; hi = 0; }
+        else if (tau < 4) { rowoff = 1; sh = 2 * (tau - 1); msk = 255; hi = 0; }
+        else if (tau < 7) { rowoff = 2; sh = 2 * (tau - 4); msk = 255; hi = 0; }
+        else if (tau < 11) { rowoff = 2; sh = 6; msk = 63; hi = (tau - 7) << 6; }
+        else { rowoff = 2; sh = 8; msk = 15; hi = ((tau - 11) & 15u) << 4; }
+        const bool lane_on = tau < 27;
         int cur = (int)n - 1;
         if (tau == 0) os[cur] = (uint16_t)s;
+        int pending_top = cur - 1;   // event index of sOut[0]
+        unsigned n_pending = 0;
         while (cur >= 1) {
-            int row; unsigned grp; bool act = true;
-            if (tau == 0) { row = cur; grp = s & 255u; }
-            else if (tau < 4) { row = cur - 1; grp = (s >> (2 * (tau - 1))) & 255u; }
-            else if (tau < 7) { row = cur - 2; grp = (s >> (2 * (tau - 4))) & 255u; }
-            else if (tau < 11) { row = cur - 2; grp = ((tau - 7) << 6) | ((s >> 6) & 63u); }
-            else if (tau < 27) { row = cur - 2; grp = ((tau - 11) << 4) | ((s >> 8) & 15u); }
-            else { row = 0; grp = 0; act = false; }
-            if (act && row >= 1)
+            const int row = cur - (int)rowoff;
+            const unsigned grp = hi | ((s >> sh) & msk);
+            if (lane_on && row >= 1)
                 *reinterpret_cast<uint4*>(&sStage[tau][0]) =
                     *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
+            __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0);   // LDS stage visible to the whole wave
-            __builtin_amdgcn_wave_barrier();
-            // resolve up to three steps (all lanes redundantly; uniform control flow)
+            // resolve up to three steps (wave-uniform)
+            unsigned sc0, sc1, sc2;
             unsigned slot = sStage[0][bp_pos(s >> 8)];
-            if (slot > 20u) { status = -6; break; }
-            const unsigned sh0 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
-            s = pred_of(s, slot);
-            if (tau == 0) os[cur - 1] = (uint16_t)s;
+            bad |= slot > 20u;
+            s = pred_uniform(s, slot > 20u ? 0u : slot, sc0);
+            const unsigned s_a = s;
+            unsigned s_b = s, s_c = s;
             int done = 1;
-            if (cur - 1 >= 1) {
-                slot = sStage[1 + sh0][bp_pos(s >> 8)];
-                if (slot > 20u) { status = -6; break; }
-                const unsigned sh1 = slot == 0 ? 0u : (slot < 5 ? 1u : 2u);
-                s = pred_of(s, slot);
-                if (tau == 0) os[cur - 2] = (uint16_t)s;
-                done = 2;
-                if (cur - 2 >= 1) {
-                    const unsigned tot = sh0 + sh1;
-                    const unsigned lane = tot <= 2 ? 4u + tot
-                                        : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
+            if (cur >= 2) {
+                slot = sStage[1 + sc0][bp_pos(s >> 8)];
+                bad |= slot > 20u;
+                s = pred_uniform(s, slot > 20u ? 0u : slot, sc1);
+                s_b = s; done = 2;
+                if (cur >= 3) {
+                    const unsigned tot = sc0 + sc1;
+                    const unsigned lane = tot <= 2 ? 4u + tot : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
                     slot = sStage[lane][bp_pos(s >> 8)];
-                    if (slot > 20u) { status = -6; break; }
-                    s = pred_of(s, slot);
-                    if (tau == 0) os[cur - 3] = (uint16_t)s;
-                    done = 3;
+                    bad |= slot > 20u;
+                    s = pred_uniform(s, slot > 20u ? 0u : slot, sc2);
+                    s_c = s; done = 3;
                 }
             }
+            if (tau == 0) {
+                sOut[n_pending] = (uint16_t)s_a;
+                if (done > 1) sOut[n_pending + 1] = (uint16_t)s_b;
+                if (done > 2) sOut[n_pending + 2] = (uint16_t)s_c;
+            }
+            n_pending += (unsigned)done;
             cur -= done;
-            __builtin_amdgcn_wave_barrier();
+            if (n_pending + 3 > 192u || cur < 1) {
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                // sOut[k] is the state of event pending_top - k
+                for (unsigned k = tau; k < n_pending; k += 64) os[pending_top - (int)k] = sOut[k];
+                pending_top -= (int)n_pending;
+                n_pending = 0;
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
-    if (tau == 0 && P.out_status) P.out_status[r] = status;
+    if (tau == 0 && P.out_status) P.out_status[r] = bad ? -6 : 0;
 }
 
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream)
