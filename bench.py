@@ -140,7 +140,7 @@ def main():
     if os.environ.get("NCHMM_PROFILE") == "1" and rank == 0:
         tk = ctx.profile_ticks()
         sys.stderr.write(f"[phase ticks, 100 MHz, summed over blocks] forward={tk[0]} traceback={tk[1]} block={tk[2]} "
-                         f"blocks={tk[3]} traceback/forward={float(tk[1]) / max(float(tk[0]), 1):.3f}\n")
+                         f"blocks={tk[3]} traceback segments re-walked={tk[4]} of {tk[5]} speculative\n")
         raw = ctx.profile_blocks()
         ng = ctx.grid_slots()
         pb = raw[:4096].reshape(2048, 2)[:ng].astype(np.int64)

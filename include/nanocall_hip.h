@@ -205,8 +205,9 @@ int nchmm_last_kernel_ms(nchmm_ctx* ctx, float out[4]);
 
 /* Phase counters of the Viterbi kernel, accumulated over launches while the environment variable
  * NCHMM_PROFILE=1 was set at nchmm_create time: out[0] = forward-sweep ticks summed over blocks,
- * [1] = unused, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks). */
-int nchmm_profile_ticks(nchmm_ctx* ctx, uint64_t out[4], int reset);
+ * [1] = unused, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks), [4] = traceback
+ * segments that had to be re-walked, [5] = speculative traceback segments, [6..7] reserved. */
+int nchmm_profile_ticks(nchmm_ctx* ctx, uint64_t out[8], int reset);
 /* (start, end) wall_clock64 ticks of the first 2048 blocks of the last profiled Viterbi launch */
 int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);
 

@@ -247,7 +247,7 @@ class Context:
         return tuple(float(x) for x in out)
 
     def profile_ticks(self, reset=True):
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(8, np.uint64)
         check(lib().nchmm_profile_ticks(self._h, _p(out), int(reset)), "nchmm_profile_ticks")
         return out
 

@@ -621,13 +621,13 @@ int nchmm_profile_blocks(nchmm_ctx* c, uint64_t* out /* 6144: 2048 x (start, end
     return NCHMM_OK;
 }
 
-int nchmm_profile_ticks(nchmm_ctx* c, uint64_t out[4], int reset)
+int nchmm_profile_ticks(nchmm_ctx* c, uint64_t out[8], int reset)
 {
     if (!c || !out) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->d_prof, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(c, hipMemset(c->d_prof, 0, sizeof(uint64_t) * 4));
+    HIP_TRY(c, hipMemcpy(out, c->d_prof, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(c, hipMemset(c->d_prof, 0, sizeof(uint64_t) * 8));
     return NCHMM_OK;
 }
 

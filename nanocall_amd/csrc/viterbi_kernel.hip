@@ -497,91 +497,166 @@ __device__ __forceinline__ unsigned pred_uniform(unsigned j, unsigned slot, unsi
     return sc == 0 ? j : ((hi | (j >> (2u * sc))) & 4095u);
 }
 
-// Viterbi::fill_state_seq, Viterbi.hpp:134-141: follow the back-pointers from the last state.
-// One wave per read.  Per round trip the wave fetches every 16-byte group that can hold the byte it
-// will need in rows cur, cur-1, cur-2 (1 + 3 + 23 groups, lanes 0..26) and then resolves three
-// events from LDS.  Decoded states are collected in LDS and written out 192 at a time, so no store
-// sits in the memory queue in front of the next round trip's loads.
-__global__ __launch_bounds__(64) void traceback_kernel(ViterbiArgs P)
+constexpr int kTbWaves = 8;      // traceback segments per read (one wave each)
+constexpr int kTbMargin = 256;   // events a speculative segment runs before its first owned event
+
+// One wave follows the back-pointers from (event ev_hi, state s) down to event ev_lo, writing
+// out_state[e] for ev_lo <= e <= min(ev_hi - 1, ev_write_hi) (the start event itself is the caller's).
+// Per round trip it fetches every 16-byte group that can hold the byte it will need in rows cur,
+// cur-1 (1 + 3 groups; LEVELS == 2) and cur-2 (+ 23 groups; LEVELS == 3) and resolves two or three
+// events from LDS.  Three levels minimise round trips (one read per wave: latency-bound); two levels
+// fetch 4.5x fewer sectors per event, which is what matters once 8 waves per read make the
+// traceback bandwidth-bound (every 16-byte group costs a whole 64-byte sector).  Decoded states
+// are collected in LDS and written 192 at a time so that no store sits in front of the next loads.
+// Returns the state at ev_lo; *mark_state receives the state at event `mark` if the walk passes it.
+template <int LEVELS>
+__device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsigned s, int ev_hi, int ev_lo, int ev_write_hi,
+                                          int mark, unsigned* mark_state, unsigned lane, uint8_t (*sStage)[16],
+                                          uint16_t* sOut, unsigned& bad)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sStage[32][16];
-    __shared__ uint16_t sOut[192];
-    const unsigned tau = threadIdx.x;
+    unsigned rowoff, sh, msk, hi;
+    if (lane == 0) { rowoff = 0; sh = 0; msk = 255; hi = 0; }
+    else if (lane < 4) { rowoff = 1; sh = 2 * (lane - 1); msk = 255; hi = 0; }
+    else if (lane < 7) { rowoff = 2; sh = 2 * (lane - 4); msk = 255; hi = 0; }
+    else if (lane < 11) { rowoff = 2; sh = 6; msk = 63; hi = (lane - 7) << 6; }
+    else { rowoff = 2; sh = 8; msk = 15; hi = ((lane - 11) & 15u) << 4; }
+    const bool lane_on = lane < (LEVELS == 3 ? 27u : 4u);
+    int cur = ev_hi;                 // row cur holds the back-pointer from event cur to event cur-1
+    int pending_top = cur - 1;       // event index of sOut[0]
+    unsigned n_pending = 0;
+    while (cur > ev_lo) {
+        const int row = cur - (int)rowoff;
+        const unsigned grp = hi | ((s >> sh) & msk);
+        if (lane_on && row > ev_lo)
+            *reinterpret_cast<uint4*>(&sStage[lane][0]) =
+                *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
+        __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
+        __builtin_amdgcn_wave_barrier();
+        unsigned sc0, sc1, sc2;
+        unsigned slot = sStage[0][bp_pos(s >> 8)];
+        bad |= slot > 20u;
+        s = pred_uniform(s, slot > 20u ? 0u : slot, sc0);
+        const unsigned s_a = s;
+        unsigned s_b = s, s_c = s;
+        int done = 1;
+        if (cur - 1 > ev_lo) {
+            slot = sStage[1 + sc0][bp_pos(s >> 8)];
+            bad |= slot > 20u;
+            s = pred_uniform(s, slot > 20u ? 0u : slot, sc1);
+            s_b = s; done = 2;
+            if (LEVELS == 3 && cur - 2 > ev_lo) {
+                const unsigned tot = sc0 + sc1;
+                const unsigned ln = tot <= 2 ? 4u + tot : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
+                slot = sStage[ln][bp_pos(s >> 8)];
+                bad |= slot > 20u;
+                s = pred_uniform(s, slot > 20u ? 0u : slot, sc2);
+                s_c = s; done = 3;
+            }
+        }
+        if (mark_state) {
+            if (cur - 1 == mark) *mark_state = s_a;
+            if (done > 1 && cur - 2 == mark) *mark_state = s_b;
+            if (done > 2 && cur - 3 == mark) *mark_state = s_c;
+        }
+        if (lane == 0) {
+            sOut[n_pending] = (uint16_t)s_a;
+            if (done > 1) sOut[n_pending + 1] = (uint16_t)s_b;
+            if (done > 2) sOut[n_pending + 2] = (uint16_t)s_c;
+        }
+        n_pending += (unsigned)done;
+        cur -= done;
+        if (n_pending + 3 > 192u || cur <= ev_lo) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            // sOut[k] is the state of event pending_top - k
+            for (unsigned k = lane; k < n_pending; k += 64) {
+                const int e = pending_top - (int)k;
+                if (e <= ev_write_hi) os[e] = sOut[k];
+            }
+            pending_top -= (int)n_pending;
+            n_pending = 0;
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    return s;
+}
+
+// Viterbi::fill_state_seq, Viterbi.hpp:134-141.  The chase is a dependent pointer walk bound by
+// HBM latency (~1 us per three events), so a read is cut into up to 8 segments walked by 8 waves
+// at once.  Only the top segment knows its start state; the others start kTbMargin events above
+// their segment from an arbitrary state and rely on Viterbi survivor paths coalescing: if the
+// speculative walk is in the same state as the true path at the first event it owns, everything
+// below is the true path (back-pointers are a function of (event, state)).  Wave 0 checks each
+// boundary top-down and re-walks a segment from the true state when its speculation had not merged,
+// so the result is exact either way.
+__global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sStage[kTbWaves][32][16];
+    __shared__ uint16_t sOut[kTbWaves][192];
+    __shared__ unsigned sLow[kTbWaves + 1], sTent[kTbWaves], sBad[kTbWaves];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned r = P.first_read + blockIdx.x;
     const uint64_t e0 = P.off[r];
-    const unsigned n = (unsigned)(P.off[r + 1] - e0);
+    const int n = (int)(P.off[r + 1] - e0);
     if (n == 0) {
-        if (tau == 0 && P.out_status) P.out_status[r] = 0;
+        if (threadIdx.x == 0 && P.out_status) P.out_status[r] = 0;
         return;
     }
     const uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
     uint16_t* __restrict__ os = P.out_state + e0;
-    unsigned s = P.last_state[r];
-    unsigned bad = (s >= (unsigned)kStates) ? 1u : 0u;
-    if (!bad) {
-        // per-lane constants of the fetch pattern: which of the three rows, and the group as
-        // hi | ((s >> sh) & msk)
-        unsigned rowoff, sh, msk, hi;
-        if (tau == 0) { rowoff = 0; sh = 0; msk = 255; hi = 0; }
-        else if (tau < 4) { rowoff = 1; sh = 2 * (tau - 1); msk = 255; hi = 0; }
-        else if (tau < 7) { rowoff = 2; sh = 2 * (tau - 4); msk = 255; hi = 0; }
-        else if (tau < 11) { rowoff = 2; sh = 6; msk = 63; hi = (tau - 7) << 6; }
-        else { rowoff = 2; sh = 8; msk = 15; hi = ((tau - 11) & 15u) << 4; }
-        const bool lane_on = tau < 27;
-        int cur = (int)n - 1;
-        if (tau == 0) os[cur] = (uint16_t)s;
-        int pending_top = cur - 1;   // event index of sOut[0]
-        unsigned n_pending = 0;
-        while (cur >= 1) {
-            const int row = cur - (int)rowoff;
-            const unsigned grp = hi | ((s >> sh) & msk);
-            if (lane_on && row >= 1)
-                *reinterpret_cast<uint4*>(&sStage[tau][0]) =
-                    *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
-            __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
-            __builtin_amdgcn_wave_barrier();
-            // resolve up to three steps (wave-uniform)
-            unsigned sc0, sc1, sc2;
-            unsigned slot = sStage[0][bp_pos(s >> 8)];
-            bad |= slot > 20u;
-            s = pred_uniform(s, slot > 20u ? 0u : slot, sc0);
-            const unsigned s_a = s;
-            unsigned s_b = s, s_c = s;
-            int done = 1;
-            if (cur >= 2) {
-                slot = sStage[1 + sc0][bp_pos(s >> 8)];
-                bad |= slot > 20u;
-                s = pred_uniform(s, slot > 20u ? 0u : slot, sc1);
-                s_b = s; done = 2;
-                if (cur >= 3) {
-                    const unsigned tot = sc0 + sc1;
-                    const unsigned lane = tot <= 2 ? 4u + tot : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
-                    slot = sStage[lane][bp_pos(s >> 8)];
-                    bad |= slot > 20u;
-                    s = pred_uniform(s, slot > 20u ? 0u : slot, sc2);
-                    s_c = s; done = 3;
-                }
-            }
-            if (tau == 0) {
-                sOut[n_pending] = (uint16_t)s_a;
-                if (done > 1) sOut[n_pending + 1] = (uint16_t)s_b;
-                if (done > 2) sOut[n_pending + 2] = (uint16_t)s_c;
-            }
-            n_pending += (unsigned)done;
-            cur -= done;
-            if (n_pending + 3 > 192u || cur < 1) {
-                __builtin_amdgcn_s_waitcnt(0);
-                __builtin_amdgcn_wave_barrier();
-                // sOut[k] is the state of event pending_top - k
-                for (unsigned k = tau; k < n_pending; k += 64) os[pending_top - (int)k] = sOut[k];
-                pending_top -= (int)n_pending;
-                n_pending = 0;
-                __builtin_amdgcn_s_waitcnt(0);
-                __builtin_amdgcn_wave_barrier();
-            }
+    const unsigned s_last = P.last_state[r];
+    if (s_last >= (unsigned)kStates) {
+        if (threadIdx.x == 0 && P.out_status) P.out_status[r] = -6;
+        return;
+    }
+    int K = n / 512;
+    K = K < 1 ? 1 : (K > kTbWaves ? kTbWaves : K);
+    const int L = (n + K - 1) / K;                 // segment w owns events [w*L, min((w+1)*L, n) - 1]
+    unsigned bad = 0;
+    if ((int)wave < K) {
+        const int lo = (int)wave * L;
+        if ((int)wave == K - 1) {
+            if (lane == 0) os[n - 1] = (uint16_t)s_last;
+            const unsigned s_lo = K == 1 ? chase<3>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad)
+                                         : chase<2>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad);
+            if (lane == 0) sLow[wave] = s_lo;
+        } else {
+            const int own_hi = lo + L - 1;             // highest event this segment owns
+            int start = own_hi + 1 + kTbMargin;        // speculative start event
+            if (start > n - 1) start = n - 1;
+            unsigned tent = 0xFFFFFFFFu;
+            // the state at event own_hi+1 is the first one compared with the segment above
+            const unsigned s_lo = chase<2>(ws, os, 0u, start, lo, own_hi, own_hi + 1, &tent, lane, sStage[wave], sOut[wave], bad);
+            if (start == own_hi + 1) tent = 0u;        // no margin left: the guess itself sits on the boundary
+            if (lane == 0) { sLow[wave] = s_lo; sTent[wave] = tent; }
         }
     }
-    if (tau == 0 && P.out_status) P.out_status[r] = bad ? -6 : 0;
+    if (lane == 0) sBad[wave] = bad;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned any_bad = 0;
+        for (int w = 0; w < K; ++w) any_bad |= sBad[w];
+        unsigned refix = 0;
+        for (int w = K - 2; w >= 0; --w) {
+            const unsigned truth = sLow[w + 1];        // true state at event (w+1)*L
+            if (sTent[w] != truth) {
+                // speculation had not merged: walk this segment again from the true state
+                unsigned b2 = 0;
+                const unsigned s_lo = chase<3>(ws, os, truth, (w + 1) * L, w * L, (w + 1) * L - 1, -1, nullptr, lane, sStage[0],
+                                            sOut[0], b2);
+                any_bad |= b2;
+                if (lane == 0) sLow[w] = s_lo;
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                ++refix;
+            }
+        }
+        if (lane == 0) {
+            if (P.out_status) P.out_status[r] = any_bad ? -6 : 0;
+            if (P.prof) { atomicAdd(&P.prof[4], (unsigned long long)refix); atomicAdd(&P.prof[5], (unsigned long long)(K - 1)); }
+        }
+    }
 }
 
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream)
@@ -591,7 +666,7 @@ void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream)
 
 void launch_traceback(const ViterbiArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(traceback_kernel, dim3(a.n_reads), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(traceback_kernel, dim3(a.n_reads), dim3(64 * kTbWaves), 0, stream, a);
 }
 
 int viterbi_blocks_per_cu()
