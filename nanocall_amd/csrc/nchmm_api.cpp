@@ -30,6 +30,7 @@ struct nchmm_ctx {
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
     bool profile = false;
+    int tb_margin = 256;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path)
     uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace (4 KiB per event of a batch)
     size_t ws_bytes = 0;
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
@@ -234,6 +235,8 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     {
         const char* e = std::getenv("NCHMM_PROFILE");
         c->profile = e && e[0] == '1';
+        const char* m = std::getenv("NCHMM_TB_MARGIN");
+        if (m) c->tb_margin = std::max(0, std::atoi(m));
     }
     if (hipEventCreate(&c->ev_vit0) != hipSuccess || hipEventCreate(&c->ev_vit1) != hipSuccess
         || hipEventCreate(&c->ev_vit2) != hipSuccess
@@ -358,6 +361,7 @@ int launch_batch(nchmm_ctx* c, size_t first, size_t count, uint64_t ev_base, uin
     a.ws = c->d_ws; a.ev_base = ev_base; a.first_read = (unsigned)first; a.last_state = c->d_last_state;
     a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
     a.queue = c->d_queue; a.cu_progress = c->d_queue + 16; a.n_reads = (unsigned)count;
+    a.tb_margin = c->tb_margin;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     const int grid = (int)std::min<size_t>((size_t)c->vit_slots, count);

@@ -43,6 +43,7 @@ struct ViterbiArgs {
     int32_t* out_status;
     unsigned* queue;           // work-queue head, zeroed before launch
     unsigned n_reads;
+    int tb_margin;             // events a speculative traceback segment runs before its first owned event
     float log_n_states;        // std::log(4096.f) from the host libm (Viterbi.hpp:51)
     float log_2pi;             // (float)std::log(2.0 * M_PI) (Pore_Model.hpp:28,37)
 };

@@ -498,7 +498,6 @@ __device__ __forceinline__ unsigned pred_uniform(unsigned j, unsigned slot, unsi
 }
 
 constexpr int kTbWaves = 8;      // traceback segments per read (one wave each)
-constexpr int kTbMargin = 256;   // events a speculative segment runs before its first owned event
 
 // One wave follows the back-pointers from (event ev_hi, state s) down to event ev_lo, writing
 // out_state[e] for ev_lo <= e <= min(ev_hi - 1, ev_write_hi) (the start event itself is the caller's).
@@ -584,7 +583,7 @@ __device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsig
 
 // Viterbi::fill_state_seq, Viterbi.hpp:134-141.  The chase is a dependent pointer walk bound by
 // HBM latency (~1 us per three events), so a read is cut into up to 8 segments walked by 8 waves
-// at once.  Only the top segment knows its start state; the others start kTbMargin events above
+// at once.  Only the top segment knows its start state; the others start tb_margin (256) events above
 // their segment from an arbitrary state and rely on Viterbi survivor paths coalescing: if the
 // speculative walk is in the same state as the true path at the first event it owns, everything
 // below is the true path (back-pointers are a function of (event, state)).  Wave 0 checks each
@@ -623,7 +622,7 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
             if (lane == 0) sLow[wave] = s_lo;
         } else {
             const int own_hi = lo + L - 1;             // highest event this segment owns
-            int start = own_hi + 1 + kTbMargin;        // speculative start event
+            int start = own_hi + 1 + P.tb_margin;      // speculative start event
             if (start > n - 1) start = n - 1;
             unsigned tent = 0xFFFFFFFFu;
             // the state at event own_hi+1 is the first one compared with the segment above

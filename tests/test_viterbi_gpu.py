@@ -202,3 +202,28 @@ def test_workspace_split_into_sub_batches(r73t):
         a, b = int(off[r]), int(off[r + 1])
         os_, ol = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, np.array([0, b - a], np.uint64), cm[a:b], sd[a:b], ls[a:b])
         assert np.array_equal(states[a:b], os_) and logp[r].tobytes() == ol[0].tobytes()
+
+
+@pytest.mark.parametrize("margin", ["0", "2"])
+def test_traceback_rewalk_path_is_exact(r73t, margin):
+    """The traceback walks 8 segments of a read speculatively and re-walks a segment whose speculation had
+    not merged with the true path.  With the normal 256-event margin that never happens on sane data, so
+    force it (margin 0 / 2) and check the result is still exact."""
+    import os
+    os.environ["NCHMM_TB_MARGIN"] = margin
+    os.environ["NCHMM_PROFILE"] = "1"
+    try:
+        ctx = na.Context(0)
+    finally:
+        del os.environ["NCHMM_TB_MARGIN"], os.environ["NCHMM_PROFILE"]
+    lens = [5000, 1023, 1024, 2100, 4097]
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=60)
+    ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+    ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    states, logp, status = ctx.viterbi(off, cm, sd, ls)
+    tk = ctx.profile_ticks()
+    ctx.close()
+    assert tk[5] > 0 and tk[4] > 0, "the re-walk path was not exercised"
+    ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
