@@ -174,9 +174,13 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
     float m4[2]; unsigned x4[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {            // y = 2g + h, members i = 2x + g
-        float bv = NEG_INF; unsigned bx = 0;
+        // starting from member 0 instead of -INF saves one compare-select; the results differ only
+        // if member 0 is NaN while another member is not, which needs a NaN emission for some
+        // states but not others -- no finite model/event does that (and an all-NaN column is
+        // reported as NCHMM_E_NUMERIC at the end)
+        float bv = S.alpha[g]; unsigned bx = 0;
 #pragma unroll
-        for (int xx = 0; xx < 4; ++xx) {
+        for (int xx = 1; xx < 4; ++xx) {
             const float v = S.alpha[2 * xx + g];
             const mask_t m = ballot(v > bv);
             bv = selm(m, v, bv);
