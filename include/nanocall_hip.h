@@ -118,18 +118,32 @@ int nchmm_last_hip_error(const nchmm_ctx* ctx); /* raw hipError_t of the last fa
 int nchmm_set_stream(nchmm_ctx* ctx, void* hip_stream);
 int nchmm_synchronize(nchmm_ctx* ctx);
 
-/* Register a scaled pore model in `slot` (0 <= slot < 64): what basecall_strand builds with
+/* Register a scaled pore model in `slot` (0 <= slot < reserved slots, 64 by default): what basecall_strand builds with
  * `Pore_Model_Type pm(models.at(m_name)); pm.scale(pm_params);` (nanocall.cpp:649-650).
  * table_Sx6 as produced by nchmm_model_pack6. */
 int nchmm_put_model(nchmm_ctx* ctx, int slot, const float* table_Sx6);
 
-/* Register transitions in `slot` (0 <= slot < 64): the `*transitions_ptr` of basecall_strand
+/* Register transitions in `slot` (0 <= slot < reserved slots): the `*transitions_ptr` of basecall_strand
  * (nanocall.cpp:651-661).  CSR by destination state, predecessors ascending (from_v order,
  * State_Transitions.hpp:85-94).  Fails with NCHMM_E_TOPOLOGY unless the graph is exactly the
  * stay/step/skip-1 graph of compute_transitions_fast and its weights factor per DESIGN.md
  * section "Transition factorisation" (always true for compute_transitions_fast output). */
 int nchmm_put_transitions(nchmm_ctx* ctx, int slot, const uint32_t* row_ptr_S1, const uint16_t* pred,
                           const float* logw);
+
+/* Slots 0..63 exist from the start; this grows the model and transition slot tables (contents kept). */
+int nchmm_reserve_slots(nchmm_ctx* ctx, int n_slots);
+
+/* Batched `Pore_Model pm(models.at(name)); pm.scale(pm_params);` (nanocall.cpp:649-650,
+ * Parameter_Trainer.hpp:105-114): slot first_slot + k receives table table_idx[k] (an S x 10 state array
+ * from nchmm_model_load, tables concatenated in states_Sx10) scaled by params_nx6[k].  Multi-threaded on
+ * the host, one upload.  Grows the slot tables as needed. */
+int nchmm_put_models_scaled(nchmm_ctx* ctx, int first_slot, size_t n, const float* states_Sx10, const int32_t* table_idx,
+                            const float* params_nx6);
+
+/* Batched `custom_transitions.compute_transitions_fast(st_params)` (nanocall.cpp:653-657,
+ * Parameter_Trainer.hpp:123-127): slot first_slot + k receives the transitions of (p_skip[k], p_stay[k]). */
+int nchmm_put_transitions_fast(nchmm_ctx* ctx, int first_slot, size_t n, const float* p_skip, const float* p_stay);
 
 /* ------------------------------------------------------------------------------------------
  * Viterbi  -- replaces `Viterbi_Type vit; vit.fill(pm, *transitions_ptr, corrected_events);

@@ -39,6 +39,9 @@ SIGNATURES = {
     "nchmm_synchronize": (C.c_int, [vp]),
     "nchmm_put_model": (C.c_int, [vp, C.c_int, vp]),
     "nchmm_put_transitions": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "nchmm_reserve_slots": (C.c_int, [vp, C.c_int]),
+    "nchmm_put_models_scaled": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, vp]),
+    "nchmm_put_transitions_fast": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp]),
     "nchmm_viterbi": (C.c_int, [vp, C.c_size_t] + [vp] * 9),
     "nchmm_viterbi_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
     "nchmm_fwbw": (C.c_int, [vp, C.c_size_t] + [vp] * 13),

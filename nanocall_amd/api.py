@@ -171,6 +171,23 @@ class Context:
         w = _f32(logw)
         check(lib().nchmm_put_transitions(self._h, slot, _p(rp), _p(pr), _p(w)), "nchmm_put_transitions")
 
+    def reserve_slots(self, n):
+        check(lib().nchmm_reserve_slots(self._h, int(n)), "nchmm_reserve_slots")
+
+    def put_models_scaled(self, first_slot, states, table_idx, params):
+        """Batched scale + upload: states = [n_tables, S, 10] (model_load outputs), params = [n, 6]."""
+        st = _f32(states).reshape(-1, S, 10)
+        idx = np.ascontiguousarray(table_idx, np.int32)
+        par = _f32(params).reshape(-1, 6)
+        assert idx.shape[0] == par.shape[0] and idx.max(initial=0) < st.shape[0]
+        check(lib().nchmm_put_models_scaled(self._h, int(first_slot), idx.shape[0], _p(st), _p(idx), _p(par)),
+              "nchmm_put_models_scaled")
+
+    def put_transitions_fast(self, first_slot, p_skip, p_stay):
+        ps, pt = _f32(np.atleast_1d(p_skip)), _f32(np.atleast_1d(p_stay))
+        check(lib().nchmm_put_transitions_fast(self._h, int(first_slot), ps.shape[0], _p(ps), _p(pt)),
+              "nchmm_put_transitions_fast")
+
     def set_stream(self, hip_stream_ptr):
         check(lib().nchmm_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)), "nchmm_set_stream")
 

@@ -2,6 +2,7 @@
 // Compiled with hipcc; see include/nanocall_hip.h for the contract of every entry point.
 #include "nanocall_hip.h"
 #include "nchmm_device.h"
+#include "nchmm_internal.hpp"
 #include "nchmm_kmer.hpp"
 
 #include <algorithm>
@@ -10,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 using namespace nchmm;
@@ -44,8 +46,8 @@ struct nchmm_ctx {
     hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_vit2 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
     bool vit_timed = false, fb_timed = false;
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool model_set[kMaxSlots] = {false};
-    bool trans_set[kMaxSlots] = {false};
+    int n_slots = 0;                // capacity of the model / transition slot tables (grows on demand)
+    std::vector<char> model_set, trans_set;
 };
 
 namespace {
@@ -162,20 +164,119 @@ void fb_weights(const float* w, float* out)
             const bool stay_in_step = (j & 1023u) == (j >> 2);
             const bool stay_in_skip = (j & 255u) == (j >> 4);
             const bool step_in_skip = ((j >> 2) & 255u) == (j >> 4);
-            out[0 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
-            out[1 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
-            out[2 * kStates + j] = (float)std::log(W2);
+            if (!stay_in_step && !stay_in_skip && !step_in_skip) {   // the common case: nothing to fold
+                out[0 * kStates + j] = w0[j]; out[1 * kStates + j] = w1[j >> 2]; out[2 * kStates + j] = w2[j >> 4];
+            } else {
+                out[0 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
+                out[1 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
+                out[2 * kStates + j] = (float)std::log(W2);
+            }
         }
         {   // backward: groups of successors, indexed by the source's low bits
             const double W1 = std::exp((double)w1[j & 1023u]), W2 = std::exp((double)w2[j & 255u]);
             const bool stay_in_step = (j >> 2) == (j & 1023u);
             const bool stay_in_skip = (j >> 4) == (j & 255u);
             const bool step_in_skip = ((j & 1023u) >> 2) == (j & 255u);
-            out[3 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
-            out[4 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
-            out[5 * kStates + j] = (float)std::log(W2);
+            if (!stay_in_step && !stay_in_skip && !step_in_skip) {
+                out[3 * kStates + j] = w0[j]; out[4 * kStates + j] = w1[j & 1023u]; out[5 * kStates + j] = w2[j & 255u];
+            } else {
+                out[3 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
+                out[4 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
+                out[5 * kStates + j] = (float)std::log(W2);
+            }
         }
     }
+}
+
+// One state of the device model image (nchmm_device.h ModelField) from the six emission fields.
+// The kernel divides by sigma, eta (per state) and stdv (per event) through correctly rounded
+// reciprocals + two FMA residual steps; that equals IEEE division when no intermediate leaves the
+// normal range, which holds for parameters inside these (very wide) bounds.  A model outside them is
+// still decoded, with true divisions (*fast = 0).
+inline void model_image_row(float* img, int j, float level_mean, float level_stdv, float log_level_stdv, float sd_mean,
+                            float sd_lambda, float log_sd_lambda, int32_t* fast)
+{
+    static const float log_2pi = static_cast<float>(std::log(2.0 * M_PI));  // Pore_Model.hpp:28,37
+    auto in = [](float v, float lo, float hi) { return std::isfinite(v) && v >= lo && v <= hi; };
+    img[MF_MU * kStates + j] = level_mean;
+    img[MF_SIGMA * kStates + j] = level_stdv;
+    img[MF_RSIGMA * kStates + j] = static_cast<float>(1.0 / static_cast<double>(level_stdv));
+    img[MF_NEG_LOG_SIGMA * kStates + j] = -log_level_stdv;
+    img[MF_ETA * kStates + j] = sd_mean;
+    img[MF_RETA * kStates + j] = static_cast<float>(1.0 / static_cast<double>(sd_mean));
+    img[MF_LAMBDA * kStates + j] = sd_lambda;
+    img[MF_C * kStates + j] = log_sd_lambda - log_2pi;  // first subtraction of log_invgauss_pdf, Pore_Model.hpp:39
+    if (!(in(std::fabs(level_mean), 0x1p-10f, 0x1p20f) && in(level_stdv, 0x1p-10f, 0x1p10f) && in(sd_mean, 0x1p-6f, 0x1p10f)
+          && in(sd_lambda, 0x1p-10f, 0x1p14f)))
+        *fast = 0;
+}
+
+template <typename F>
+void parallel_for(size_t n, F&& f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min<unsigned>(nt, 32) : 4;
+    if (n < 4 || nt < 2) { f(0, n); return; }
+    nt = (unsigned)std::min<size_t>(nt, n);
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; ++i) th.emplace_back([&, i] { f(n * i / nt, n * (i + 1) / nt); });
+    for (auto& t : th) t.join();
+}
+
+// w0 | w1 | w2 of compute_transitions_fast(p_skip, p_stay) from one representative arc per class
+void fast_transition_weights(float p_skip, float p_stay, float* out)
+{
+    float p_step, p_skip_1;
+    step_params(p_skip, p_stay, p_step, p_skip_1);
+    float* w0 = out; float* w1 = out + kStates; float* w2 = out + kStates + 1024;
+    for (unsigned j = 0; j < (unsigned)kStates; ++j) w0[j] = std::log(trans_prob(j, j, p_stay, p_step, p_skip_1));
+    for (unsigned r = 0; r < 1024; ++r) {
+        // a step arc p -> j with p & 1023 == r == j >> 2 that is not the stay arc
+        unsigned p = r, j = r << 2;            // x = 0, a = 0
+        if (p == j) j |= 1u;                   // r == 0: p = j = 0
+        w1[r] = std::log(trans_prob(p, j, p_stay, p_step, p_skip_1));
+    }
+    for (unsigned q = 0; q < 256; ++q) {
+        // a skip arc p -> j with p & 255 == q == j >> 4 that is neither a step arc nor the stay arc
+        float w = 0; bool found = false;
+        for (unsigned xy = 0; xy < 16 && !found; ++xy)
+            for (unsigned ab = 0; ab < 16 && !found; ++ab) {
+                const unsigned p = (xy << 8) | q, j = (q << 4) | ab;
+                if (p == j || (p & 1023u) == (j >> 2)) continue;
+                w = std::log(trans_prob(p, j, p_stay, p_step, p_skip_1));
+                found = true;
+            }
+        w2[q] = w;
+    }
+}
+
+// Grow the slot tables (models, Viterbi weights, FB weights, fast flags) to hold n slots, keeping
+// what is already uploaded.
+int reserve_slots(nchmm_ctx* c, int n)
+{
+    if (n <= c->n_slots) return NCHMM_OK;
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    auto grow = [&](void** p, size_t elem_bytes) -> int {
+        void* q = nullptr;
+        int rc = dev_alloc(c, &q, elem_bytes * (size_t)n);
+        if (rc != NCHMM_OK) return rc;
+        if (*p) {
+            HIP_TRY(c, hipMemcpy(q, *p, elem_bytes * (size_t)c->n_slots, hipMemcpyDeviceToDevice));
+            HIP_TRY(c, hipFree(*p));
+            c->counters[6] -= elem_bytes * (size_t)c->n_slots;
+        }
+        *p = q;
+        return NCHMM_OK;
+    };
+    int rc;
+    if ((rc = grow((void**)&c->d_models, sizeof(float) * kModelFloats))) return rc;
+    if ((rc = grow((void**)&c->d_trans, sizeof(float) * kTransFloats))) return rc;
+    if ((rc = grow((void**)&c->d_trans_fb, sizeof(float) * kFbTransFloats))) return rc;
+    if ((rc = grow((void**)&c->d_model_fast, sizeof(int32_t)))) return rc;
+    HIP_TRY(c, hipMemset(c->d_model_fast + c->n_slots, 0, sizeof(int32_t) * (size_t)(n - c->n_slots)));
+    c->model_set.resize(n, 0); c->trans_set.resize(n, 0);
+    c->n_slots = n;
+    return NCHMM_OK;
 }
 
 int check_offsets(size_t n, const uint64_t* off, size_t* max_events, size_t* total)
@@ -214,9 +315,7 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NCHMM_E_HIP);
     c->stream = c->own_stream;
-    if ((rc = dev_alloc(c, (void**)&c->d_models, sizeof(float) * kMaxSlots * kModelFloats))) return fail(rc);
-    if ((rc = dev_alloc(c, (void**)&c->d_trans, sizeof(float) * kMaxSlots * kTransFloats))) return fail(rc);
-    if ((rc = dev_alloc(c, (void**)&c->d_trans_fb, sizeof(float) * kMaxSlots * kFbTransFloats))) return fail(rc);
+    if ((rc = reserve_slots(c, kMaxSlots))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_train_mask, 512))) return fail(rc);
     {
         // Parameter_Trainer::init, Parameter_Trainer.hpp:30-57
@@ -228,9 +327,7 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         if (hipMemcpy(c->d_train_mask, mask.data(), 512, hipMemcpyHostToDevice) != hipSuccess) return fail(NCHMM_E_HIP);
     }
     if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * (16 + 4096)))) return fail(rc);
-    if ((rc = dev_alloc(c, (void**)&c->d_model_fast, sizeof(int32_t) * kMaxSlots))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 6200))) return fail(rc);
-    if (hipMemset(c->d_model_fast, 0, sizeof(int32_t) * kMaxSlots) != hipSuccess) return fail(NCHMM_E_HIP);
     if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 6200) != hipSuccess) return fail(NCHMM_E_HIP);
     {
         const char* e = std::getenv("NCHMM_PROFILE");
@@ -293,29 +390,13 @@ int nchmm_synchronize(nchmm_ctx* c)
 
 int nchmm_put_model(nchmm_ctx* c, int slot, const float* t6)
 {
-    if (!c || !t6 || slot < 0 || slot >= kMaxSlots) return NCHMM_E_INVALID;
+    if (!c || !t6 || slot < 0 || slot >= c->n_slots) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    const float log_2pi = static_cast<float>(std::log(2.0 * M_PI));  // Pore_Model.hpp:28,37
     std::vector<float> img(kModelFloats);
-    // The kernel divides by sigma, eta (per state) and stdv (per event) through correctly rounded
-    // reciprocals + two FMA residual steps; that equals IEEE division when no intermediate leaves
-    // the normal range, which holds for parameters inside these (very wide) bounds.  A model outside
-    // them is still decoded, with true divisions.
-    auto in = [](float v, float lo, float hi) { return std::isfinite(v) && v >= lo && v <= hi; };
     int32_t fast = 1;
     for (int j = 0; j < kStates; ++j) {
         const float* s = t6 + (size_t)j * 6;
-        img[MF_MU * kStates + j] = s[0];
-        img[MF_SIGMA * kStates + j] = s[1];
-        img[MF_RSIGMA * kStates + j] = static_cast<float>(1.0 / static_cast<double>(s[1]));
-        img[MF_NEG_LOG_SIGMA * kStates + j] = -s[2];
-        img[MF_ETA * kStates + j] = s[3];
-        img[MF_RETA * kStates + j] = static_cast<float>(1.0 / static_cast<double>(s[3]));
-        img[MF_LAMBDA * kStates + j] = s[4];
-        img[MF_C * kStates + j] = s[5] - log_2pi;  // first subtraction of log_invgauss_pdf, Pore_Model.hpp:39
-        if (!(in(std::fabs(s[0]), 0x1p-10f, 0x1p20f) && in(s[1], 0x1p-10f, 0x1p10f) && in(s[3], 0x1p-6f, 0x1p10f)
-              && in(s[4], 0x1p-10f, 0x1p14f)))
-            fast = 0;
+        model_image_row(img.data(), j, s[0], s[1], s[2], s[3], s[4], s[5], &fast);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // a running kernel may still read this slot
     HIP_TRY(c, hipMemcpy(c->d_models + (size_t)slot * kModelFloats, img.data(), sizeof(float) * kModelFloats,
@@ -325,9 +406,83 @@ int nchmm_put_model(nchmm_ctx* c, int slot, const float* t6)
     return NCHMM_OK;
 }
 
+int nchmm_reserve_slots(nchmm_ctx* c, int n_slots)
+{
+    if (!c || n_slots < 0 || n_slots > (1 << 20)) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return reserve_slots(c, n_slots);
+}
+
+// Batched Pore_Model::scale + upload: slot first_slot + k gets table table_idx[k] scaled by params[k].
+// The float operations are those of Pore_Model_State::scale (Pore_Model.hpp:126-138) on the fields the
+// emission reads (sd_stdv is not one of them and is skipped).
+int nchmm_put_models_scaled(nchmm_ctx* c, int first_slot, size_t n, const float* states_Sx10, const int32_t* table_idx,
+                            const float* params_nx6)
+{
+    if (!c || first_slot < 0 || (n && (!states_Sx10 || !params_nx6))) return NCHMM_E_INVALID;
+    if (n == 0) return NCHMM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = reserve_slots(c, first_slot + (int)n);
+    if (rc != NCHMM_OK) return rc;
+    std::vector<float> img((size_t)n * kModelFloats);
+    std::vector<int32_t> fast(n, 1);
+    auto work = [&](size_t a, size_t b) {
+        for (size_t k = a; k < b; ++k) {
+            const float* st = states_Sx10 + (size_t)(table_idx ? table_idx[k] : 0) * kStates * 10;
+            const float* p = params_nx6 + 6 * k;
+            const float log_var = std::log(p[3]), log_var_sd = std::log(p[5]);
+            float* im = img.data() + k * kModelFloats;
+            for (int j = 0; j < kStates; ++j) {
+                const float* s = st + (size_t)j * 10;
+                const float level_mean = s[0] * p[0] + p[1];
+                const float level_stdv = s[1] * p[3];
+                const float sd_mean = s[2] * p[4];
+                const float sd_lambda = s[4] * p[5];
+                const float log_level_stdv = s[6] + log_var;
+                const float log_sd_lambda = s[9] + log_var_sd;
+                model_image_row(im, j, level_mean, level_stdv, log_level_stdv, sd_mean, sd_lambda, log_sd_lambda, &fast[k]);
+            }
+        }
+    };
+    parallel_for(n, work);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_models + (size_t)first_slot * kModelFloats, img.data(), sizeof(float) * img.size(),
+                         hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_model_fast + first_slot, fast.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < n; ++k) c->model_set[first_slot + k] = 1;
+    return NCHMM_OK;
+}
+
+// Batched State_Transitions::compute_transitions_fast + upload, without materialising the 85 936
+// arcs: the factorised weights w0/w1/w2 are read off one representative arc per stay / step-group /
+// skip-group (same get_trans_prob arithmetic), which is what factor_transitions would extract from
+// the full CSR (tests compare the two routes).
+int nchmm_put_transitions_fast(nchmm_ctx* c, int first_slot, size_t n, const float* p_skip, const float* p_stay)
+{
+    if (!c || first_slot < 0 || (n && (!p_skip || !p_stay))) return NCHMM_E_INVALID;
+    if (n == 0) return NCHMM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = reserve_slots(c, first_slot + (int)n);
+    if (rc != NCHMM_OK) return rc;
+    std::vector<float> w((size_t)n * kTransFloats), fb((size_t)n * kFbTransFloats);
+    auto work = [&](size_t a, size_t b) {
+        for (size_t k = a; k < b; ++k) {
+            fast_transition_weights(p_skip[k], p_stay[k], w.data() + k * kTransFloats);
+            fb_weights(w.data() + k * kTransFloats, fb.data() + k * kFbTransFloats);
+        }
+    };
+    parallel_for(n, work);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_trans + (size_t)first_slot * kTransFloats, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_trans_fb + (size_t)first_slot * kFbTransFloats, fb.data(), sizeof(float) * fb.size(),
+                         hipMemcpyHostToDevice));
+    for (size_t k = 0; k < n; ++k) c->trans_set[first_slot + k] = 1;
+    return NCHMM_OK;
+}
+
 int nchmm_put_transitions(nchmm_ctx* c, int slot, const uint32_t* row_ptr, const uint16_t* pred, const float* logw)
 {
-    if (!c || !row_ptr || !pred || !logw || slot < 0 || slot >= kMaxSlots) return NCHMM_E_INVALID;
+    if (!c || !row_ptr || !pred || !logw || slot < 0 || slot >= c->n_slots) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<float> w(kTransFloats), fb(kFbTransFloats);
     int rc = factor_transitions(row_ptr, pred, logw, w.data());
@@ -451,7 +606,7 @@ int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float
     if (!out_logp || (total && (!cmean || !stdv || !lstdv || !out_state))) return NCHMM_E_INVALID;
     for (size_t r = 0; r < n_reads; ++r) {
         const int ms = model_slot ? model_slot[r] : 0, ts = trans_slot ? trans_slot[r] : 0;
-        if (ms < 0 || ms >= kMaxSlots || ts < 0 || ts >= kMaxSlots || !c->model_set[ms] || !c->trans_set[ts])
+        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts])
             return NCHMM_E_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -551,7 +706,7 @@ int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cme
     for (size_t w = 0; w < n_win; ++w) {
         const int ms = scaled_slot ? scaled_slot[w] : 0, us = unscaled_slot ? unscaled_slot[w] : ms;
         const int ts = trans_slot ? trans_slot[w] : 0;
-        if (ms < 0 || ms >= kMaxSlots || us < 0 || us >= kMaxSlots || ts < 0 || ts >= kMaxSlots || !c->model_set[ms]
+        if (ms < 0 || ms >= c->n_slots || us < 0 || us >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms]
             || !c->model_set[us] || !c->trans_set[ts])
             return NCHMM_E_INVALID;
     }

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "nchmm_internal.hpp"
 #include "nchmm_kmer.hpp"
 
 namespace {
@@ -105,19 +106,9 @@ int nchmm_transitions_fast(float p_skip, float p_stay, uint32_t* row_ptr, uint16
 {
     if (!row_ptr || !pred || !logw) return NCHMM_E_INVALID;
     using nchmm::Kmer6;
-    const float p_step = static_cast<float>(1.0 - p_stay - p_skip);        // :198
-    const float p_skip_1 = static_cast<float>(p_skip / (p_skip + 1.0));   // :200
-    // get_trans_prob :125-144 -- float accumulator, double pow terms
-    auto trans_prob = [&](unsigned i, unsigned j) {
-        float p = 0;
-        if (i == j) p += p_stay;
-        if (Kmer6::suffix(i, 5) == Kmer6::prefix(j, 5)) p += p_step / 4;
-        for (unsigned l = 2; l < 6; ++l)
-            if (Kmer6::suffix(i, 6 - l) == Kmer6::prefix(j, 6 - l))
-                p += std::pow(static_cast<double>(p_skip_1), static_cast<double>(l - 1)) / (1u << (2 * l));
-        p += (std::pow(static_cast<double>(p_skip_1), 5.0) / (1.0f - p_skip_1)) / 4096u;
-        return p;
-    };
+    float p_step, p_skip_1;
+    nchmm::step_params(p_skip, p_stay, p_step, p_skip_1);
+    auto trans_prob = [&](unsigned i, unsigned j) { return nchmm::trans_prob(i, j, p_stay, p_step, p_skip_1); };
     // destination-major build: the predecessors of j are j, (x<<10)|(j>>2), (xy<<8)|(j>>4)
     uint32_t n = 0;
     for (unsigned j = 0; j < NCHMM_N_STATES; ++j) {

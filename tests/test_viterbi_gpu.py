@@ -227,3 +227,21 @@ def test_traceback_rewalk_path_is_exact(r73t, margin):
     ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
     assert np.array_equal(states, ostates)
     assert_bits_equal(logp, ologp, "path probability")
+
+
+def test_batched_uploads_equal_single_uploads(gpu_ctx, r73t, r9t):
+    """nchmm_put_models_scaled / nchmm_put_transitions_fast (batched, no CSR) must put exactly what
+    model_scale + put_model / transitions_fast + put_transitions put: same Viterbi bits, slots beyond 64."""
+    params = [(1.0, 0.0, 0.0, 1.0, 1.0, 1.0), (1.05, 2.5, 0.002, 1.1, 0.9, 1.2), (0.93, -4.0, 0.0, 0.8, 1.3, 0.7)]
+    trans = [(0.3, 0.1), (0.17, 0.12), (0.4, 0.05)]
+    states = np.stack([na.model_load(r73t), na.model_load(r9t)])
+    base = 200
+    gpu_ctx.put_models_scaled(base, states, [0, 0, 1], params)
+    gpu_ctx.put_transitions_fast(base, [t[0] for t in trans], [t[1] for t in trans])
+    tables = [r73t, r73t, r9t]
+    for k in range(3):
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(tables[k], [333], first_read=90 + k, drift=params[k][2])
+        slot = np.array([base + k], np.int32)
+        s_b, lp_b, _ = gpu_ctx.viterbi(off, cm, sd, ls, model_slot=slot, trans_slot=slot)
+        s_s, lp_s, _ = _run(gpu_ctx, tables[k], params[k], trans[k][0], trans[k][1], off, cm, sd, ls, slot=7)
+        assert np.array_equal(s_b, s_s) and lp_b.tobytes() == lp_s.tobytes()
