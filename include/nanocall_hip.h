@@ -205,6 +205,47 @@ int nchmm_fwbw_dev(nchmm_ctx* ctx, size_t n_win, size_t max_events, size_t total
                    float* d_out_alpha, float* d_out_beta);
 
 /* ------------------------------------------------------------------------------------------
+ * EM driver loop -- replaces the body of train_reads (src/nanocall/nanocall.cpp:292-574): window
+ * extraction :327-338, the round loop with its stop / roll-back rules :367-426 (2D) and :483-542 (1D),
+ * and threshold model selection :437-459 / :552-570 -- batched: every round, all jobs still training go
+ * through ONE nchmm_fwbw launch.
+ *
+ * A job is one iteration of the reference's model loops: (read, m0, m1) with both >= 0 when the read's
+ * strands are scaled together, or (read, m, -1) / (read, -1, m) for a single strand.  Reads are given as
+ * 2 strands each: strand st of read r owns events [strand_off[2r+st], strand_off[2r+st+1]) of mean / stdv /
+ * start (uncorrected; stdv after Event::update_logs).  model_states_Sx10 = n_models tables from
+ * nchmm_model_load (unscaled).  job_pm (n_jobs x 6) and job_st (n_jobs x 4 = {p_stay, p_skip} per strand)
+ * hold the initial parameters on entry (Fast5_Summary's pm_params_m / st_params_m) and the trained ones on
+ * return; job_fit / job_rounds receive the final fit and round count.  read_preferred (may be NULL),
+ * n_reads x 3: the job selected for strand 0, strand 1 and the 2D pair (preferred_model), or -1.
+ * Uses model slots [0, n_models + 2*jobs) and transition slots [0, 1 + 2*jobs) of the context. */
+typedef struct nchmm_train_opts {
+    uint32_t scaling_num_events;       /* --scaling-num-events      200  nanocall.cpp:72 */
+    uint32_t scaling_max_rounds;       /* --scaling-max-rounds       10  :71 (2D jobs run up to twice this, :420) */
+    float scaling_min_progress;        /* --scaling-min-progress    1.0  :70 */
+    float scaling_select_threshold;    /* --scaling-select-threshold 20  :69 (INFINITY: no selection) */
+    uint32_t min_ed_events;            /* --min-ed-events            10  :66 */
+    int32_t train_scaling;             /* !--no-train-scaling */
+    int32_t train_transitions;         /* !--no-train-transitions */
+    int32_t train_drift;               /* Parameter_Trainer::pm_train_drift() (r73: 1, r9: 0, :943-970) */
+    float default_p_stay, default_p_skip;   /* --pr-stay .1 / --pr-skip .3: what is_default() compares with */
+} nchmm_train_opts;
+
+int nchmm_train_opts_default(nchmm_train_opts* opts);
+
+/* The job list the reference's loops would visit (models in the order given; pass them sorted by name to
+ * mirror std::map).  model_strand[a] in {0, 1, 2}.  On entry *n_jobs = capacity of the arrays (which may
+ * be NULL to only count), on return the number of jobs. */
+int nchmm_train_enumerate(const nchmm_train_opts* opts, size_t n_models, const int32_t* model_strand, size_t n_reads,
+                          const uint64_t* strand_off, const uint8_t* scale_strands_together, size_t* n_jobs,
+                          int32_t* job_read, int32_t* job_m0, int32_t* job_m1);
+
+int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* opts, size_t n_models, const float* model_states_Sx10,
+                      size_t n_reads, const uint64_t* strand_off, const float* mean, const float* stdv, const float* start,
+                      size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1, float* job_pm,
+                      float* job_st, float* job_fit, uint32_t* job_rounds, int32_t* read_preferred);
+
+/* ------------------------------------------------------------------------------------------
  * Counters (what the 8-GPU run gathers with one RCCL all-reduce)
  * out[0]=reads decoded, [1]=events decoded, [2]=back-pointer bytes written, [3]=kernel launches,
  * [4]=windows (FB), [5]=FB event-rounds, [6]=device bytes allocated, [7]=reserved

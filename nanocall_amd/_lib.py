@@ -32,6 +32,9 @@ SIGNATURES = {
     "nchmm_st_train_kmers": (C.c_int, [vp, vp]),
     "nchmm_train_pm_finish": (C.c_int, [C.c_size_t, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
     "nchmm_train_st_finish": (C.c_int, [C.c_size_t, vp, vp, vp]),
+    "nchmm_train_opts_default": (C.c_int, [vp]),
+    "nchmm_train_enumerate": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]),
+    "nchmm_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),
     "nchmm_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "nchmm_destroy": (C.c_int, [vp]),
     "nchmm_last_hip_error": (C.c_int, [vp]),
@@ -52,6 +55,14 @@ SIGNATURES = {
     "nchmm_profile_blocks": (C.c_int, [vp, vp]),
     "nchmm_grid_slots": (C.c_int, [vp, vp]),
 }
+
+
+class TrainOpts(C.Structure):
+    """nchmm_train_opts"""
+    _fields_ = [("scaling_num_events", C.c_uint32), ("scaling_max_rounds", C.c_uint32), ("scaling_min_progress", C.c_float),
+                ("scaling_select_threshold", C.c_float), ("min_ed_events", C.c_uint32), ("train_scaling", C.c_int32),
+                ("train_transitions", C.c_int32), ("train_drift", C.c_int32), ("default_p_stay", C.c_float),
+                ("default_p_skip", C.c_float)]
 
 
 class NchmmError(RuntimeError):

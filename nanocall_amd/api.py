@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import lib, check, NchmmError  # noqa: F401
+from ._lib import lib, check, NchmmError, TrainOpts  # noqa: F401
 
 S = 4096
 MAX_ARCS = S * 21
@@ -122,6 +122,30 @@ def train_st_finish(st_sums):
     a, b = C.c_float(0), C.c_float(0)
     check(lib().nchmm_train_st_finish(st.shape[0], _p(st), C.byref(a), C.byref(b)), "nchmm_train_st_finish")
     return a.value, b.value
+
+
+def train_opts(**kw):
+    """nchmm_train_opts with the reference's CLI defaults, overridden by keyword."""
+    o = TrainOpts()
+    check(lib().nchmm_train_opts_default(C.byref(o)), "nchmm_train_opts_default")
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def train_enumerate(opts, model_strand, strand_off, together):
+    """Job list of train_reads -> (job_read, job_m0, job_m1) int32 arrays."""
+    ms = np.ascontiguousarray(model_strand, np.int32)
+    so = np.ascontiguousarray(strand_off, np.uint64)
+    tg = np.ascontiguousarray(together, np.uint8)
+    n_reads = tg.shape[0]
+    n = C.c_size_t(0)
+    check(lib().nchmm_train_enumerate(C.byref(opts), ms.shape[0], _p(ms), n_reads, _p(so), _p(tg), C.byref(n), None, None, None),
+          "nchmm_train_enumerate")
+    jr, j0, j1 = (np.empty(n.value, np.int32) for _ in range(3))
+    check(lib().nchmm_train_enumerate(C.byref(opts), ms.shape[0], _p(ms), n_reads, _p(so), _p(tg), C.byref(n), _p(jr), _p(j0), _p(j1)),
+          "nchmm_train_enumerate")
+    return jr, j0, j1
 
 
 # ------------------------------------------------------------------------------------------------
@@ -250,6 +274,26 @@ class Context:
                                    _dp(d_lstdv), _dp(d_scaled_slot), _dp(d_unscaled_slot), _dp(d_trans_slot),
                                    _dp(d_st_params), _dp(d_out_lpd), _dp(d_out_pm), _dp(d_out_st),
                                    _dp(d_out_alpha), _dp(d_out_beta)), "nchmm_fwbw_dev")
+
+    # -- EM driver --
+    def train_reads(self, opts, model_states, strand_off, mean, stdv, start, job_read, job_m0, job_m1, init_pm=None,
+                    init_st=None):
+        """nchmm_train_reads -> dict(pm[n_jobs,6], st[n_jobs,4], fit, rounds, preferred[n_reads,3])."""
+        st10 = _f32(model_states).reshape(-1, S, 10)
+        so = np.ascontiguousarray(strand_off, np.uint64)
+        n_reads = (so.shape[0] - 1) // 2
+        jr, j0, j1 = (np.ascontiguousarray(a, np.int32) for a in (job_read, job_m0, job_m1))
+        nj = jr.shape[0]
+        pm = np.tile(np.float32([1, 0, 0, 1, 1, 1]), (nj, 1)) if init_pm is None else _f32(init_pm).reshape(nj, 6).copy()
+        st = (np.tile(np.float32([opts.default_p_stay, opts.default_p_skip] * 2), (nj, 1)) if init_st is None
+              else _f32(init_st).reshape(nj, 4).copy())
+        fit = np.empty(nj, np.float32)
+        rounds = np.empty(nj, np.uint32)
+        pref = np.empty((n_reads, 3), np.int32)
+        check(lib().nchmm_train_reads(self._h, C.byref(opts), st10.shape[0], _p(st10), n_reads, _p(so), _p(_f32(mean)),
+                                      _p(_f32(stdv)), _p(_f32(start)), nj, _p(jr), _p(j0), _p(j1), _p(pm), _p(st), _p(fit),
+                                      _p(rounds), _p(pref)), "nchmm_train_reads")
+        return dict(pm=pm, st=st, fit=fit, rounds=rounds, preferred=pref)
 
     # -- introspection --
     def counters(self):

@@ -1,0 +1,258 @@
+// nchmm_train.cpp -- the EM driver loop of nanocall's train_reads (src/nanocall/nanocall.cpp:275-582),
+// batched across reads: every round, ALL jobs that are still training contribute their windows to one
+// nchmm_fwbw launch, then each job finishes its round on the host exactly as
+// Parameter_Trainer::train_one_round does (Parameter_Trainer.hpp:541-579) and applies the reference's
+// stop / roll-back rules (nanocall.cpp:394-426, :510-542) and model selection (:437-459, :552-570).
+//
+// A "job" is one (read, model) in per-strand mode or one (read, template model, complement model) in
+// scale_strands_together mode -- one iteration of the reference's `for m_name...` loops.
+// Pure host C++ over the C ABI (no HIP here).
+#include "nanocall_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+struct Window { uint64_t begin; uint32_t len; uint32_t strand; };
+
+struct Job {
+    int read, m[2];
+    float pm[6], st[4], fit;
+    float old_pm[6], old_st[4], old_fit;
+    unsigned round = 0;
+    bool active = true;
+    std::vector<Window> win;   // training windows, strand 0 first (nanocall.cpp:344-352)
+    bool have[2] = {false, false};
+};
+
+}  // namespace
+
+extern "C" {
+
+int nchmm_train_opts_default(nchmm_train_opts* o)
+{
+    if (!o) return NCHMM_E_INVALID;
+    o->scaling_num_events = 200;      // nanocall.cpp:72
+    o->scaling_max_rounds = 10;       // :71
+    o->scaling_min_progress = 1.0f;   // :70
+    o->scaling_select_threshold = 20.0f;   // :69
+    o->min_ed_events = 10;            // :66
+    o->train_scaling = 1; o->train_transitions = 1; o->train_drift = 1;
+    o->default_p_stay = .1f;          // :85
+    o->default_p_skip = .3f;          // :84
+    return NCHMM_OK;
+}
+
+// the model_list / pair loops of train_reads (nanocall.cpp:300-323, :356-358, :474)
+int nchmm_train_enumerate(const nchmm_train_opts* o, size_t n_models, const int32_t* model_strand, size_t n_reads,
+                          const uint64_t* strand_off, const uint8_t* together, size_t* n_jobs, int32_t* job_read,
+                          int32_t* job_m0, int32_t* job_m1)
+{
+    if (!o || !model_strand || !strand_off || !n_jobs) return NCHMM_E_INVALID;
+    const size_t cap = *n_jobs;
+    size_t n = 0;
+    auto push = [&](size_t r, int a, int b) {
+        if (job_read && n < cap) { job_read[n] = (int32_t)r; job_m0[n] = a; job_m1[n] = b; }
+        ++n;
+    };
+    for (size_t r = 0; r < n_reads; ++r) {
+        const bool ok0 = strand_off[2 * r + 1] - strand_off[2 * r] >= o->min_ed_events;
+        const bool ok1 = strand_off[2 * r + 2] - strand_off[2 * r + 1] >= o->min_ed_events;
+        if (together && together[r]) {
+            if (!ok0 || !ok1) continue;
+            for (size_t a = 0; a < n_models; ++a) {
+                if (model_strand[a] == 1) continue;
+                for (size_t b = 0; b < n_models; ++b)
+                    if (model_strand[b] != 0) push(r, (int)a, (int)b);
+            }
+        } else {
+            for (int st = 0; st < 2; ++st) {
+                if (!(st ? ok1 : ok0)) continue;
+                for (size_t a = 0; a < n_models; ++a)
+                    if (model_strand[a] == st || model_strand[a] == 2) push(r, st == 0 ? (int)a : -1, st == 1 ? (int)a : -1);
+            }
+        }
+    }
+    *n_jobs = n;
+    return (job_read && n > cap) ? NCHMM_E_NOMEM : NCHMM_OK;
+}
+
+int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models, const float* model_states_Sx10,
+                      size_t n_reads, const uint64_t* strand_off, const float* mean, const float* stdv, const float* start,
+                      size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1, float* job_pm,
+                      float* job_st, float* job_fit, uint32_t* job_rounds, int32_t* read_preferred)
+{
+    if (!ctx || !o || !model_states_Sx10 || !strand_off || !mean || !stdv || !start || !job_read || !job_m0 || !job_m1
+        || !job_pm || !job_st || !job_fit || !job_rounds)
+        return NCHMM_E_INVALID;
+    const float NEG_INF = -std::numeric_limits<float>::infinity();
+    const uint64_t total_events = strand_off[2 * n_reads];
+    // Event::update_logs happened at load time in the reference; the log of stdv is what the emission needs
+    std::vector<float> log_stdv(total_events);
+    for (uint64_t e = 0; e < total_events; ++e) log_stdv[e] = std::log(stdv[e]);
+
+    std::vector<Job> jobs(n_jobs);
+    for (size_t k = 0; k < n_jobs; ++k) {
+        Job& j = jobs[k];
+        j.read = job_read[k]; j.m[0] = job_m0[k]; j.m[1] = job_m1[k];
+        if (j.read < 0 || (size_t)j.read >= n_reads || (j.m[0] < 0 && j.m[1] < 0)) return NCHMM_E_INVALID;
+        for (int s = 0; s < 2; ++s)
+            if (j.m[s] >= (int)n_models) return NCHMM_E_INVALID;
+        std::memcpy(j.pm, job_pm + 6 * k, sizeof(j.pm));
+        std::memcpy(j.st, job_st + 4 * k, sizeof(j.st));
+        j.fit = NEG_INF;   // nanocall.cpp:365
+        for (int s = 0; s < 2; ++s) {
+            if (j.m[s] < 0) continue;
+            const uint64_t b = strand_off[2 * j.read + s], e = strand_off[2 * j.read + s + 1];
+            const uint64_t n_ev = e - b;
+            if (n_ev < o->min_ed_events) { if (j.m[1 - s] < 0) j.active = false; continue; }
+            // nanocall.cpp:333-337: first and last num_train_events / 2 events
+            const uint64_t num = std::min<uint64_t>(o->scaling_num_events, n_ev);
+            const uint32_t half = (uint32_t)(num / 2);
+            j.win.push_back(Window{b, half, (uint32_t)s});
+            j.win.push_back(Window{e - half, half, (uint32_t)s});
+            j.have[s] = true;
+        }
+        if (j.win.empty()) j.active = false;
+    }
+
+    // unscaled models: slots [0, n_models) (identity scaling reproduces the loaded table bit for bit)
+    int rc;
+    {
+        std::vector<int32_t> idx(n_models);
+        std::vector<float> ident(6 * n_models);
+        for (size_t a = 0; a < n_models; ++a) {
+            idx[a] = (int32_t)a;
+            const float id[6] = {1, 0, 0, 1, 1, 1};
+            std::memcpy(&ident[6 * a], id, sizeof(id));
+        }
+        if ((rc = nchmm_put_models_scaled(ctx, 0, n_models, model_states_Sx10, idx.data(), ident.data()))) return rc;
+        if ((rc = nchmm_put_transitions_fast(ctx, 0, 1, &o->default_p_skip, &o->default_p_stay))) return rc;
+    }
+
+    std::vector<size_t> act;
+    for (;;) {
+        act.clear();
+        for (size_t k = 0; k < n_jobs; ++k) if (jobs[k].active) act.push_back(k);
+        if (act.empty()) break;
+        const size_t na = act.size();
+        // ---- Parameter_Trainer::fill_train_data (Parameter_Trainer.hpp:99-155), all active jobs at once ----
+        std::vector<int32_t> m_idx; std::vector<float> m_par;         // scaled models: slot n_models + 2p + s
+        std::vector<float> t_skip(2 * na, o->default_p_skip), t_stay(2 * na, o->default_p_stay);
+        std::vector<uint64_t> off{0};
+        std::vector<float> cm, sd, ls, raw_mean, raw_start, stp;
+        std::vector<int32_t> s_slot, u_slot, t_slot;
+        std::vector<size_t> first_win(na + 1, 0);
+        m_idx.assign(2 * na, 0); m_par.assign(12 * na, 0.f);
+        for (size_t p = 0; p < na; ++p) {
+            Job& j = jobs[act[p]];
+            std::memcpy(j.old_pm, j.pm, sizeof(j.pm)); std::memcpy(j.old_st, j.st, sizeof(j.st)); j.old_fit = j.fit;
+            for (int s = 0; s < 2; ++s) {
+                m_idx[2 * p + s] = j.m[s] >= 0 ? j.m[s] : std::max(j.m[0], j.m[1]);
+                std::memcpy(&m_par[6 * (2 * p + s)], j.old_pm, sizeof(j.old_pm));
+                t_stay[2 * p + s] = j.old_st[2 * s]; t_skip[2 * p + s] = j.old_st[2 * s + 1];
+            }
+            for (const Window& w : j.win) {
+                for (uint32_t i = 0; i < w.len; ++i) {
+                    const uint64_t e = w.begin + i;
+                    float c = mean[e];
+                    c -= j.old_pm[2] * start[e];   // apply_drift_correction, Event.hpp:77-84
+                    cm.push_back(c); sd.push_back(stdv[e]); ls.push_back(log_stdv[e]);
+                    raw_mean.push_back(mean[e]); raw_start.push_back(start[e]);
+                }
+                off.push_back(cm.size());
+                s_slot.push_back((int32_t)(n_models + 2 * p + w.strand));
+                u_slot.push_back(j.m[w.strand]);
+                // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
+                const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
+                t_slot.push_back(dflt ? 0 : (int32_t)(1 + 2 * p + w.strand));
+                stp.push_back(j.old_st[2 * w.strand]); stp.push_back(j.old_st[2 * w.strand + 1]);
+            }
+            first_win[p + 1] = s_slot.size();
+        }
+        if ((rc = nchmm_put_models_scaled(ctx, (int)n_models, 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
+        if ((rc = nchmm_put_transitions_fast(ctx, 1, 2 * na, t_skip.data(), t_stay.data()))) return rc;
+        const size_t n_win = s_slot.size(), tot = cm.size();
+        std::vector<float> lpd(n_win), pm_sums(6 * tot), st_sums(3 * n_win);
+        rc = nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), u_slot.data(), t_slot.data(),
+                        stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr);
+        if (rc != NCHMM_OK) return rc;
+        // ---- finish the round per job (Parameter_Trainer.hpp:557-578) and apply the stop rules ----
+        for (size_t p = 0; p < na; ++p) {
+            Job& j = jobs[act[p]];
+            const size_t w0 = first_win[p], w1 = first_win[p + 1];
+            float fit = 0;
+            for (size_t w = w0; w < w1; ++w) fit += lpd[w];   // data.fit += log_pr_data, :154
+            j.fit = fit;
+            bool done = false;
+            if (o->train_scaling) {
+                const size_t e0 = off[w0], e1 = off[w1];
+                int d = 0;
+                rc = nchmm_train_pm_finish(e1 - e0, &pm_sums[6 * e0], &raw_mean[e0], &sd[e0], &raw_start[e0], o->train_drift,
+                                           j.old_pm, j.pm, &d);
+                if (rc != NCHMM_OK) return rc;
+                done = d != 0;
+            }
+            if (done) {
+                std::memcpy(j.st, j.old_st, sizeof(j.st));   // new_st_params = crt_st_params, :568-572
+            } else if (o->train_transitions) {
+                for (int s = 0; s < 2; ++s) {
+                    if (!j.have[s]) continue;   // (the reference leaves NaN in the absent strand's slot; it is never read)
+                    std::vector<float> mine;
+                    for (size_t w = w0; w < w1; ++w)
+                        if (j.win[w - w0].strand == (uint32_t)s) mine.insert(mine.end(), &st_sums[3 * w], &st_sums[3 * w] + 3);
+                    rc = nchmm_train_st_finish(mine.size() / 3, mine.data(), &j.st[2 * s], &j.st[2 * s + 1]);
+                    if (rc != NCHMM_OK) return rc;
+                }
+            }
+            // nanocall.cpp:394-426 (2D) / :510-542 (1D)
+            if (done) { j.active = false; continue; }
+            if (j.fit < j.old_fit) {   // regression: roll back
+                std::memcpy(j.pm, j.old_pm, sizeof(j.pm)); std::memcpy(j.st, j.old_st, sizeof(j.st)); j.fit = j.old_fit;
+                j.active = false;
+                continue;
+            }
+            ++j.round;
+            const bool two_d = j.m[0] >= 0 && j.m[1] >= 0;
+            const unsigned limit = two_d ? 2u * o->scaling_max_rounds : o->scaling_max_rounds;
+            if (j.round >= limit || (j.round > 1 && j.fit < j.old_fit + o->scaling_min_progress)) j.active = false;
+        }
+    }
+    for (size_t k = 0; k < n_jobs; ++k) {
+        std::memcpy(job_pm + 6 * k, jobs[k].pm, sizeof(jobs[k].pm));
+        std::memcpy(job_st + 4 * k, jobs[k].st, sizeof(jobs[k].st));
+        job_fit[k] = jobs[k].fit; job_rounds[k] = jobs[k].round;
+    }
+    // ---- model selection, nanocall.cpp:437-459 / :552-570 ----
+    if (read_preferred) {
+        for (size_t i = 0; i < 3 * n_reads; ++i) read_preferred[i] = -1;
+        if (o->scaling_select_threshold < std::numeric_limits<float>::infinity()) {
+            for (size_t r = 0; r < n_reads; ++r)
+                for (int kind = 0; kind < 3; ++kind) {
+                    long best = -1;
+                    for (size_t k = 0; k < n_jobs; ++k) {
+                        const Job& j = jobs[k];
+                        const int jk = (j.m[0] >= 0 && j.m[1] >= 0) ? 2 : (j.m[0] >= 0 ? 0 : 1);
+                        if ((size_t)j.read != r || jk != kind || j.win.empty()) continue;
+                        if (best < 0 || j.fit > jobs[best].fit) best = (long)k;   // first maximum
+                    }
+                    if (best < 0) continue;
+                    bool unique = true;
+                    for (size_t k = 0; k < n_jobs && unique; ++k) {
+                        const Job& j = jobs[k];
+                        const int jk = (j.m[0] >= 0 && j.m[1] >= 0) ? 2 : (j.m[0] >= 0 ? 0 : 1);
+                        if ((size_t)j.read != r || jk != kind || j.win.empty() || (long)k == best) continue;
+                        if (!(j.fit + o->scaling_select_threshold < jobs[best].fit)) unique = false;
+                    }
+                    if (unique) read_preferred[3 * r + kind] = (int32_t)best;
+                }
+        }
+    }
+    return NCHMM_OK;
+}
+
+}  // extern "C"

@@ -94,13 +94,6 @@ __device__ __forceinline__ unsigned swap1(unsigned v)
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ unsigned pred_of(unsigned j, unsigned slot)
-{
-    if (slot == 0) return j;
-    if (slot < 5) return ((slot - 1) << 10) | (j >> 2);
-    return ((slot - 5) << 8) | (j >> 4);
-}
-
 // byte of state j inside its 16-byte group: k = j >> 8 = 4x + y  ->  ((y&1)<<3) | (x<<1) | (y>>1)
 __device__ __forceinline__ unsigned bp_pos(unsigned k) { return ((k & 1u) << 3) | ((k >> 2) << 1) | ((k >> 1) & 1u); }
 

@@ -1,0 +1,95 @@
+"""The batched EM driver (nchmm_train_reads = train_reads of nanocall.cpp:292-574) against a straight
+transcription of that loop driven by the CPU oracle's train_one_round: same control flow (round counts,
+roll-backs, selected models), parameters within the EM tolerances of test_fwbw_gpu.py."""
+import numpy as np
+import pytest
+
+import nanocall_amd as na
+from nanocall_amd import api, synth
+import nc_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_train_job(opts, tables, windows, strands, m, pm, st):
+    """One iteration of the reference's model loop (nanocall.cpp:360-426 / :476-542) on the oracle."""
+    off = np.concatenate([[0], np.cumsum([len(w[0]) for w in windows])]).astype(np.uint64)
+    mean = np.concatenate([w[0] for w in windows]); stdv = np.concatenate([w[1] for w in windows])
+    start = np.concatenate([w[2] for w in windows])
+    two_d = m[0] >= 0 and m[1] >= 0
+    t0 = tables[m[0] if m[0] >= 0 else m[1]]
+    t1 = tables[m[1] if m[1] >= 0 else m[0]]
+    crt_pm, crt_st, crt_fit, rnd = np.float32(pm), np.float32(st), np.float32(-np.inf), 0
+    while True:
+        old_pm, old_st, old_fit = crt_pm.copy(), crt_st.copy(), crt_fit
+        r = oracle.train_one_round(off, np.asarray(strands, np.uint32), mean, stdv, start, t0, t1, old_pm, old_st,
+                                   opts.default_p_stay, opts.default_p_skip, opts.train_drift, bool(opts.train_scaling),
+                                   bool(opts.train_transitions))
+        crt_pm, crt_fit = r["pm"], r["fit"]
+        new_st = r["st"].copy()
+        for s in range(2):                      # the oracle leaves NaN for an absent strand, like the reference
+            if s not in strands:
+                new_st[2 * s:2 * s + 2] = old_st[2 * s:2 * s + 2]
+        crt_st = new_st
+        if r["done"]:
+            break
+        if crt_fit < old_fit:
+            crt_pm, crt_st, crt_fit = old_pm, old_st, old_fit
+            break
+        rnd += 1
+        limit = 2 * opts.scaling_max_rounds if two_d else opts.scaling_max_rounds
+        if rnd >= limit or (rnd > 1 and crt_fit < old_fit + opts.scaling_min_progress):
+            break
+    return crt_pm, crt_st, crt_fit, rnd
+
+
+def test_train_reads_matches_reference_loop(gpu_ctx):
+    opts = api.train_opts(scaling_max_rounds=2, scaling_num_events=120, scaling_select_threshold=5.0)
+    names = ["r73.c.p1", "r73.c.p2", "r73.t"]           # sorted by name, like the reference's std::map
+    strands = [1, 1, 0]
+    tables = [na.builtin_model(n) for n in names]
+    states = np.stack([na.model_load(t) for t in tables])
+    # read 0: 2D (template from r73.t, complement from r73.c.p1); read 1: template only; read 2: complement too short
+    ev = [(synth.generate(tables[2], 1, 700, first_read=500), synth.generate(tables[0], 1, 650, first_read=501)),
+          (synth.generate(tables[2], 1, 90, first_read=502), None),
+          (synth.generate(tables[2], 1, 300, first_read=503), synth.generate(tables[1], 1, 4, first_read=504))]
+    together = [1, 0, 0]
+    mean, stdv, start, so = [], [], [], [0]
+    for e0, e1 in ev:
+        for e in (e0, e1):
+            if e is not None:
+                m, s, t = e["mean"][0], e["stdv"][0], e["start"][0]
+                _, s, _ = na.events_prepare(m, s, t, 0.0)      # Event::update_logs: stdv 0 -> .01
+                mean.append(m); stdv.append(s); start.append(t)
+            so.append(so[-1] + (0 if e is None else len(e["mean"][0])))
+    mean, stdv, start = np.concatenate(mean), np.concatenate(stdv), np.concatenate(start)
+    so = np.array(so, np.uint64)
+    jr, j0, j1 = api.train_enumerate(opts, strands, so, together)
+    # read 0 -> (t, c.p1), (t, c.p2); read 1 -> (t,-1); read 2 -> (t,-1) only (4 complement events < min_ed_events)
+    assert list(zip(jr, j0, j1)) == [(0, 2, 0), (0, 2, 1), (1, 2, -1), (2, 2, -1)]
+    out = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    for k, (r, a, b) in enumerate(zip(jr, j0, j1)):
+        windows, wst = [], []
+        for s, mm in ((0, a), (1, b)):
+            if mm < 0:
+                continue
+            lo, hi = int(so[2 * r + s]), int(so[2 * r + s + 1])
+            half = min(opts.scaling_num_events, hi - lo) // 2
+            for sl in (slice(lo, lo + half), slice(hi - half, hi)):
+                windows.append((mean[sl], stdv[sl], start[sl])); wst.append(s)
+        pm, st, fit, rnd = reference_train_job(opts, tables, windows, wst, (a, b), [1, 0, 0, 1, 1, 1], [0.1, 0.3, 0.1, 0.3])
+        assert out["rounds"][k] == rnd, (k, out["rounds"][k], rnd)
+        assert abs(out["fit"][k] - fit) <= 1e-4 * abs(fit), (k, out["fit"][k], fit)
+        got = out["pm"][k]
+        for q in (0, 4, 5):
+            assert abs(got[q] - pm[q]) <= 2e-4 * abs(pm[q]), (k, q, got, pm)
+        assert abs(got[3] - pm[3]) <= 1e-3 * abs(pm[3]), (k, got, pm)           # var: see test_fwbw_gpu.py
+        assert abs(got[1] - pm[1]) <= 2e-4 * 60 and abs(got[2] - pm[2]) <= 2e-4 * 60 / max(float(start.max()), 1.0)
+        assert np.allclose(out["st"][k], st, rtol=5e-4, atol=0), (k, out["st"][k], st)
+    # selection: read 0's pair trained on the matching complement model must win by > threshold or not at all,
+    # exactly as the oracle-side fits say
+    fits = out["fit"][:2]
+    exp = int(np.argmax(fits)) if abs(fits[0] - fits[1]) > opts.scaling_select_threshold else -1
+    assert out["preferred"][0, 2] == exp
+    assert out["preferred"][1, 0] == 2 and out["preferred"][2, 0] == 3       # single candidates are always preferred
+    assert out["preferred"][2, 1] == -1 and out["preferred"][0, 0] == -1
