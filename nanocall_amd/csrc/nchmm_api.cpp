@@ -43,6 +43,8 @@ struct nchmm_ctx {
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
+    size_t h_pin_bytes = 0;
     hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_vit2 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
     bool vit_timed = false, fb_timed = false;
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -157,34 +159,24 @@ int factor_transitions(const uint32_t* row_ptr, const uint16_t* pred, const floa
 void fb_weights(const float* w, float* out)
 {
     const float* w0 = w; const float* w1 = w + kStates; const float* w2 = w + kStates + 1024;
+    auto fold = [](float lw0, float lw1, float lw2, bool stay_in_step, bool stay_in_skip, bool step_in_skip, float* c0,
+                   float* c1, float* c2) {
+        if (!stay_in_step && !stay_in_skip && !step_in_skip) {   // the common case: nothing to fold
+            *c0 = lw0; *c1 = lw1; *c2 = lw2;
+            return;
+        }
+        const double T0 = std::exp((double)lw0), W1 = std::exp((double)lw1), W2 = std::exp((double)lw2);
+        *c0 = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
+        *c1 = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
+        *c2 = lw2;
+    };
     for (unsigned j = 0; j < (unsigned)kStates; ++j) {
-        const double T0 = std::exp((double)w0[j]);
-        {   // forward: groups of predecessors, indexed by the consumer's high bits
-            const double W1 = std::exp((double)w1[j >> 2]), W2 = std::exp((double)w2[j >> 4]);
-            const bool stay_in_step = (j & 1023u) == (j >> 2);
-            const bool stay_in_skip = (j & 255u) == (j >> 4);
-            const bool step_in_skip = ((j >> 2) & 255u) == (j >> 4);
-            if (!stay_in_step && !stay_in_skip && !step_in_skip) {   // the common case: nothing to fold
-                out[0 * kStates + j] = w0[j]; out[1 * kStates + j] = w1[j >> 2]; out[2 * kStates + j] = w2[j >> 4];
-            } else {
-                out[0 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
-                out[1 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
-                out[2 * kStates + j] = (float)std::log(W2);
-            }
-        }
-        {   // backward: groups of successors, indexed by the source's low bits
-            const double W1 = std::exp((double)w1[j & 1023u]), W2 = std::exp((double)w2[j & 255u]);
-            const bool stay_in_step = (j >> 2) == (j & 1023u);
-            const bool stay_in_skip = (j >> 4) == (j & 255u);
-            const bool step_in_skip = ((j & 1023u) >> 2) == (j & 255u);
-            if (!stay_in_step && !stay_in_skip && !step_in_skip) {
-                out[3 * kStates + j] = w0[j]; out[4 * kStates + j] = w1[j & 1023u]; out[5 * kStates + j] = w2[j & 255u];
-            } else {
-                out[3 * kStates + j] = (float)std::log(T0 - (stay_in_step ? W1 : 0.0) - (stay_in_skip && !stay_in_step ? W2 : 0.0));
-                out[4 * kStates + j] = (float)std::log(W1 - (step_in_skip ? W2 : 0.0));
-                out[5 * kStates + j] = (float)std::log(W2);
-            }
-        }
+        // forward: groups of predecessors, indexed by the consumer's high bits
+        fold(w0[j], w1[j >> 2], w2[j >> 4], (j & 1023u) == (j >> 2), (j & 255u) == (j >> 4), ((j >> 2) & 255u) == (j >> 4),
+             &out[0 * kStates + j], &out[1 * kStates + j], &out[2 * kStates + j]);
+        // backward: groups of successors, indexed by the source's low bits
+        fold(w0[j], w1[j & 1023u], w2[j & 255u], (j >> 2) == (j & 1023u), (j >> 4) == (j & 255u),
+             ((j & 1023u) >> 2) == (j & 255u), &out[3 * kStates + j], &out[4 * kStates + j], &out[5 * kStates + j]);
     }
 }
 
@@ -223,31 +215,72 @@ void parallel_for(size_t n, F&& f)
     for (auto& t : th) t.join();
 }
 
-// w0 | w1 | w2 of compute_transitions_fast(p_skip, p_stay) from one representative arc per class
+// w0 | w1 | w2 of compute_transitions_fast(p_skip, p_stay).  get_trans_prob is a function of the 6-bit
+// overlap mask of (i, j) only, so one representative arc per class gives the class's mask, and the
+// weight is evaluated once per distinct mask (18 of them) instead of once per arc.
+struct MaskTables {
+    uint8_t m0[kStates], m1[1024], m2[256];   // overlap mask of the stay arc / step-group arc / skip-group arc
+    uint16_t rep_i[64], rep_j[64];            // one arc (i -> j) having each mask
+    bool used[64];
+    MaskTables()
+    {
+        std::memset(used, 0, sizeof(used));
+        auto mask = [](unsigned i, unsigned j) {
+            unsigned m = i == j ? 1u : 0u;
+            for (unsigned l = 1; l < 6; ++l)
+                if (Kmer6::suffix(i, 6 - l) == Kmer6::prefix(j, 6 - l)) m |= 1u << l;
+            return m;
+        };
+        auto note = [&](unsigned i, unsigned j) {
+            const unsigned m = mask(i, j);
+            if (!used[m]) { used[m] = true; rep_i[m] = (uint16_t)i; rep_j[m] = (uint16_t)j; }
+            return (uint8_t)m;
+        };
+        for (unsigned j = 0; j < (unsigned)kStates; ++j) m0[j] = note(j, j);
+        for (unsigned r = 0; r < 1024; ++r) {
+            // a step arc p -> j with p & 1023 == r == j >> 2 that is not the stay arc
+            unsigned p = r, j = r << 2;            // x = 0, a = 0
+            if (p == j) j |= 1u;                   // r == 0: p = j = 0
+            m1[r] = note(p, j);
+        }
+        for (unsigned q = 0; q < 256; ++q) {
+            // a skip arc p -> j with p & 255 == q == j >> 4 that is neither a step arc nor the stay arc
+            bool found = false;
+            for (unsigned xy = 0; xy < 16 && !found; ++xy)
+                for (unsigned ab = 0; ab < 16 && !found; ++ab) {
+                    const unsigned p = (xy << 8) | q, j = (q << 4) | ab;
+                    if (p == j || (p & 1023u) == (j >> 2)) continue;
+                    m2[q] = note(p, j);
+                    found = true;
+                }
+        }
+    }
+};
+
 void fast_transition_weights(float p_skip, float p_stay, float* out)
 {
+    static const MaskTables T;
     float p_step, p_skip_1;
     step_params(p_skip, p_stay, p_step, p_skip_1);
+    float wm[64];
+    for (unsigned m = 0; m < 64; ++m)
+        wm[m] = T.used[m] ? std::log(trans_prob(T.rep_i[m], T.rep_j[m], p_stay, p_step, p_skip_1)) : 0.0f;
     float* w0 = out; float* w1 = out + kStates; float* w2 = out + kStates + 1024;
-    for (unsigned j = 0; j < (unsigned)kStates; ++j) w0[j] = std::log(trans_prob(j, j, p_stay, p_step, p_skip_1));
-    for (unsigned r = 0; r < 1024; ++r) {
-        // a step arc p -> j with p & 1023 == r == j >> 2 that is not the stay arc
-        unsigned p = r, j = r << 2;            // x = 0, a = 0
-        if (p == j) j |= 1u;                   // r == 0: p = j = 0
-        w1[r] = std::log(trans_prob(p, j, p_stay, p_step, p_skip_1));
+    for (unsigned j = 0; j < (unsigned)kStates; ++j) w0[j] = wm[T.m0[j]];
+    for (unsigned r = 0; r < 1024; ++r) w1[r] = wm[T.m1[r]];
+    for (unsigned q = 0; q < 256; ++q) w2[q] = wm[T.m2[q]];
+}
+
+int pinned(nchmm_ctx* c, size_t bytes, void** out)
+{
+    if (c->h_pin_bytes < bytes) {
+        if (c->h_pin) { HIP_TRY(c, hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_bytes = 0; }
+        bytes += bytes / 8;
+        HIP_TRY(c, hipHostMalloc(&c->h_pin, bytes, hipHostMallocDefault));
+        c->h_pin_bytes = bytes;
     }
-    for (unsigned q = 0; q < 256; ++q) {
-        // a skip arc p -> j with p & 255 == q == j >> 4 that is neither a step arc nor the stay arc
-        float w = 0; bool found = false;
-        for (unsigned xy = 0; xy < 16 && !found; ++xy)
-            for (unsigned ab = 0; ab < 16 && !found; ++ab) {
-                const unsigned p = (xy << 8) | q, j = (q << 4) | ab;
-                if (p == j || (p & 1023u) == (j >> 2)) continue;
-                w = std::log(trans_prob(p, j, p_stay, p_step, p_skip_1));
-                found = true;
-            }
-        w2[q] = w;
-    }
+    *out = c->h_pin;
+    return NCHMM_OK;
 }
 
 // Grow the slot tables (models, Viterbi weights, FB weights, fast flags) to hold n slots, keeping
@@ -361,6 +394,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_last_state) (void)hipFree(c->d_last_state);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->ev_vit0) (void)hipEventDestroy(c->ev_vit0);
     if (c->ev_vit1) (void)hipEventDestroy(c->ev_vit1);
     if (c->ev_vit2) (void)hipEventDestroy(c->ev_vit2);
@@ -424,14 +458,16 @@ int nchmm_put_models_scaled(nchmm_ctx* c, int first_slot, size_t n, const float*
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = reserve_slots(c, first_slot + (int)n);
     if (rc != NCHMM_OK) return rc;
-    std::vector<float> img((size_t)n * kModelFloats);
+    void* hp = nullptr;
+    if ((rc = pinned(c, sizeof(float) * n * kModelFloats, &hp))) return rc;
+    float* const img = (float*)hp;
     std::vector<int32_t> fast(n, 1);
     auto work = [&](size_t a, size_t b) {
         for (size_t k = a; k < b; ++k) {
             const float* st = states_Sx10 + (size_t)(table_idx ? table_idx[k] : 0) * kStates * 10;
             const float* p = params_nx6 + 6 * k;
             const float log_var = std::log(p[3]), log_var_sd = std::log(p[5]);
-            float* im = img.data() + k * kModelFloats;
+            float* im = img + k * kModelFloats;
             for (int j = 0; j < kStates; ++j) {
                 const float* s = st + (size_t)j * 10;
                 const float level_mean = s[0] * p[0] + p[1];
@@ -446,7 +482,7 @@ int nchmm_put_models_scaled(nchmm_ctx* c, int first_slot, size_t n, const float*
     };
     parallel_for(n, work);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(c->d_models + (size_t)first_slot * kModelFloats, img.data(), sizeof(float) * img.size(),
+    HIP_TRY(c, hipMemcpy(c->d_models + (size_t)first_slot * kModelFloats, img, sizeof(float) * n * kModelFloats,
                          hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_model_fast + first_slot, fast.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     for (size_t k = 0; k < n; ++k) c->model_set[first_slot + k] = 1;
@@ -464,17 +500,20 @@ int nchmm_put_transitions_fast(nchmm_ctx* c, int first_slot, size_t n, const flo
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = reserve_slots(c, first_slot + (int)n);
     if (rc != NCHMM_OK) return rc;
-    std::vector<float> w((size_t)n * kTransFloats), fb((size_t)n * kFbTransFloats);
+    void* hp = nullptr;
+    if ((rc = pinned(c, sizeof(float) * n * (kTransFloats + kFbTransFloats), &hp))) return rc;
+    float* const w = (float*)hp;
+    float* const fb = w + n * kTransFloats;
     auto work = [&](size_t a, size_t b) {
         for (size_t k = a; k < b; ++k) {
-            fast_transition_weights(p_skip[k], p_stay[k], w.data() + k * kTransFloats);
-            fb_weights(w.data() + k * kTransFloats, fb.data() + k * kFbTransFloats);
+            fast_transition_weights(p_skip[k], p_stay[k], w + k * kTransFloats);
+            fb_weights(w + k * kTransFloats, fb + k * kFbTransFloats);
         }
     };
     parallel_for(n, work);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(c->d_trans + (size_t)first_slot * kTransFloats, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_trans_fb + (size_t)first_slot * kFbTransFloats, fb.data(), sizeof(float) * fb.size(),
+    HIP_TRY(c, hipMemcpy(c->d_trans + (size_t)first_slot * kTransFloats, w, sizeof(float) * n * kTransFloats, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_trans_fb + (size_t)first_slot * kFbTransFloats, fb, sizeof(float) * n * kFbTransFloats,
                          hipMemcpyHostToDevice));
     for (size_t k = 0; k < n; ++k) c->trans_set[first_slot + k] = 1;
     return NCHMM_OK;
