@@ -245,6 +245,20 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* opts, size_t n_mod
                       size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1, float* job_pm,
                       float* job_st, float* job_fit, uint32_t* job_rounds, int32_t* read_preferred);
 
+/* basecall_reads (src/nanocall/nanocall.cpp:593-868) for the same reads / jobs: every candidate job (the
+ * preferred one where read_preferred names one, else all jobs of the read) is Viterbi-decoded with its
+ * trained parameters -- `pm.scale(pm_params)`, custom transitions unless default, drift-corrected events
+ * (:645-690) -- in one batched launch; 2D jobs are ranked by the float sum of their two path
+ * log-probabilities (:725-739), single-strand jobs by their own (:807-825), highest wins (the later
+ * candidate on an exact tie, as `sort ... back()`).  out_state is indexed like mean/stdv/start and
+ * receives the winner's Event::model_state_idx for every decoded strand; out_best_job / out_best_logp are
+ * n_reads x 2 (per strand; -1 / NaN where nothing was decoded). */
+int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* opts, size_t n_models, const float* model_states_Sx10,
+                         size_t n_reads, const uint64_t* strand_off, const float* mean, const float* stdv, const float* start,
+                         size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1,
+                         const float* job_pm, const float* job_st, const int32_t* read_preferred, uint16_t* out_state,
+                         int32_t* out_best_job, float* out_best_logp);
+
 /* ------------------------------------------------------------------------------------------
  * Counters (what the 8-GPU run gathers with one RCCL all-reduce)
  * out[0]=reads decoded, [1]=events decoded, [2]=back-pointer bytes written, [3]=kernel launches,

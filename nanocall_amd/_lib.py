@@ -35,6 +35,7 @@ SIGNATURES = {
     "nchmm_train_opts_default": (C.c_int, [vp]),
     "nchmm_train_enumerate": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]),
     "nchmm_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),
+    "nchmm_basecall_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 9),
     "nchmm_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "nchmm_destroy": (C.c_int, [vp]),
     "nchmm_last_hip_error": (C.c_int, [vp]),

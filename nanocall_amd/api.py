@@ -295,6 +295,25 @@ class Context:
                                       _p(rounds), _p(pref)), "nchmm_train_reads")
         return dict(pm=pm, st=st, fit=fit, rounds=rounds, preferred=pref)
 
+    def basecall_reads(self, opts, model_states, strand_off, mean, stdv, start, job_read, job_m0, job_m1, job_pm, job_st,
+                       preferred=None):
+        """nchmm_basecall_reads -> dict(states u16[total], best_job i32[n_reads,2], best_logp f32[n_reads,2])."""
+        st10 = _f32(model_states).reshape(-1, S, 10)
+        so = np.ascontiguousarray(strand_off, np.uint64)
+        n_reads = (so.shape[0] - 1) // 2
+        jr, j0, j1 = (np.ascontiguousarray(a, np.int32) for a in (job_read, job_m0, job_m1))
+        pm, st = _f32(job_pm).reshape(-1, 6), _f32(job_st).reshape(-1, 4)
+        pref = None if preferred is None else np.ascontiguousarray(preferred, np.int32).reshape(n_reads, 3)
+        states = np.zeros(int(so[-1]), np.uint16)
+        bj = np.empty((n_reads, 2), np.int32)
+        bl = np.empty((n_reads, 2), np.float32)
+        rc = lib().nchmm_basecall_reads(self._h, C.byref(opts), st10.shape[0], _p(st10), n_reads, _p(so), _p(_f32(mean)),
+                                        _p(_f32(stdv)), _p(_f32(start)), jr.shape[0], _p(jr), _p(j0), _p(j1), _p(pm), _p(st),
+                                        _p(pref), _p(states), _p(bj), _p(bl))
+        if rc not in (0, -6):
+            check(rc, "nchmm_basecall_reads")
+        return dict(states=states, best_job=bj, best_logp=bl)
+
     # -- introspection --
     def counters(self):
         out = np.zeros(8, np.uint64)

@@ -255,4 +255,100 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     return NCHMM_OK;
 }
 
+// basecall_reads, nanocall.cpp:593-868: for every read, Viterbi-decode each candidate model (pair) with
+// its trained parameters and keep the one with the highest (summed) path log-probability.
+int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models, const float* model_states_Sx10,
+                         size_t n_reads, const uint64_t* strand_off, const float* mean, const float* stdv, const float* start,
+                         size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1,
+                         const float* job_pm, const float* job_st, const int32_t* read_preferred, uint16_t* out_state,
+                         int32_t* out_best_job, float* out_best_logp)
+{
+    if (!ctx || !o || !model_states_Sx10 || !strand_off || !mean || !stdv || !start || !job_read || !job_m0 || !job_m1
+        || !job_pm || !job_st || !out_state || !out_best_job || !out_best_logp)
+        return NCHMM_E_INVALID;
+    const uint64_t total_events = strand_off[2 * n_reads];
+    std::vector<float> log_stdv(total_events);
+    for (uint64_t e = 0; e < total_events; ++e) log_stdv[e] = std::log(stdv[e]);
+    // candidate list (nanocall.cpp:696-709 / :790-806): the preferred job if one was selected, else every job
+    struct Cand { size_t job; int strand; size_t vread; };
+    std::vector<Cand> cands;
+    std::vector<uint64_t> off{0};
+    std::vector<float> cm, sd, ls;
+    std::vector<int32_t> m_idx, slot_m, slot_t;
+    std::vector<float> m_par, t_skip, t_stay;
+    for (size_t k = 0; k < n_jobs; ++k) {
+        const int r = job_read[k];
+        if (r < 0 || (size_t)r >= n_reads) return NCHMM_E_INVALID;
+        const int kind = (job_m0[k] >= 0 && job_m1[k] >= 0) ? 2 : (job_m0[k] >= 0 ? 0 : 1);
+        if (read_preferred && read_preferred[3 * r + kind] >= 0 && read_preferred[3 * r + kind] != (int32_t)k) continue;
+        const int m[2] = {job_m0[k], job_m1[k]};
+        for (int s = 0; s < 2; ++s) {
+            if (m[s] < 0) continue;
+            if (m[s] >= (int)n_models) return NCHMM_E_INVALID;
+            const uint64_t b = strand_off[2 * r + s], e = strand_off[2 * r + s + 1];
+            if (e - b < o->min_ed_events) continue;
+            const float drift = job_pm[6 * k + 2];
+            for (uint64_t i = b; i < e; ++i) {
+                float c = mean[i];
+                c -= drift * start[i];   // corrected_events.apply_drift_correction(pm_params.drift), nanocall.cpp:685-686
+                cm.push_back(c); sd.push_back(stdv[i]); ls.push_back(log_stdv[i]);
+            }
+            off.push_back(cm.size());
+            const size_t v = cands.size();
+            cands.push_back(Cand{k, s, v});
+            m_idx.push_back(m[s]);
+            m_par.insert(m_par.end(), job_pm + 6 * k, job_pm + 6 * k + 6);
+            const float p_stay = job_st[4 * k + 2 * s], p_skip = job_st[4 * k + 2 * s + 1];
+            t_stay.push_back(p_stay); t_skip.push_back(p_skip);
+            slot_m.push_back((int32_t)v);
+            slot_t.push_back((int32_t)v);
+        }
+    }
+    for (size_t i = 0; i < 2 * n_reads; ++i) { out_best_job[i] = -1; out_best_logp[i] = std::numeric_limits<float>::quiet_NaN(); }
+    if (cands.empty()) return NCHMM_OK;
+    int rc;
+    if ((rc = nchmm_put_models_scaled(ctx, 0, cands.size(), model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
+    if ((rc = nchmm_put_transitions_fast(ctx, 0, cands.size(), t_skip.data(), t_stay.data()))) return rc;
+    std::vector<uint16_t> states(cm.size());
+    std::vector<float> logp(cands.size());
+    std::vector<int32_t> status(cands.size());
+    rc = nchmm_viterbi(ctx, cands.size(), off.data(), cm.data(), sd.data(), ls.data(), slot_m.data(), slot_t.data(), states.data(),
+                       logp.data(), status.data());
+    if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) return rc;
+    // choose per read: 2D jobs by the float sum of both strands (:725-739), 1D jobs per strand (:807-825);
+    // `sort ... back()` = the highest value, the later candidate among exact ties
+    std::vector<float> best_total(2 * n_reads, -std::numeric_limits<float>::infinity());
+    std::vector<long> best_c0(2 * n_reads, -1), best_c1(2 * n_reads, -1);
+    for (size_t v = 0; v < cands.size();) {
+        const size_t k = cands[v].job;
+        const int r = job_read[k];
+        const bool two_d = job_m0[k] >= 0 && job_m1[k] >= 0;
+        if (two_d && v + 1 < cands.size() && cands[v + 1].job == k) {
+            const float tot = logp[v] + logp[v + 1];
+            if (tot >= best_total[2 * r] || best_c0[2 * r] < 0) { best_total[2 * r] = tot; best_c0[2 * r] = (long)v; best_c1[2 * r] = (long)v + 1; }
+            v += 2;
+        } else {
+            const int s = cands[v].strand;
+            if (!two_d && (logp[v] >= best_total[2 * r + s] || best_c0[2 * r + s] < 0)) {
+                // a 1D job on a read that also has a 2D winner is a different mode; the caller passes one mode per read
+                best_total[2 * r + s] = logp[v]; best_c0[2 * r + s] = (long)v; best_c1[2 * r + s] = -1;
+            }
+            v += 1;
+        }
+    }
+    auto emit = [&](long v) {
+        const Cand& c = cands[(size_t)v];
+        const int r = job_read[c.job];
+        const uint64_t b = strand_off[2 * r + c.strand], n = strand_off[2 * r + c.strand + 1] - b;
+        if (status[(size_t)v] == 0) std::memcpy(out_state + b, states.data() + off[(size_t)v], n * sizeof(uint16_t));
+        out_best_job[2 * r + c.strand] = (int32_t)c.job;
+        out_best_logp[2 * r + c.strand] = logp[(size_t)v];
+    };
+    for (size_t i = 0; i < 2 * n_reads; ++i) {
+        if (best_c0[i] >= 0) emit(best_c0[i]);
+        if (best_c1[i] >= 0) emit(best_c1[i]);
+    }
+    return rc;
+}
+
 }  // extern "C"

@@ -93,3 +93,50 @@ def test_train_reads_matches_reference_loop(gpu_ctx):
     assert out["preferred"][0, 2] == exp
     assert out["preferred"][1, 0] == 2 and out["preferred"][2, 0] == 3       # single candidates are always preferred
     assert out["preferred"][2, 1] == -1 and out["preferred"][0, 0] == -1
+
+
+def test_basecall_reads_picks_best_model_and_matches_oracle(gpu_ctx):
+    """basecall_reads: candidates decoded with their own parameters, winner by (summed) path log-prob."""
+    opts = api.train_opts()
+    names = ["r73.c.p1", "r73.c.p2", "r73.t"]
+    strands = [1, 1, 0]
+    tables = [na.builtin_model(n) for n in names]
+    states10 = np.stack([na.model_load(t) for t in tables])
+    e0 = synth.generate(tables[2], 1, 600, first_read=700)
+    e1 = synth.generate(tables[1], 1, 500, first_read=701)      # complement really comes from c.p2
+    e2 = synth.generate(tables[2], 1, 350, first_read=702)
+    mean = np.concatenate([e0["mean"][0], e1["mean"][0], e2["mean"][0]])
+    stdv = np.concatenate([e0["stdv"][0], e1["stdv"][0], e2["stdv"][0]])
+    start = np.concatenate([e0["start"][0], e1["start"][0], e2["start"][0]])
+    so = np.array([0, 600, 1100, 1450, 1450], np.uint64)
+    jr, j0, j1 = api.train_enumerate(opts, strands, so, [1, 0])
+    assert list(zip(jr, j0, j1)) == [(0, 2, 0), (0, 2, 1), (1, 2, -1)]
+    pm = np.float32([[1.01, 0.3, 0.001, 1.05, 0.98, 1.1], [0.99, -0.2, 0.0, 1.0, 1.02, 0.9], [1, 0, 0, 1, 1, 1]])
+    st = np.float32([[0.11, 0.27, 0.1, 0.3], [0.1, 0.3, 0.12, 0.25], [0.1, 0.3, 0.1, 0.3]])
+    out = gpu_ctx.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st)
+    # oracle: every candidate
+    exp = {}
+    for k, (r, a, b) in enumerate(zip(jr, j0, j1)):
+        for s, m in ((0, a), (1, b)):
+            if m < 0:
+                continue
+            lo, hi = int(so[2 * r + s]), int(so[2 * r + s + 1])
+            om = oracle.Model(tables[m], pm[k])
+            ot = oracle.Transitions(float(st[k, 2 * s + 1]), float(st[k, 2 * s]))
+            cm, sd, ls = oracle.events_prepare(mean[lo:hi], stdv[lo:hi], start[lo:hi], float(pm[k, 2]))
+            exp[(k, s)] = oracle.viterbi(om, ot, cm, sd, ls)
+    tot = [np.float32(exp[(k, 0)][2] + exp[(k, 1)][2]) for k in (0, 1)]
+    win = 1 if tot[1] >= tot[0] else 0
+    assert win == 1                                           # the matching complement model wins
+    assert out["best_job"].tolist() == [[win, win], [2, -1]]
+    for s in range(2):
+        lo, hi = int(so[s]), int(so[s + 1])
+        assert np.array_equal(out["states"][lo:hi], exp[(win, s)][0])
+        assert out["best_logp"][0, s].tobytes() == np.float32(exp[(win, s)][2]).tobytes()
+    assert np.array_equal(out["states"][1100:1450], exp[(2, 0)][0])
+    assert out["best_logp"][1, 0].tobytes() == np.float32(exp[(2, 0)][2]).tobytes() and np.isnan(out["best_logp"][1, 1])
+    # with a preferred pair only that one is decoded
+    pref = np.full((2, 3), -1, np.int32); pref[0, 2] = 0
+    out2 = gpu_ctx.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st, preferred=pref)
+    assert out2["best_job"].tolist() == [[0, 0], [2, -1]]
+    assert np.array_equal(out2["states"][0:600], exp[(0, 0)][0])
