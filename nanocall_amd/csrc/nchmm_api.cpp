@@ -43,6 +43,8 @@ struct nchmm_ctx {
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    void* d_tab_stage = nullptr;    // device staging of unscaled tables + per-slot parameters
+    size_t tab_stage_bytes = 0;
     void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
     size_t h_pin_bytes = 0;
     hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_vit2 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
@@ -395,6 +397,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
     if (c->ev_vit0) (void)hipEventDestroy(c->ev_vit0);
     if (c->ev_vit1) (void)hipEventDestroy(c->ev_vit1);
     if (c->ev_vit2) (void)hipEventDestroy(c->ev_vit2);
@@ -458,33 +461,43 @@ int nchmm_put_models_scaled(nchmm_ctx* c, int first_slot, size_t n, const float*
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = reserve_slots(c, first_slot + (int)n);
     if (rc != NCHMM_OK) return rc;
+    // tables + per-slot parameters go up (small); the images are built on the device (tables_kernel.hip)
+    int32_t max_idx = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const int32_t ti = table_idx ? table_idx[k] : 0;
+        if (ti < 0) return NCHMM_E_INVALID;
+        max_idx = std::max(max_idx, ti);
+    }
+    const size_t n_tables = (size_t)max_idx + 1;
+    const size_t b_states = sizeof(float) * n_tables * kStates * 10, b_idx = sizeof(int32_t) * n, b_par = sizeof(float) * 8 * n;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     void* hp = nullptr;
-    if ((rc = pinned(c, sizeof(float) * n * kModelFloats, &hp))) return rc;
-    float* const img = (float*)hp;
-    std::vector<int32_t> fast(n, 1);
-    auto work = [&](size_t a, size_t b) {
-        for (size_t k = a; k < b; ++k) {
-            const float* st = states_Sx10 + (size_t)(table_idx ? table_idx[k] : 0) * kStates * 10;
-            const float* p = params_nx6 + 6 * k;
-            const float log_var = std::log(p[3]), log_var_sd = std::log(p[5]);
-            float* im = img + k * kModelFloats;
-            for (int j = 0; j < kStates; ++j) {
-                const float* s = st + (size_t)j * 10;
-                const float level_mean = s[0] * p[0] + p[1];
-                const float level_stdv = s[1] * p[3];
-                const float sd_mean = s[2] * p[4];
-                const float sd_lambda = s[4] * p[5];
-                const float log_level_stdv = s[6] + log_var;
-                const float log_sd_lambda = s[9] + log_var_sd;
-                model_image_row(im, j, level_mean, level_stdv, log_level_stdv, sd_mean, sd_lambda, log_sd_lambda, &fast[k]);
-            }
-        }
-    };
-    parallel_for(n, work);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(c->d_models + (size_t)first_slot * kModelFloats, img, sizeof(float) * n * kModelFloats,
-                         hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_model_fast + first_slot, fast.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if ((rc = pinned(c, al(b_idx) + al(b_par) + al(sizeof(int32_t) * n), &hp))) return rc;
+    int32_t* h_idx = (int32_t*)hp;
+    float* h_par = (float*)((char*)hp + al(b_idx));
+    int32_t* h_one = (int32_t*)((char*)hp + al(b_idx) + al(b_par));
+    for (size_t k = 0; k < n; ++k) {
+        h_idx[k] = table_idx ? table_idx[k] : 0;
+        const float* p = params_nx6 + 6 * k;
+        std::memcpy(h_par + 8 * k, p, 6 * sizeof(float));
+        h_par[8 * k + 6] = std::log(p[3]);   // log_params.var, Pore_Model.hpp:193
+        h_par[8 * k + 7] = std::log(p[5]);   // log_params.var_sd :195
+        h_one[k] = 1;
+    }
+    void* dp = c->d_tab_stage;
+    rc = ensure(c, &dp, &c->tab_stage_bytes, al(b_states) + al(b_idx) + al(b_par));
+    c->d_tab_stage = dp;
+    if (rc != NCHMM_OK) return rc;
+    char* d = (char*)c->d_tab_stage;
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(d, states_Sx10, b_states, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d + al(b_states), h_idx, b_idx, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d + al(b_states) + al(b_idx), h_par, b_par, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_model_fast + first_slot, h_one, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    launch_scale_models((const float*)d, (const int32_t*)(d + al(b_states)), (const float*)(d + al(b_states) + al(b_idx)),
+                        c->d_models, c->d_model_fast, first_slot, n, static_cast<float>(std::log(2.0 * M_PI)), st);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(st));   // the pinned staging buffer is reused by the next call
     for (size_t k = 0; k < n; ++k) c->model_set[first_slot + k] = 1;
     return NCHMM_OK;
 }
