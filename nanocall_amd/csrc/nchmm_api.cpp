@@ -43,6 +43,7 @@ struct nchmm_ctx {
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    uint8_t* d_masks = nullptr;     // overlap-mask ids of the stay / step-group / skip-group arcs (5376 bytes)
     void* d_tab_stage = nullptr;    // device staging of unscaled tables + per-slot parameters
     size_t tab_stage_bytes = 0;
     void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
@@ -259,18 +260,20 @@ struct MaskTables {
     }
 };
 
-void fast_transition_weights(float p_skip, float p_stay, float* out)
+const MaskTables& mask_tables()
 {
     static const MaskTables T;
+    return T;
+}
+
+// log weight of every overlap mask that occurs, for compute_transitions_fast(p_skip, p_stay)
+void mask_weights(float p_skip, float p_stay, float wm[64])
+{
+    const MaskTables& T = mask_tables();
     float p_step, p_skip_1;
     step_params(p_skip, p_stay, p_step, p_skip_1);
-    float wm[64];
     for (unsigned m = 0; m < 64; ++m)
         wm[m] = T.used[m] ? std::log(trans_prob(T.rep_i[m], T.rep_j[m], p_stay, p_step, p_skip_1)) : 0.0f;
-    float* w0 = out; float* w1 = out + kStates; float* w2 = out + kStates + 1024;
-    for (unsigned j = 0; j < (unsigned)kStates; ++j) w0[j] = wm[T.m0[j]];
-    for (unsigned r = 0; r < 1024; ++r) w1[r] = wm[T.m1[r]];
-    for (unsigned q = 0; q < 256; ++q) w2[q] = wm[T.m2[q]];
 }
 
 int pinned(nchmm_ctx* c, size_t bytes, void** out)
@@ -352,6 +355,13 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     c->stream = c->own_stream;
     if ((rc = reserve_slots(c, kMaxSlots))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_train_mask, 512))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_masks, kTransFloats))) return fail(rc);
+    {
+        const MaskTables& T = mask_tables();
+        std::vector<uint8_t> mk(kTransFloats);
+        std::memcpy(mk.data(), T.m0, kStates); std::memcpy(mk.data() + kStates, T.m1, 1024); std::memcpy(mk.data() + kStates + 1024, T.m2, 256);
+        if (hipMemcpy(c->d_masks, mk.data(), kTransFloats, hipMemcpyHostToDevice) != hipSuccess) return fail(NCHMM_E_HIP);
+    }
     {
         // Parameter_Trainer::init, Parameter_Trainer.hpp:30-57
         std::vector<uint16_t> km(kStates);
@@ -398,6 +408,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
+    if (c->d_masks) (void)hipFree(c->d_masks);
     if (c->ev_vit0) (void)hipEventDestroy(c->ev_vit0);
     if (c->ev_vit1) (void)hipEventDestroy(c->ev_vit1);
     if (c->ev_vit2) (void)hipEventDestroy(c->ev_vit2);
@@ -514,20 +525,17 @@ int nchmm_put_transitions_fast(nchmm_ctx* c, int first_slot, size_t n, const flo
     int rc = reserve_slots(c, first_slot + (int)n);
     if (rc != NCHMM_OK) return rc;
     void* hp = nullptr;
-    if ((rc = pinned(c, sizeof(float) * n * (kTransFloats + kFbTransFloats), &hp))) return rc;
-    float* const w = (float*)hp;
-    float* const fb = w + n * kTransFloats;
-    auto work = [&](size_t a, size_t b) {
-        for (size_t k = a; k < b; ++k) {
-            fast_transition_weights(p_skip[k], p_stay[k], w + k * kTransFloats);
-            fb_weights(w + k * kTransFloats, fb + k * kFbTransFloats);
-        }
-    };
-    parallel_for(n, work);
+    if ((rc = pinned(c, sizeof(float) * 64 * n, &hp))) return rc;
+    float* const wm = (float*)hp;
+    for (size_t k = 0; k < n; ++k) mask_weights(p_skip[k], p_stay[k], wm + 64 * k);
+    void* dp = c->d_tab_stage;
+    rc = ensure(c, &dp, &c->tab_stage_bytes, sizeof(float) * 64 * n);
+    c->d_tab_stage = dp;
+    if (rc != NCHMM_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_tab_stage, wm, sizeof(float) * 64 * n, hipMemcpyHostToDevice, c->stream));
+    launch_expand_transitions((const float*)c->d_tab_stage, c->d_masks, c->d_trans, c->d_trans_fb, first_slot, n, c->stream);
+    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(c->d_trans + (size_t)first_slot * kTransFloats, w, sizeof(float) * n * kTransFloats, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_trans_fb + (size_t)first_slot * kFbTransFloats, fb, sizeof(float) * n * kFbTransFloats,
-                         hipMemcpyHostToDevice));
     for (size_t k = 0; k < n; ++k) c->trans_set[first_slot + k] = 1;
     return NCHMM_OK;
 }

@@ -79,6 +79,8 @@ struct FwbwArgs {
 
 void launch_scale_models(const float* d_states, const int32_t* d_table_idx, const float* d_params, float* d_models,
                          int32_t* d_model_fast, int first_slot, size_t n, float log_2pi, hipStream_t stream);
+void launch_expand_transitions(const float* d_wm, const uint8_t* d_masks, float* d_trans, float* d_trans_fb, int first_slot,
+                               size_t n, hipStream_t stream);
 void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream);
 int fwbw_blocks_per_cu();
 
