@@ -256,13 +256,21 @@ __global__ __launch_bounds__(kThreads, 2) void fwbw_kernel(FwbwArgs P)
             for (int u = 0; u < 8; ++u) { beta[u] = 0.0f; gprev[u] = 0.0f; h1prev[u] = 0.0f; }   // Forward_Backward.hpp:93-103
             if (tau < 16) { sAcc[0][tau & 7] = 0.0f; sAcc[1][tau & 7] = 0.0f; }
             __syncthreads();
+            // alpha rows and event values are fetched one event ahead so their latency hides behind the
+            // previous event's arithmetic
+            float4 nx_lo = *reinterpret_cast<const float4*>(arow + (uint64_t)(n - 1) * kStates + j0);
+            float4 nx_hi = *reinterpret_cast<const float4*>(arow + (uint64_t)(n - 1) * kStates + j0 + 4);
+            float nx_x = ex[n - 1], nx_y = ey[n - 1], nx_l = el[n - 1];
             for (int i = (int)n - 1; i >= 0; --i) {
                 const unsigned buf = (unsigned)i & 1u;
                 // alpha_i of my 8 consecutive states
-                const float4 a_lo = *reinterpret_cast<const float4*>(arow + (uint64_t)i * kStates + j0);
-                const float4 a_hi = *reinterpret_cast<const float4*>(arow + (uint64_t)i * kStates + j0 + 4);
-                const float al[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
-                const float x = ex[i], y = ey[i], ly3 = 3.0f * el[i], ry = 1.0f / y;
+                const float al[8] = {nx_lo.x, nx_lo.y, nx_lo.z, nx_lo.w, nx_hi.x, nx_hi.y, nx_hi.z, nx_hi.w};
+                const float x = nx_x, y = nx_y, ly3 = 3.0f * nx_l, ry = 1.0f / y;
+                if (i > 0) {
+                    nx_lo = *reinterpret_cast<const float4*>(arow + (uint64_t)(i - 1) * kStates + j0);
+                    nx_hi = *reinterpret_cast<const float4*>(arow + (uint64_t)(i - 1) * kStates + j0 + 4);
+                    nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_l = el[i - 1];
+                }
                 float ps[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
