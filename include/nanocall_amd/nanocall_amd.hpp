@@ -388,7 +388,7 @@ public:
         const uint64_t off[2] = {0, cm.size()};
         const int32_t s = slot;
         _alpha.assign(cm.size() * n_states, 0); _beta.assign(cm.size() * n_states, 0);
-        check(nchmm_fwbw(Device::instance().ctx(), 1, off, cm.data(), sd.data(), ls.data(), &s, &s, &s, nullptr, &_log_pr_data,
+        check(nchmm_fwbw(Device::instance().ctx(), 1, off, cm.data(), sd.data(), ls.data(), &s, nullptr, &s, nullptr, &_log_pr_data,
                          nullptr, nullptr, _alpha.data(), _beta.data()), "nchmm_fwbw");
     }
 private:
@@ -416,7 +416,7 @@ struct Parameter_Trainer {
     static std::vector<unsigned>& st_train_kmers() { static std::vector<unsigned> v; return v; }
     static unsigned& pm_train_drift() { static unsigned v = 1; return v; }
 
-    // Parameter_Trainer.hpp:541-579.  Device slots used: 60/61 unscaled models, 62/63 scaled models + transitions.
+    // Parameter_Trainer.hpp:541-579.  Device slots used: 62/63 scaled models + transitions.
     static void train_one_round(const std::vector<std::pair<const Event_Sequence_Type*, unsigned>>& event_seq_ptrs,
                                 const std::array<const Pore_Model_Type*, 2>& model_ptrs,
                                 const State_Transitions_Type& default_transitions,
@@ -433,7 +433,6 @@ struct Parameter_Trainer {
         for (const auto& p : event_seq_ptrs) have[p.second] = true;
         for (unsigned st = 0; st < 2; ++st) {
             if (!have[st]) continue;
-            model_ptrs[st]->put(60 + st);
             Pore_Model_Type scaled(*model_ptrs[st]);
             scaled.scale(crt_pm_params);
             scaled.put(62 + st);
@@ -447,20 +446,23 @@ struct Parameter_Trainer {
         }
         std::vector<uint64_t> off{0};
         std::vector<float> cm, sd, ls, mean, start;
-        std::vector<int32_t> s_slot, u_slot;
-        std::vector<float> stp;
+        std::vector<int32_t> s_slot;
+        std::vector<float> stp, w_pm;
         for (const auto& p : event_seq_ptrs) {
             Event_Sequence_Type corrected(*p.first);
             corrected.apply_drift_correction(crt_pm_params.drift);
             detail::soa(corrected, cm, sd, ls);
             for (const auto& e : *p.first) { mean.push_back(e.mean); start.push_back(e.start); }
             off.push_back(cm.size());
-            s_slot.push_back(62 + (int)p.second); u_slot.push_back(60 + (int)p.second);
+            s_slot.push_back(62 + (int)p.second);
+            for (float v : {crt_pm_params.scale, crt_pm_params.shift, crt_pm_params.drift, crt_pm_params.var, crt_pm_params.scale_sd,
+                            crt_pm_params.var_sd})
+                w_pm.push_back(v);
             stp.push_back(crt_st_params[p.second].p_stay); stp.push_back(crt_st_params[p.second].p_skip);
         }
         const size_t n_win = event_seq_ptrs.size(), total = cm.size();
         std::vector<float> lpd(n_win), pm_sums(6 * total), st_sums(3 * n_win);
-        check(nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), u_slot.data(), s_slot.data(),
+        check(nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), w_pm.data(), s_slot.data(),
                          stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr), "nchmm_fwbw");
         fit = 0;
         for (float v : lpd) fit += v;   // :154

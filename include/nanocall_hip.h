@@ -184,7 +184,12 @@ int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t 
  * Windows are SoA like Viterbi reads.  For window w:
  *   out_log_pr_data[w]            = Forward_Backward::log_pr_data()
  *   out_pm_sums[e*6 .. e*6+5]     = {s0,s1,s2,l0,l1,l2} of event e (Parameter_Trainer.hpp:273-296),
- *                                   taken over the UNSCALED model in unscaled_slot[w]
+ *                                   taken over the UNSCALED model: the one that Pore_Model::scale
+ *                                   (Pore_Model.hpp:126-138,190-201) with pm_params[w] = {scale, shift,
+ *                                   drift, var, scale_sd, var_sd} turned into scaled_slot[w].  The
+ *                                   kernel holds only the scaled states and undoes the (affine) scaling
+ *                                   on the six block sums; pm_params NULL = identity (sums over the
+ *                                   scaled model itself)
  *   out_st_sums[w*3 .. w*3+2]     = {denom, stay_num, skip_num} log-sums of train_st_params over the
  *                                   events of this window (log_p_stay / log_p_step_4 from st_params)
  *   out_alpha / out_beta          = optional full matrices (n x S, log space), NULL to skip
@@ -192,14 +197,14 @@ int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t 
  * ---------------------------------------------------------------------------------------- */
 int nchmm_fwbw(nchmm_ctx* ctx, size_t n_win, const uint64_t* off, const float* corrected_mean,
                const float* stdv, const float* log_stdv, const int32_t* scaled_slot,
-               const int32_t* unscaled_slot, const int32_t* trans_slot,
+               const float* pm_params /* n_win x 6 or NULL */, const int32_t* trans_slot,
                const float* st_params /* n_win x 2 {p_stay, p_skip} or NULL */,
                float* out_log_pr_data, float* out_pm_sums, float* out_st_sums,
                float* out_alpha, float* out_beta);
 
 int nchmm_fwbw_dev(nchmm_ctx* ctx, size_t n_win, size_t max_events, size_t total_events,
                    const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
-                   const float* d_log_stdv, const int32_t* d_scaled_slot, const int32_t* d_unscaled_slot,
+                   const float* d_log_stdv, const int32_t* d_scaled_slot, const float* d_pm_params,
                    const int32_t* d_trans_slot, const float* d_st_params,
                    float* d_out_log_pr_data, float* d_out_pm_sums, float* d_out_st_sums,
                    float* d_out_alpha, float* d_out_beta);

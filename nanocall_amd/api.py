@@ -246,16 +246,18 @@ class Context:
               "nchmm_viterbi_dev")
 
     # -- forward-backward --
-    def fwbw(self, off, cmean, stdv, log_stdv, scaled_slot=None, unscaled_slot=None, trans_slot=None,
+    def fwbw(self, off, cmean, stdv, log_stdv, scaled_slot=None, pm_params=None, trans_slot=None,
              st_params=None, want_matrices=False):
         """Host-buffer batch forward-backward + EM sums.
+        pm_params (n_win x 6, or one row for all windows) are the scaling parameters behind each window's
+        scaled model; the pm sums are taken over the corresponding unscaled model (None: identity).
         Returns dict(log_pr_data[n_win], pm_sums[total,6], st_sums[n_win,3], alpha, beta)."""
         off = np.ascontiguousarray(off, np.uint64)
         n = off.shape[0] - 1
         total = int(off[-1]) if n > 0 else 0
         cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
         ss = None if scaled_slot is None else np.ascontiguousarray(scaled_slot, np.int32)
-        us = None if unscaled_slot is None else np.ascontiguousarray(unscaled_slot, np.int32)
+        us = None if pm_params is None else np.ascontiguousarray(np.broadcast_to(_f32(pm_params).reshape(-1, 6), (n, 6)))
         ts = None if trans_slot is None else np.ascontiguousarray(trans_slot, np.int32)
         sp = None if st_params is None else _f32(st_params).reshape(n, 2)
         lpd = np.empty(n, np.float32)
@@ -268,10 +270,10 @@ class Context:
         return dict(log_pr_data=lpd, pm_sums=pm, st_sums=stt, alpha=al, beta=be)
 
     def fwbw_dev(self, n_win, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_out_lpd, d_out_pm,
-                 d_out_st, d_scaled_slot=None, d_unscaled_slot=None, d_trans_slot=None, d_st_params=None,
+                 d_out_st, d_scaled_slot=None, d_pm_params=None, d_trans_slot=None, d_st_params=None,
                  d_out_alpha=None, d_out_beta=None):
         check(lib().nchmm_fwbw_dev(self._h, n_win, max_events, total_events, _dp(d_off), _dp(d_cmean), _dp(d_stdv),
-                                   _dp(d_lstdv), _dp(d_scaled_slot), _dp(d_unscaled_slot), _dp(d_trans_slot),
+                                   _dp(d_lstdv), _dp(d_scaled_slot), _dp(d_pm_params), _dp(d_trans_slot),
                                    _dp(d_st_params), _dp(d_out_lpd), _dp(d_out_pm), _dp(d_out_st),
                                    _dp(d_out_alpha), _dp(d_out_beta)), "nchmm_fwbw_dev")
 

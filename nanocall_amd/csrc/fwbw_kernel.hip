@@ -9,7 +9,15 @@
 // Numerics: log space, fp32, max-shifted log-sum-exp (the reference's `logsumset` is an un-vendored
 // hpptools class; any exact log-sum-exp is inside the 1e-4 relative tolerance north_star sets for
 // forward log-likelihoods -- tests hold log_pr_data, alpha/beta cells and the trained parameters to
-// that).  Transcendentals are the hardware exp2/log2 (v_exp_f32 / v_log_f32).
+// that).  Inside the kernels every log-quantity is kept in BASE 2 (multiplied by log2 e once), so the
+// hardware exp2/log2 (v_exp_f32 / v_log_f32) are used without per-term scaling; rows written to HBM
+// and all outputs are natural logs again.
+//
+// Two kernels, one window per 512-thread block each (persistent blocks + work queue), both within
+// 128 VGPRs so that two blocks share a CU (4 waves/SIMD): fwbw_forward_kernel writes the alpha rows
+// and log_pr_data, fwbw_backward_kernel reads them back one event ahead of use.  Per-state tables
+// touched once per cell (-log sigma, log lambda - log 2pi and the stay / step coefficients) live in
+// LDS (64 KiB); the skip coefficient equals the group weight w2 and is added once by the producer.
 //
 // Structure (same k-mer algebra as viterbi_kernel.hip, sums instead of maxima):
 //   forward   alpha_i[j] = e_j(i) + LSE( c0[j] + alpha[j], c1[j] + G1[j>>2], c2[j] + G2[j>>4] )
@@ -42,53 +50,57 @@ namespace {
 constexpr unsigned kFbChunk = 128;   // events staged in LDS at a time
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -3.0e38f;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
-__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * kLn2; }   // v_log_f32 is log2
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 is log2
 
 __device__ __forceinline__ float swap1(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-// n / d through the precomputed reciprocal r = RN(1/d) with one residual correction: within 1 ulp of
-// the IEEE quotient (FB is tolerance-checked at 1e-4, not bit-checked), 3 ops instead of ~10 + v_rcp.
-__device__ __forceinline__ float quot(float n, float d, float r)
+// Pore_Model_State::log_pr_corrected_emission (Pore_Model.hpp:145-149) in base 2, regrouped as
+//   k0 - [ (x - mu)^2 r2 + (y - eta)^2 lq / y + l3 ]
+// with the per-state constants  r2 = log2e / (2 sigma^2),  lq = log2e lambda / (2 eta^2),
+// k0 = log2e (-log sigma + (log lambda - 2 log 2pi) / 2)  and the per-event  l3 = log2e * 3 log(y) / 2.
+// (Same real function; the regrouping moves each cell by a few 1e-7 relative, far inside the 1e-4 FB tolerance.)
+struct StateK { float mu, r2, eta, lq, k0; };
+
+__device__ __forceinline__ StateK make_state(const float* __restrict__ M, unsigned j, float log_2pi)
 {
-    const float q = n * r;
-    return __builtin_fmaf(__builtin_fmaf(-q, d, n), r, q);
+    StateK s;
+    const float rsg = M[MF_RSIGMA * kStates + j], reta = M[MF_RETA * kStates + j];
+    s.mu = M[MF_MU * kStates + j];
+    s.eta = M[MF_ETA * kStates + j];
+    s.r2 = (0.5f * kLog2e) * rsg * rsg;
+    s.lq = (0.5f * kLog2e) * M[MF_LAMBDA * kStates + j] * reta * reta;
+    s.k0 = kLog2e * (M[MF_NEG_LOG_SIGMA * kStates + j] + 0.5f * (M[MF_C * kStates + j] - log_2pi));
+    return s;
 }
 
-// Pore_Model_State::log_pr_corrected_emission, Pore_Model.hpp:145-149 (same expression as the
-// Viterbi kernel)
-__device__ __forceinline__ float emission(float x, float y, float ry, float ly3, float log_2pi, float mu, float sg, float rsg,
-                                          float nls, float eta, float reta, float lam, float c)
+__device__ __forceinline__ float emission2(float x, float y, float ry, float l3, float mu, float r2, float eta, float lq, float k0)
 {
-    const float a = quot(x - mu, sg, rsg);
-    const float n = nls - (log_2pi + a * a) / 2.0f;
-    const float b = quot(y - eta, eta, reta);
-    const float ig = (c - ly3 - quot(lam * b * b, y, ry)) / 2.0f;
-    return n + ig;
+    const float dx = x - mu, dy = y - eta;
+    return k0 - __builtin_fmaf(dx * dx, r2, __builtin_fmaf(dy * dy * lq, ry, l3));
 }
 
-struct MaxSum { float m, s; };   // running log-sum-exp: value = m + log(s)
+struct MaxSum { float m, s; };   // running base-2 log-sum-exp: value = m + log2(s)
 
 __device__ __forceinline__ MaxSum lse_merge(MaxSum a, MaxSum b)
 {
     const float m = __builtin_fmaxf(__builtin_fmaxf(a.m, b.m), kNegBig);
-    return MaxSum{m, a.s * fexp(a.m - m) + b.s * fexp(b.m - m)};
+    return MaxSum{m, a.s * ex2(a.m - m) + b.s * ex2(b.m - m)};
 }
-
 __device__ __forceinline__ MaxSum lse4(float a, float b, float c, float d)
 {
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)), kNegBig);
-    return MaxSum{m, fexp(a - m) + fexp(b - m) + fexp(c - m) + fexp(d - m)};
+    return MaxSum{m, ex2(a - m) + ex2(b - m) + ex2(c - m) + ex2(d - m)};
 }
-
 __device__ __forceinline__ float lse3(float a, float b, float c)
 {
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), c), kNegBig);
-    return m + flog(fexp(a - m) + fexp(b - m) + fexp(c - m));
+    return m + lg2(ex2(a - m) + ex2(b - m) + ex2(c - m));
 }
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -104,21 +116,43 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// Sum over the 64 lanes of a wave on the DPP path (no LDS traffic): quad swaps, row mirrors, then the two
+// row broadcasts.  Only lane 63 holds the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v)
+{
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane of a row holds the row's sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// LDS tables are pair-major: the two floats of thread tau's cell pair `pair` of a table sit at
+// sTab[f][(pair * 512 + tau) * 2 ..]: consecutive lanes read consecutive 8-byte words (conflict-free
+// ds_read_b64) and every access of a thread is ONE base register plus an immediate offset.
+__device__ __forceinline__ unsigned tab_off(unsigned tau, unsigned pair) { return (pair * (unsigned)kThreads + tau) * 2u; }
+
 }  // namespace
 
-__global__ __launch_bounds__(kThreads, 2) void fwbw_kernel(FwbwArgs P)
+// ================================================ forward ================================================
+__global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
 {
     __shared__ __attribute__((aligned(16))) float sG1[2][1024];
     __shared__ __attribute__((aligned(16))) float sG2[2][256];
-    __shared__ __attribute__((aligned(16))) float4 sEv[kFbChunk];   // x, y, 3 log y, start-of-chunk pad
+    __shared__ __attribute__((aligned(16))) float4 sEv[kFbChunk];     // x, y, log2e * 3 log(y) / 2, 1/y
     __shared__ float sRed[16];
-    __shared__ float sAcc[2][8];
     __shared__ unsigned sWork;
 
     const unsigned tau = threadIdx.x;
     const unsigned t = tau >> 1, h = tau & 1u;
     const unsigned wave = tau >> 6, lane = tau & 63u;
-    float* const ws = P.ws_alpha;
 
     for (;;) {
         if (tau == 0) sWork = atomicAdd(P.queue, 1u);
@@ -129,240 +163,339 @@ __global__ __launch_bounds__(kThreads, 2) void fwbw_kernel(FwbwArgs P)
         const uint64_t e0 = P.off[w];
         const unsigned n = (unsigned)(P.off[w + 1] - e0);
         if (n == 0) {
-            if (tau == 0) {
-                P.out_log_pr_data[w] = __builtin_nanf("");
-                if (P.out_st_sums) { P.out_st_sums[3 * w] = P.out_st_sums[3 * w + 1] = P.out_st_sums[3 * w + 2] = -__builtin_inff(); }
-            }
+            if (tau == 0) P.out_log_pr_data[w] = __builtin_nanf("");
             continue;
         }
         const int ms = P.scaled_slot ? P.scaled_slot[w] : 0;
-        const int us = P.unscaled_slot ? P.unscaled_slot[w] : ms;
         const int ts = P.trans_slot ? P.trans_slot[w] : 0;
         const float* __restrict__ M = P.models + (size_t)ms * kModelFloats;
-        const float* __restrict__ U = P.models + (size_t)us * kModelFloats;
         const float* __restrict__ C = P.trans_fb + (size_t)ts * kFbTransFloats;
         const float* __restrict__ ex = P.cmean + e0;
         const float* __restrict__ ey = P.stdv + e0;
         const float* __restrict__ el = P.lstdv + e0;
-        float* const arow = ws + e0 * (uint64_t)kStates;   // alpha row i at arow + i*4096
+        float* const arow = P.ws_alpha + e0 * (uint64_t)kStates;   // alpha row i at arow + i*4096
+        const float store_scale = P.alpha_natural ? kLn2 : 1.0f;
 
-        // =========================== forward ===========================
-        float lpd;
-        {
-            float mu[8], sg[8], rsg[8], nls[8], eta[8], reta[8], lam[8], cc[8], c0[8], c1[8], c2[8], alpha[8];
-            unsigned jj[8];
+        float mu[8], r2[8], eta[8], lq[8], k0[8], c0[8], c1[8], alpha[8];   // alpha in base 2
+        unsigned jj[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned k = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h;
-                const unsigned j = t + 256u * k;
-                jj[i] = j;
-                mu[i] = M[MF_MU * kStates + j]; sg[i] = M[MF_SIGMA * kStates + j]; rsg[i] = M[MF_RSIGMA * kStates + j];
-                nls[i] = M[MF_NEG_LOG_SIGMA * kStates + j]; eta[i] = M[MF_ETA * kStates + j]; reta[i] = M[MF_RETA * kStates + j];
-                lam[i] = M[MF_LAMBDA * kStates + j]; cc[i] = M[MF_C * kStates + j];
-                c0[i] = C[0 * kStates + j]; c1[i] = C[1 * kStates + j]; c2[i] = C[2 * kStates + j];
-            }
-            const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
-            for (unsigned base = 0; base < n; base += kFbChunk) {
-                const unsigned ie = base + tau;
-                if (tau < kFbChunk && ie < n) sEv[tau] = make_float4(ex[ie], ey[ie], 3.0f * el[ie], 1.0f / ey[ie]);
-                __syncthreads();
-                const unsigned hi = (n - base < kFbChunk) ? n - base : kFbChunk;
-                for (unsigned c = 0; c < hi; ++c) {
-                    const float4 ev = sEv[c];
-                    const unsigned i = base + c;
-                    if (i == 0) {
-                        // Forward_Backward.hpp:58-68
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            alpha[u] = emission(ev.x, ev.y, ev.w, ev.z, P.log_2pi, mu[u], sg[u], rsg[u], nls[u], eta[u], reta[u],
-                                                lam[u], cc[u]) - P.log_n_states;
-                    } else {
-                        // Forward_Backward.hpp:72-89
-                        const unsigned buf = i & 1u;
-                        const MaxSum a = lse4(alpha[0], alpha[2], alpha[4], alpha[6]);   // y = h
-                        const MaxSum b = lse4(alpha[1], alpha[3], alpha[5], alpha[7]);   // y = h + 2
-                        MaxSum s8 = lse_merge(a, b);
-                        s8 = lse_merge(s8, MaxSum{swap1(s8.m), swap1(s8.s)});
-                        sG1[buf][(h << 8) | t] = a.m + flog(a.s);
-                        sG1[buf][((2u + h) << 8) | t] = b.m + flog(b.s);
-                        if (h == 0) sG2[buf][t] = s8.m + flog(s8.s);
-                        __syncthreads();
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const unsigned kc = 4u * (unsigned)(u >> 1) + 2u * (unsigned)(u & 1);
-                            const float g1 = sG1[buf][r1_base + (kc << 6)], g2 = sG2[buf][q_base + (kc << 4)];
-                            const float e = emission(ev.x, ev.y, ev.w, ev.z, P.log_2pi, mu[u], sg[u], rsg[u], nls[u], eta[u], reta[u],
-                                                     lam[u], cc[u]);
-                            alpha[u] = e + lse3(c0[u] + alpha[u], c1[u] + g1, c2[u] + g2);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) arow[(uint64_t)i * kStates + jj[u]] = alpha[u];
-                }
-                __syncthreads();
-            }
-            // log_pr_data = LSE_j alpha[n-1][j]  (Forward_Backward.hpp:129-134)
-            float m = kNegBig;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m = __builtin_fmaxf(m, alpha[u]);
-            m = wave_max(m);
-            if (lane == 0) sRed[wave] = m;
-            __syncthreads();
-            float bm = sRed[0];
-#pragma unroll
-            for (int q = 1; q < kThreads / 64; ++q) bm = __builtin_fmaxf(bm, sRed[q]);
-            float s = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += fexp(alpha[u] - bm);
-            s = wave_sum(s);
-            if (lane == 0) sRed[8 + wave] = s;
-            __syncthreads();
-            float bs = 0;
-#pragma unroll
-            for (int q = 0; q < kThreads / 64; ++q) bs += sRed[8 + q];
-            lpd = bm + flog(bs);
-            if (tau == 0) P.out_log_pr_data[w] = lpd;
-            __syncthreads();   // alpha rows visible to the whole block (different ownership below); sRed reusable
+        for (int i = 0; i < 8; ++i) {
+            const unsigned k = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h;
+            const unsigned j = t + 256u * k;
+            jj[i] = j;
+            const StateK s = make_state(M, j, P.log_2pi);
+            mu[i] = s.mu; r2[i] = s.r2; eta[i] = s.eta; lq[i] = s.lq; k0[i] = s.k0;
+            c0[i] = C[0 * kStates + j] * kLog2e;
+            c1[i] = C[1 * kStates + j] * kLog2e;
         }
+        // the skip coefficient c2[j] is the group weight w2[j >> 4] for every state: the producer of group t adds it
+        const float w2 = P.trans[(size_t)ts * kTransFloats + kStates + 1024 + t] * kLog2e;
+        const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
 
-        // =========================== backward + statistics ===========================
-        {
-            const unsigned j0 = tau * 8u;
-            float mu[8], sg[8], rsg[8], nls[8], eta[8], reta[8], lam[8], cc[8], c0[8], c1[8], c2[8];
-            float u0[8], u1[8], u2[8], v0[8], v1[8], v2[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned j = j0 + u;
-                mu[u] = M[MF_MU * kStates + j]; sg[u] = M[MF_SIGMA * kStates + j]; rsg[u] = M[MF_RSIGMA * kStates + j];
-                nls[u] = M[MF_NEG_LOG_SIGMA * kStates + j]; eta[u] = M[MF_ETA * kStates + j]; reta[u] = M[MF_RETA * kStates + j];
-                lam[u] = M[MF_LAMBDA * kStates + j]; cc[u] = M[MF_C * kStates + j];
-                c0[u] = C[3 * kStates + j]; c1[u] = C[4 * kStates + j]; c2[u] = C[5 * kStates + j];
-                // Parameter_Trainer.hpp:284-289 on the UNSCALED model
-                const float usg = U[MF_SIGMA * kStates + j], umu = U[MF_MU * kStates + j];
-                const float ulam = U[MF_LAMBDA * kStates + j], ueta = U[MF_ETA * kStates + j];
-                u0[u] = 1.0f / (usg * usg); u1[u] = u0[u] * umu; u2[u] = u1[u] * umu;
-                v0[u] = ulam; v1[u] = v0[u] / ueta; v2[u] = v1[u] / ueta;
+        for (unsigned base = 0; base < n; base += kFbChunk) {
+            const unsigned ie = base + tau;
+            if (tau < kFbChunk && ie < n) {
+                const float y = ey[ie];
+                sEv[tau] = make_float4(ex[ie], y, (1.5f * kLog2e) * el[ie], 1.0f / y);
             }
-            const unsigned train = P.train_mask[tau];   // bit u: state j0+u is a transition-training k-mer
-            float lps = 0.0f, lps4 = 0.0f;
-            if (P.st_params) {
-                const float p_stay = P.st_params[2 * w], p_skip = P.st_params[2 * w + 1];
-                lps = flog(p_stay);                                   // Parameter_Trainer.hpp:444
-                lps4 = flog(1.0f - p_stay - p_skip) - flog(4.0f);     // :445
-            }
-            float beta[8], gprev[8], h1prev[8];
-            float acc_p = 0, acc_stay = 0, acc_skip = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { beta[u] = 0.0f; gprev[u] = 0.0f; h1prev[u] = 0.0f; }   // Forward_Backward.hpp:93-103
-            if (tau < 16) { sAcc[0][tau & 7] = 0.0f; sAcc[1][tau & 7] = 0.0f; }
             __syncthreads();
-            // alpha rows and event values are fetched one event ahead so their latency hides behind the
-            // previous event's arithmetic
-            float4 nx_lo = *reinterpret_cast<const float4*>(arow + (uint64_t)(n - 1) * kStates + j0);
-            float4 nx_hi = *reinterpret_cast<const float4*>(arow + (uint64_t)(n - 1) * kStates + j0 + 4);
-            float nx_x = ex[n - 1], nx_y = ey[n - 1], nx_l = el[n - 1];
-            for (int i = (int)n - 1; i >= 0; --i) {
-                const unsigned buf = (unsigned)i & 1u;
-                // alpha_i of my 8 consecutive states
-                const float al[8] = {nx_lo.x, nx_lo.y, nx_lo.z, nx_lo.w, nx_hi.x, nx_hi.y, nx_hi.z, nx_hi.w};
-                const float x = nx_x, y = nx_y, ly3 = 3.0f * nx_l, ry = 1.0f / y;
+            const unsigned hi = (n - base < kFbChunk) ? n - base : kFbChunk;
+            for (unsigned c = 0; c < hi; ++c) {
+                const float4 ev = sEv[c];
+                const unsigned i = base + c;
+                const unsigned buf = i & 1u;
                 if (i > 0) {
-                    nx_lo = *reinterpret_cast<const float4*>(arow + (uint64_t)(i - 1) * kStates + j0);
-                    nx_hi = *reinterpret_cast<const float4*>(arow + (uint64_t)(i - 1) * kStates + j0 + 4);
-                    nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_l = el[i - 1];
-                }
-                float ps[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float lp = al[u] + beta[u] - lpd;          // Forward_Backward::log_posterior
-                    const float p = fexp(lp);
-                    ps[0] += p * u0[u]; ps[1] += p * u1[u]; ps[2] += p * u2[u];
-                    ps[3] += p * v0[u]; ps[4] += p * v1[u]; ps[5] += p * v2[u];
-                    if ((i + 1 < (int)n) && ((train >> u) & 1u)) {
-                        // Parameter_Trainer.hpp:470-512 for the pair (i, i+1); gprev/h1prev belong to event i+1
-                        const float pst = __builtin_fminf(fexp(al[u] + lps + gprev[u] - lpd), p);
-                        const float pstep = fexp(al[u] + lps4 + h1prev[u] - lpd);
-                        const float p01 = __builtin_fminf(pst + pstep, p);
-                        acc_p += p; acc_stay += pst; acc_skip += p - p01;
-                    }
-                }
-                if (P.out_beta) {
-                    float* brow = P.out_beta + (e0 + (uint64_t)i) * kStates + j0;
-                    *reinterpret_cast<float4*>(brow) = make_float4(beta[0], beta[1], beta[2], beta[3]);
-                    *reinterpret_cast<float4*>(brow + 4) = make_float4(beta[4], beta[5], beta[6], beta[7]);
-                }
-                // per-event block sums -> out_pm_sums[e0 + i][0..5]
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const float v = wave_sum(ps[q]);
-                    if (lane == 0) atomicAdd(&sAcc[buf][q], v);
-                }
-                if (i > 0) {
-                    // g = emission(event i) + beta_i; H1/H2 over consecutive successor groups (Forward_Backward.hpp:107-125)
-                    float g[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        g[u] = emission(x, y, ry, ly3, P.log_2pi, mu[u], sg[u], rsg[u], nls[u], eta[u], reta[u], lam[u], cc[u]) + beta[u];
-                    const MaxSum a = lse4(g[0], g[1], g[2], g[3]);
-                    const MaxSum b = lse4(g[4], g[5], g[6], g[7]);
+                    // Forward_Backward.hpp:72-89: raw group sums of the previous column
+                    const MaxSum a = lse4(alpha[0], alpha[2], alpha[4], alpha[6]);   // y = h
+                    const MaxSum b = lse4(alpha[1], alpha[3], alpha[5], alpha[7]);   // y = h + 2
                     MaxSum s8 = lse_merge(a, b);
                     s8 = lse_merge(s8, MaxSum{swap1(s8.m), swap1(s8.s)});
-                    sG1[buf][2 * tau] = a.m + flog(a.s);
-                    sG1[buf][2 * tau + 1] = b.m + flog(b.s);
-                    if (h == 0) sG2[buf][t] = s8.m + flog(s8.s);
-                    __syncthreads();
-                    const unsigned rb = j0 & 1023u, qb = j0 & 255u;
-                    const float4 h1a = *reinterpret_cast<const float4*>(&sG1[buf][rb]);
-                    const float4 h1b = *reinterpret_cast<const float4*>(&sG1[buf][rb + 4]);
-                    const float4 h2a = *reinterpret_cast<const float4*>(&sG2[buf][qb]);
-                    const float4 h2b = *reinterpret_cast<const float4*>(&sG2[buf][qb + 4]);
-                    const float H1[8] = {h1a.x, h1a.y, h1a.z, h1a.w, h1b.x, h1b.y, h1b.z, h1b.w};
-                    const float H2[8] = {h2a.x, h2a.y, h2a.z, h2a.w, h2b.x, h2b.y, h2b.z, h2b.w};
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        beta[u] = lse3(c0[u] + g[u], c1[u] + H1[u], c2[u] + H2[u]);
-                        gprev[u] = g[u]; h1prev[u] = H1[u];
-                    }
-                } else {
+                    sG1[buf][(h << 8) | t] = a.m + lg2(a.s);
+                    sG1[buf][((2u + h) << 8) | t] = b.m + lg2(b.s);
+                    if (h == 0) sG2[buf][t] = s8.m + lg2(s8.s) + w2;
                     __syncthreads();
                 }
-                // the barrier above also completed every wave's atomicAdd for event i
-                if (tau < 6 && P.out_pm_sums) P.out_pm_sums[(e0 + (uint64_t)i) * 6 + tau] = sAcc[buf][tau];
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the read above precedes the reset below
-                if (tau < 6) sAcc[buf][tau] = 0.0f;    // reused two events later, after another barrier
-            }
-            // window totals of the transition statistics
-            acc_p = wave_sum(acc_p); acc_stay = wave_sum(acc_stay); acc_skip = wave_sum(acc_skip);
-            __syncthreads();
-            if (lane == 0) { sRed[wave] = acc_p; sRed[8 + wave] = acc_stay; }
-            __syncthreads();
-            float tp = 0, tst = 0;
-            if (tau == 0) {
-                for (int q = 0; q < kThreads / 64; ++q) { tp += sRed[q]; tst += sRed[8 + q]; }
+                const float* pa = &sG1[buf][r1_base];
+                const float* pb = &sG2[buf][q_base];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned kc = 4u * (unsigned)(q >> 1) + 2u * (unsigned)(q & 1);
+                    const float e = emission2(ev.x, ev.y, ev.w, ev.z, mu[q], r2[q], eta[q], lq[q], k0[q]);
+                    if (i == 0) alpha[q] = e - P.log_n_states * kLog2e;                   // Forward_Backward.hpp:58-68
+                    else alpha[q] = e + lse3(c0[q] + alpha[q], c1[q] + pa[kc << 6], pb[kc << 4]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) arow[(uint64_t)i * kStates + jj[q]] = alpha[q] * store_scale;
             }
             __syncthreads();
-            if (lane == 0) sRed[wave] = acc_skip;
-            __syncthreads();
-            if (tau == 0 && P.out_st_sums) {
-                float tsk = 0;
-                for (int q = 0; q < kThreads / 64; ++q) tsk += sRed[q];
-                P.out_st_sums[3 * w + 0] = flog(tp);
-                P.out_st_sums[3 * w + 1] = flog(tst);
-                P.out_st_sums[3 * w + 2] = flog(tsk);
+        }
+        // log_pr_data = LSE_j alpha[n-1][j]  (Forward_Backward.hpp:129-134)
+        float m = kNegBig;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = __builtin_fmaxf(m, alpha[q]);
+        m = wave_max(m);
+        if (lane == 0) sRed[wave] = m;
+        __syncthreads();
+        float bm = sRed[0];
+#pragma unroll
+        for (int q = 1; q < kThreads / 64; ++q) bm = __builtin_fmaxf(bm, sRed[q]);
+        float s = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += ex2(alpha[q] - bm);
+        s = wave_sum(s);
+        if (lane == 0) sRed[8 + wave] = s;
+        __syncthreads();
+        float bs = 0;
+#pragma unroll
+        for (int q = 0; q < kThreads / 64; ++q) bs += sRed[8 + q];
+        if (tau == 0) {
+            const float l2 = bm + lg2(bs);
+            P.ws_lpd2[w] = l2;
+            P.out_log_pr_data[w] = l2 * kLn2;
+        }
+    }
+}
+
+// ================================================ backward + statistics ================================================
+// The emission statistics of Parameter_Trainer.hpp:284-296 are sums over the UNSCALED model:
+//   s0,s1,s2 = sum_j p / su^2 {1, mu_u, mu_u^2}     l0,l1,l2 = sum_j p lambda_u {1, 1/eta_u, 1/eta_u^2}
+// The kernel holds only the scaled states (mu = mu_u scale + shift, sigma = su var, eta = eta_u scale_sd,
+// lambda = lambda_u var_sd; Pore_Model.hpp:126-138) and accumulates, per event,
+//   S0,S1,S2 = sum_j p r2 {1, mu, mu^2}            S3,S4,S5 = sum_j p lq {eta^2, eta, 1}
+// (r2, lq are the emission constants already in registers).  The six block sums are mapped back by one thread
+// each, in double:  s0 = cU S0, s1 = cU (S1 - shift S0) / scale, s2 = cU (S2 - 2 shift S1 + shift^2 S0) / scale^2,
+// l0 = cL S3, l1 = cL scale_sd S4, l2 = cL scale_sd^2 S5,  cU = 2 ln2 var^2, cL = 2 ln2 / var_sd.
+__global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
+{
+    __shared__ __attribute__((aligned(16))) float sTab[3][kStates];   // c0b log2 | c1b log2 | emission constant k0
+    __shared__ __attribute__((aligned(16))) float sG1[2][1024];
+    __shared__ __attribute__((aligned(16))) float sG2[2][256];
+    __shared__ float sRed[16];
+    __shared__ __attribute__((aligned(16))) float sAcc[2][kThreads / 64][8];   // per-event sums of each wave, by event parity
+    __shared__ float sCoef[6][4];   // per window: how output q is formed from the block sums {k_a, k_b, k_c}
+    __shared__ unsigned sWork;
+
+    const unsigned tau = threadIdx.x;
+    const unsigned t = tau >> 1, h = tau & 1u;
+    const unsigned wave = tau >> 6, lane = tau & 63u;
+    const unsigned j0 = tau * 8u;
+
+    for (;;) {
+        if (tau == 0) sWork = atomicAdd(P.queue, 1u);
+        __syncthreads();
+        const unsigned w = sWork;
+        __syncthreads();
+        if (w >= P.n_win) break;
+        const uint64_t e0 = P.off[w];
+        const unsigned n = (unsigned)(P.off[w + 1] - e0);
+        if (n == 0) {
+            if (tau == 0 && P.out_st_sums) { P.out_st_sums[3 * w] = P.out_st_sums[3 * w + 1] = P.out_st_sums[3 * w + 2] = -__builtin_inff(); }
+            continue;
+        }
+        const int ms = P.scaled_slot ? P.scaled_slot[w] : 0;
+        const int ts = P.trans_slot ? P.trans_slot[w] : 0;
+        const float* __restrict__ M = P.models + (size_t)ms * kModelFloats;
+        const float* __restrict__ C = P.trans_fb + (size_t)ts * kFbTransFloats;
+        const float* __restrict__ ex = P.cmean + e0;
+        const float* __restrict__ ey = P.stdv + e0;
+        const float* __restrict__ el = P.lstdv + e0;
+        const float* const arow = P.ws_alpha + e0 * (uint64_t)kStates;
+        const float lpd = P.ws_lpd2[w];   // base 2
+        const float load_scale = P.alpha_natural ? kLog2e : 1.0f;
+
+        float mu[8], r2[8], eta[8], lq[8], beta[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned j = j0 + u;
+            const StateK s = make_state(M, j, P.log_2pi);
+            mu[u] = s.mu; r2[u] = s.r2; eta[u] = s.eta; lq[u] = s.lq;
+            const unsigned o = tab_off(tau, (unsigned)u >> 1) + ((unsigned)u & 1u);
+            sTab[2][o] = s.k0;
+            sTab[0][o] = C[3 * kStates + j] * kLog2e;
+            sTab[1][o] = C[4 * kStates + j] * kLog2e;   // (each thread reads back only what it wrote)
+            beta[u] = 0.0f;                        // Forward_Backward.hpp:93-103
+        }
+        // c2b[j] = w2[j & 255] for every state: the producer of successor group q = tau >> 1 adds it
+        const float w2 = P.trans[(size_t)ts * kTransFloats + kStates + 1024 + t] * kLog2e;
+        const unsigned train = P.train_mask[tau];   // bit u: state j0+u is a transition-training k-mer
+        float lps = 0.0f, lps4 = 0.0f;
+        if (P.st_params) {
+            const float p_stay = P.st_params[2 * w], p_skip = P.st_params[2 * w + 1];
+            lps = lg2(p_stay);                              // Parameter_Trainer.hpp:444
+            lps4 = lg2(1.0f - p_stay - p_skip) - 2.0f;      // :445  (log2 of 1/4)
+        }
+        // how thread q < 6 turns the block sums {S_q, S_ib, S_ic} into its output (see the kernel comment)
+        if (tau < 6) {
+            float k_a = 0, k_b = 0, k_c = 0;
+            float scale = 1, shift = 0, var = 1, scale_sd = 1, var_sd = 1;
+            if (P.pm_params) {
+                const float* q = P.pm_params + 6 * (size_t)w;
+                scale = q[0]; shift = q[1]; var = q[3]; scale_sd = q[4]; var_sd = q[5];
             }
+            const double two_ln2 = 2.0 * 0.69314718055994530942;
+            const double cU = two_ln2 * (double)var * (double)var, cL = two_ln2 / (double)var_sd;
+            const double sh = shift, sc = scale, ssd = scale_sd;
+            switch (tau) {
+            case 0: k_a = (float)cU; break;
+            case 1: k_a = (float)(cU / sc); k_b = (float)(-cU * sh / sc); break;                   // with S0
+            case 2:
+                k_a = (float)(cU / (sc * sc)); k_b = (float)(-2.0 * cU * sh / (sc * sc));          // with S1
+                k_c = (float)(cU * sh * sh / (sc * sc));                                             // with S0
+                break;
+            case 3: k_a = (float)cL; break;
+            case 4: k_a = (float)(cL * ssd); break;
+            default: k_a = (float)(cL * ssd * ssd); break;
+            }
+            sCoef[tau][0] = k_a; sCoef[tau][1] = k_b; sCoef[tau][2] = k_c;   // read back by the same thread only
+        }
+        float acc_p = 0, acc_stay = 0, acc_skip = 0;
+
+        const float* rowp = arow + (uint64_t)(n - 1) * kStates;    // uniform row pointer + 32-bit thread offset
+        float4 nx_lo = *reinterpret_cast<const float4*>(rowp + j0);
+        float4 nx_hi = *reinterpret_cast<const float4*>(rowp + j0 + 4);
+        float nx_x = ex[n - 1], nx_y = ey[n - 1], nx_l = el[n - 1];
+        float ps[6];
+        // the six emission sums of one state (Parameter_Trainer.hpp:284-296, on the scaled constants)
+        auto pm_add = [&](int u, float p) {
+            const float t0 = p * r2[u], l0 = p * lq[u];
+            const float t1 = t0 * mu[u], l1 = l0 * eta[u];
+            ps[0] += t0; ps[1] += t1; ps[2] += t1 * mu[u];
+            ps[5] += l0; ps[4] += l1; ps[3] += l1 * eta[u];
+        };
+        // end of one event's statistics: beta row out, the wave's six sums to LDS.  The block total is formed after
+        // the NEXT barrier (publish) -> out_pm_sums[e0 + ei][0..5]
+        auto stats_end = [&](unsigned ei) {
+            if (P.out_beta) {
+                float* brow = P.out_beta + (e0 + (uint64_t)ei) * kStates;
+                brow += j0;
+                *reinterpret_cast<float4*>(brow) = make_float4(beta[0] * kLn2, beta[1] * kLn2, beta[2] * kLn2, beta[3] * kLn2);
+                *reinterpret_cast<float4*>(brow + 4) = make_float4(beta[4] * kLn2, beta[5] * kLn2, beta[6] * kLn2, beta[7] * kLn2);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ps[q] = wave_sum_lane63(ps[q]);
+            if (lane == 63) {
+                float* dst = &sAcc[ei & 1u][wave][0];
+                *reinterpret_cast<float4*>(dst) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+                *reinterpret_cast<f2*>(dst + 4) = f2{ps[4], ps[5]};
+            }
+        };
+        auto publish = [&](unsigned ei) {
+            if (tau < 6 && P.out_pm_sums) {
+                const unsigned i_b = tau == 2 ? 1u : 0u;    // second term: S1 for s2, S0 for s1; third term: S0
+                float va = 0.0f, vb = 0.0f, vc = 0.0f;
+#pragma unroll
+                for (int wv = 0; wv < kThreads / 64; ++wv) {
+                    va += sAcc[ei & 1u][wv][tau]; vb += sAcc[ei & 1u][wv][i_b]; vc += sAcc[ei & 1u][wv][0];
+                }
+                P.out_pm_sums[(e0 + (uint64_t)ei) * 6 + tau] =
+                    __builtin_fmaf(sCoef[tau][0], va, __builtin_fmaf(sCoef[tau][1], vb, sCoef[tau][2] * vc));
+            }
+        };
+
+        {   // event n-1: beta = 0, no following event
+            const float al[8] = {nx_lo.x, nx_lo.y, nx_lo.z, nx_lo.w, nx_hi.x, nx_hi.y, nx_hi.z, nx_hi.w};
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ps[q] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pm_add(u, ex2(al[u] * load_scale - lpd));
+            stats_end(n - 1);
+        }
+        for (int i = (int)n - 1; i >= 1; --i) {
+            // on entry: beta = beta_i; nx_x/y/l = event i.  Leaves beta = beta_{i-1} and the statistics of event i-1.
+            const unsigned buf = (unsigned)i & 1u;
+            const float x = nx_x, y = nx_y, l3 = (1.5f * kLog2e) * nx_l, ry = 1.0f / y;
+            // alpha_{i-1} for the statistics at the end of this iteration, event i-1 for the next one
+            rowp -= kStates;
+            nx_lo = *reinterpret_cast<const float4*>(rowp + j0);
+            nx_hi = *reinterpret_cast<const float4*>(rowp + j0 + 4);
+            nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_l = el[i - 1];
+            // g = emission(event i) + beta_i; H1/H2 over consecutive successor groups (Forward_Backward.hpp:107-125)
+            float g[8];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const f2 k02 = *reinterpret_cast<const f2*>(&sTab[2][tab_off(tau, pr)]);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int q = 2 * pr + v;
+                    g[q] = emission2(x, y, ry, l3, mu[q], r2[q], eta[q], lq[q], k02[v]) + beta[q];
+                }
+            }
+            const MaxSum a = lse4(g[0], g[1], g[2], g[3]);
+            const MaxSum b = lse4(g[4], g[5], g[6], g[7]);
+            MaxSum s8 = lse_merge(a, b);
+            s8 = lse_merge(s8, MaxSum{swap1(s8.m), swap1(s8.s)});
+            sG1[buf][2 * tau] = a.m + lg2(a.s);
+            sG1[buf][2 * tau + 1] = b.m + lg2(b.s);
+            if (h == 0) sG2[buf][t] = s8.m + lg2(s8.s) + w2;
+            __syncthreads();
+            publish((unsigned)i);    // the barrier made every wave's sums of event i visible
+            const float al[8] = {nx_lo.x, nx_lo.y, nx_lo.z, nx_lo.w, nx_hi.x, nx_hi.y, nx_hi.z, nx_hi.w};
+            const float* ph1 = &sG1[buf][j0 & 1023u];
+            const float* ph2 = &sG2[buf][j0 & 255u];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ps[q] = 0.0f;
+            // per state: beta_{i-1}, then at once everything that needs (g, H1) of event i -- the posterior of event
+            // i-1 and the transition sums of the pair (i-1, i), Parameter_Trainer.hpp:470-512 -- so both die here
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const f2 c02 = *reinterpret_cast<const f2*>(&sTab[0][tab_off(tau, pr)]);
+                const f2 c12 = *reinterpret_cast<const f2*>(&sTab[1][tab_off(tau, pr)]);
+                const f2 h1 = *reinterpret_cast<const f2*>(ph1 + 2 * pr);
+                const f2 h2 = *reinterpret_cast<const f2*>(ph2 + 2 * pr);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int u = 2 * pr + v;
+                    beta[u] = lse3(c02[v] + g[u], c12[v] + h1[v], h2[v]);
+                    const float a2 = al[u] * load_scale;
+                    const float p = ex2(a2 + beta[u] - lpd);             // exp(Forward_Backward::log_posterior)
+                    pm_add(u, p);
+                    const float pm = ((train >> u) & 1u) ? p : 0.0f;      // only transition-training k-mers count
+                    const float pst = __builtin_fminf(ex2(a2 + lps + g[u] - lpd), pm);
+                    const float pstep = ex2(a2 + lps4 + h1[v] - lpd);
+                    const float p01 = __builtin_fminf(pst + pstep, pm);
+                    acc_p += pm; acc_stay += pst; acc_skip += pm - p01;
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one state pair in flight: bounds the live temporaries
+            }
+            stats_end((unsigned)(i - 1));
+        }
+        __syncthreads();
+        publish(0u);
+        // window totals of the transition statistics
+        acc_p = wave_sum(acc_p); acc_stay = wave_sum(acc_stay); acc_skip = wave_sum(acc_skip);
+        __syncthreads();
+        if (lane == 0) { sRed[wave] = acc_p; sRed[8 + wave] = acc_stay; }
+        __syncthreads();
+        float tp = 0, tst = 0;
+        if (tau == 0) {
+            for (int q = 0; q < kThreads / 64; ++q) { tp += sRed[q]; tst += sRed[8 + q]; }
+        }
+        __syncthreads();
+        if (lane == 0) sRed[wave] = acc_skip;
+        __syncthreads();
+        if (tau == 0 && P.out_st_sums) {
+            float tsk = 0;
+            for (int q = 0; q < kThreads / 64; ++q) tsk += sRed[q];
+            P.out_st_sums[3 * w + 0] = lg2(tp) * kLn2;
+            P.out_st_sums[3 * w + 1] = lg2(tst) * kLn2;
+            P.out_st_sums[3 * w + 2] = lg2(tsk) * kLn2;
         }
     }
 }
 
 void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(fwbw_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
+    // two launches on one stream: the backward sweep reads the alpha rows and log_pr_data of the forward one
+    FwbwArgs f = a, b = a;
+    f.queue = a.queue; b.queue = a.queue + 1;
+    hipLaunchKernelGGL(fwbw_forward_kernel, dim3(grid), dim3(kThreads), 0, stream, f);
+    hipLaunchKernelGGL(fwbw_backward_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
 }
 
-int fwbw_blocks_per_cu()
+static int blocks_per_cu(const void* fn)
 {
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fwbw_kernel)) != hipSuccess) return 1;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 1;
     const int by_lds = fa.sharedSizeBytes > 0 ? (int)(163840 / fa.sharedSizeBytes) : 8;
     const int regs = ((fa.numRegs + 7) / 8) * 8;
     const int waves_per_simd = regs > 0 ? 512 / regs : 8;
@@ -370,6 +503,13 @@ int fwbw_blocks_per_cu()
     if (by_lds < nb) nb = by_lds;
     if (nb > 32 / (kThreads / 64)) nb = 32 / (kThreads / 64);
     return nb < 1 ? 1 : nb;
+}
+
+int fwbw_blocks_per_cu()
+{
+    const int f = blocks_per_cu(reinterpret_cast<const void*>(fwbw_forward_kernel));
+    const int b = blocks_per_cu(reinterpret_cast<const void*>(fwbw_backward_kernel));
+    return f < b ? f : b;
 }
 
 }  // namespace nchmm

@@ -40,6 +40,8 @@ struct nchmm_ctx {
     size_t last_state_bytes = 0;
     float* d_fb_ws = nullptr;       // FB alpha workspace
     size_t fb_ws_floats = 0;
+    float* d_fb_lpd2 = nullptr;     // FB per-window log2 Pr(data), forward kernel -> backward kernel
+    size_t fb_lpd2_bytes = 0;
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -405,6 +407,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_last_state) (void)hipFree(c->d_last_state);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
+    if (c->d_fb_lpd2) (void)hipFree(c->d_fb_lpd2);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
@@ -716,7 +719,7 @@ int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float
 
 int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_events, const uint64_t* d_off,
                    const float* d_cmean, const float* d_stdv, const float* d_lstdv, const int32_t* d_scaled_slot,
-                   const int32_t* d_unscaled_slot, const int32_t* d_trans_slot, const float* d_st_params,
+                   const float* d_pm_params, const int32_t* d_trans_slot, const float* d_st_params,
                    float* d_out_lpd, float* d_out_pm, float* d_out_st, float* d_out_alpha, float* d_out_beta)
 {
     if (!c) return NCHMM_E_INVALID;
@@ -734,16 +737,22 @@ int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_e
         if (rc != NCHMM_OK) return rc;
         alpha = c->d_fb_ws;
     }
+    {
+        void* p = c->d_fb_lpd2;
+        int rc = ensure(c, &p, &c->fb_lpd2_bytes, n_win * sizeof(float));
+        c->d_fb_lpd2 = (float*)p;
+        if (rc != NCHMM_OK) return rc;
+    }
     FwbwArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
-    a.scaled_slot = d_scaled_slot; a.unscaled_slot = d_unscaled_slot; a.trans_slot = d_trans_slot;
-    a.st_params = d_st_params; a.models = c->d_models; a.trans_fb = c->d_trans_fb; a.train_mask = c->d_train_mask;
-    a.ws_alpha = alpha; a.out_log_pr_data = d_out_lpd; a.out_pm_sums = d_out_pm; a.out_st_sums = d_out_st;
+    a.scaled_slot = d_scaled_slot; a.pm_params = d_pm_params; a.trans_slot = d_trans_slot;
+    a.st_params = d_st_params; a.models = c->d_models; a.trans_fb = c->d_trans_fb; a.trans = c->d_trans; a.train_mask = c->d_train_mask;
+    a.ws_alpha = alpha; a.ws_lpd2 = c->d_fb_lpd2; a.alpha_natural = d_out_alpha ? 1 : 0; a.out_log_pr_data = d_out_lpd; a.out_pm_sums = d_out_pm; a.out_st_sums = d_out_st;
     a.out_beta = d_out_beta; a.queue = c->d_queue + 1; a.n_win = (unsigned)n_win;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Forward_Backward.hpp:53
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     const int grid = (int)std::min<size_t>((size_t)c->fb_slots, n_win);
-    HIP_TRY(c, hipMemsetAsync(c->d_queue + 1, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue + 1, 0, 2 * sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_fb0, c->stream));
     launch_fwbw(a, grid, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -754,7 +763,7 @@ int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_e
 }
 
 int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cmean, const float* stdv, const float* lstdv,
-               const int32_t* scaled_slot, const int32_t* unscaled_slot, const int32_t* trans_slot, const float* st_params,
+               const int32_t* scaled_slot, const float* pm_params, const int32_t* trans_slot, const float* st_params,
                float* out_lpd, float* out_pm, float* out_st, float* out_alpha, float* out_beta)
 {
     if (!c) return NCHMM_E_INVALID;
@@ -764,17 +773,16 @@ int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cme
     if (rc != NCHMM_OK) return rc;
     if (!out_lpd || (total && (!cmean || !stdv || !lstdv))) return NCHMM_E_INVALID;
     for (size_t w = 0; w < n_win; ++w) {
-        const int ms = scaled_slot ? scaled_slot[w] : 0, us = unscaled_slot ? unscaled_slot[w] : ms;
+        const int ms = scaled_slot ? scaled_slot[w] : 0;
         const int ts = trans_slot ? trans_slot[w] : 0;
-        if (ms < 0 || ms >= c->n_slots || us < 0 || us >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms]
-            || !c->model_set[us] || !c->trans_set[ts])
+        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts])
             return NCHMM_E_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t mat = out_alpha || out_beta ? al(4 * total * kStates) : 0;
     size_t o_off = 0, o_cm = o_off + al(8 * (n_win + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total);
-    size_t o_ss = o_ls + al(4 * total), o_us = o_ss + al(4 * n_win), o_ts = o_us + al(4 * n_win), o_sp = o_ts + al(4 * n_win);
+    size_t o_ss = o_ls + al(4 * total), o_us = o_ss + al(4 * n_win), o_ts = o_us + al(24 * n_win), o_sp = o_ts + al(4 * n_win);
     size_t o_lp = o_sp + al(8 * n_win), o_pm = o_lp + al(4 * n_win), o_st = o_pm + al(24 * total), o_al = o_st + al(12 * n_win);
     size_t o_be = o_al + (out_alpha ? mat : 0), need = o_be + (out_beta ? mat : 0);
     rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
@@ -788,12 +796,12 @@ int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cme
         HIP_TRY(c, hipMemcpyAsync(d + o_ls, lstdv, 4 * total, hipMemcpyHostToDevice, s));
     }
     if (scaled_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ss, scaled_slot, 4 * n_win, hipMemcpyHostToDevice, s));
-    if (unscaled_slot) HIP_TRY(c, hipMemcpyAsync(d + o_us, unscaled_slot, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (pm_params) HIP_TRY(c, hipMemcpyAsync(d + o_us, pm_params, 24 * n_win, hipMemcpyHostToDevice, s));
     if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_win, hipMemcpyHostToDevice, s));
     if (st_params) HIP_TRY(c, hipMemcpyAsync(d + o_sp, st_params, 8 * n_win, hipMemcpyHostToDevice, s));
     rc = nchmm_fwbw_dev(c, n_win, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm),
                         (const float*)(d + o_sd), (const float*)(d + o_ls), scaled_slot ? (const int32_t*)(d + o_ss) : nullptr,
-                        unscaled_slot ? (const int32_t*)(d + o_us) : nullptr, trans_slot ? (const int32_t*)(d + o_ts) : nullptr,
+                        pm_params ? (const float*)(d + o_us) : nullptr, trans_slot ? (const int32_t*)(d + o_ts) : nullptr,
                         st_params ? (const float*)(d + o_sp) : nullptr, (float*)(d + o_lp), out_pm ? (float*)(d + o_pm) : nullptr,
                         out_st ? (float*)(d + o_st) : nullptr, out_alpha ? (float*)(d + o_al) : nullptr,
                         out_beta ? (float*)(d + o_be) : nullptr);

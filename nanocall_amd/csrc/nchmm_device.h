@@ -60,18 +60,21 @@ struct FwbwArgs {
     const float* lstdv;
     const uint64_t* off;
     const int32_t* scaled_slot;
-    const int32_t* unscaled_slot;
+    const float* pm_params;     // n_win x 6 {scale, shift, drift, var, scale_sd, var_sd} behind scaled_slot[w], or null (identity)
     const int32_t* trans_slot;
     const float* st_params;     // n_win x 2 {p_stay, p_skip} or null
     const float* models;        // [kMaxSlots][kModelFloats]
     const float* trans_fb;      // [kMaxSlots][kFbTransFloats]
+    const float* trans;         // [kMaxSlots][kTransFloats] (the group weights w2 are read from here)
     const uint8_t* train_mask;  // [512] bit u of byte tau: state 8*tau+u is a transition-training k-mer
     float* ws_alpha;            // alpha rows, one per event of the batch (4096 floats each)
+    float* ws_lpd2;             // [n_win] log2 Pr(data | window), forward kernel -> backward kernel
+    int alpha_natural;          // rows are natural logs (caller's out_alpha buffer) instead of the internal base 2
     float* out_log_pr_data;
     float* out_pm_sums;
     float* out_st_sums;
     float* out_beta;
-    unsigned* queue;
+    unsigned* queue;            // [2] work-queue heads: forward kernel, backward kernel
     unsigned n_win;
     float log_n_states;
     float log_2pi;

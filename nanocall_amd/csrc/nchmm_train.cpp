@@ -145,7 +145,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         std::vector<float> t_skip(2 * na, o->default_p_skip), t_stay(2 * na, o->default_p_stay);
         std::vector<uint64_t> off{0};
         std::vector<float> cm, sd, ls, raw_mean, raw_start, stp;
-        std::vector<int32_t> s_slot, u_slot, t_slot;
+        std::vector<int32_t> s_slot, t_slot;
+        std::vector<float> w_pm;                                      // per window: the parameters behind its scaled model
         std::vector<size_t> first_win(na + 1, 0);
         m_idx.assign(2 * na, 0); m_par.assign(12 * na, 0.f);
         for (size_t p = 0; p < na; ++p) {
@@ -166,7 +167,7 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
                 }
                 off.push_back(cm.size());
                 s_slot.push_back((int32_t)(n_models + 2 * p + w.strand));
-                u_slot.push_back(j.m[w.strand]);
+                w_pm.insert(w_pm.end(), j.old_pm, j.old_pm + 6);
                 // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
                 const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
                 t_slot.push_back(dflt ? 0 : (int32_t)(1 + 2 * p + w.strand));
@@ -178,7 +179,7 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         if ((rc = nchmm_put_transitions_fast(ctx, 1, 2 * na, t_skip.data(), t_stay.data()))) return rc;
         const size_t n_win = s_slot.size(), tot = cm.size();
         std::vector<float> lpd(n_win), pm_sums(6 * tot), st_sums(3 * n_win);
-        rc = nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), u_slot.data(), t_slot.data(),
+        rc = nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), w_pm.data(), t_slot.data(),
                         stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr);
         if (rc != NCHMM_OK) return rc;
         // ---- finish the round per job (Parameter_Trainer.hpp:557-578) and apply the stop rules ----

@@ -81,9 +81,12 @@ def test_train_reads_matches_reference_loop(gpu_ctx):
         assert out["rounds"][k] == rnd, (k, out["rounds"][k], rnd)
         assert abs(out["fit"][k] - fit) <= 1e-4 * abs(fit), (k, out["fit"][k], fit)
         got = out["pm"][k]
-        for q in (0, 4, 5):
+        for q in (0, 4):
             assert abs(got[q] - pm[q]) <= 2e-4 * abs(pm[q]), (k, q, got, pm)
-        assert abs(got[3] - pm[3]) <= 1e-3 * abs(pm[3]), (k, got, pm)           # var: see test_fwbw_gpu.py
+        # var, var_sd: ill-conditioned (fp32 reference noise ~1e-4 per round, test_fwbw_gpu.py) and this loop
+        # runs free, each round starting from its own previous parameters
+        for q in (3, 5):
+            assert abs(got[q] - pm[q]) <= 1.5e-3 * abs(pm[q]), (k, q, got, pm)
         assert abs(got[1] - pm[1]) <= 2e-4 * 60 and abs(got[2] - pm[2]) <= 2e-4 * 60 / max(float(start.max()), 1.0)
         assert np.allclose(out["st"][k], st, rtol=5e-4, atol=0), (k, out["st"][k], st)
     # selection: read 0's pair trained on the matching complement model must win by > threshold or not at all,

@@ -44,7 +44,7 @@ d_st = torch.empty(n_win * 3, dtype=torch.float32, device=dev)
 
 def step():
     ctx.fwbw_dev(n_win, n_ev, total, d_off, d_cm, d_sd, d_ls, d_lpd, d_pm, d_st, d_scaled_slot=d_slot,
-                 d_unscaled_slot=d_slot, d_trans_slot=d_tr, d_st_params=d_sp)
+                 d_trans_slot=d_tr, d_st_params=d_sp)
 
 
 step(); torch.cuda.synchronize()

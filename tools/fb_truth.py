@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""tools/fb_truth.py -- where does the fp32 noise of one EM round come from?
+
+Runs round 0 of the 2D EM fixture (tests/golden/em_2d_drift1.npz: 4 windows x 100 events, identity
+scaling, p_stay 0.1 / p_skip 0.3) three ways and prints the six trained scaling parameters:
+
+  truth   forward-backward and the per-event inner sums in float64 (numpy; same fp32 inputs: model
+          tables, transition weights, events), finished by nchmm_train_pm_finish
+  oracle  the CPU restatement of the reference (fp32 throughout, as the reference is) -- the fixture
+  gpu     the HIP kernels
+
+The relative distance of `oracle` and `gpu` to `truth` is what the parameter tolerances in
+tests/test_fwbw_gpu.py are set from: the reference's own fp32 arithmetic is no closer to the real-number
+answer than the GPU's.  Needs a GPU (run through gpurun); the float64 part is plain numpy.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nanocall_amd as na  # noqa: E402
+
+S = 4096
+LOG_2PI = np.log(2.0 * np.pi)
+
+
+def lse(a, axis):
+    m = np.max(a, axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    return (m + np.log(np.sum(np.exp(a - m), axis=axis, keepdims=True))).squeeze(axis)
+
+
+def emission64(t6, x, y):
+    mu, sg, eta, lam = (t6[:, k].astype(np.float64) for k in (0, 1, 3, 4))
+    a = (x - mu) / sg
+    n = -np.log(sg) - (LOG_2PI + a * a) / 2.0
+    ig = (np.log(lam) - LOG_2PI - 3.0 * np.log(y) - lam * (y - eta) ** 2 / (eta * eta * y)) / 2.0
+    return n + ig
+
+
+def fwbw64(t6, rp, pred, logw, cm, sd):
+    n = cm.shape[0]
+    deg = np.diff(rp.astype(np.int64))
+    dmax = int(deg.max())
+    P = np.zeros((S, dmax), np.int64)
+    W = np.full((S, dmax), -np.inf)
+    SP = [[] for _ in range(S)]
+    for j in range(S):
+        a, b = int(rp[j]), int(rp[j + 1])
+        P[j, : b - a] = pred[a:b]
+        W[j, : b - a] = logw[a:b]
+        for k in range(a, b):
+            SP[int(pred[k])].append((j, float(logw[k])))
+    smax = max(len(v) for v in SP)
+    Q = np.zeros((S, smax), np.int64)
+    V = np.full((S, smax), -np.inf)
+    for p, v in enumerate(SP):
+        for k, (j, w) in enumerate(v):
+            Q[p, k] = j
+            V[p, k] = w
+    E = np.stack([emission64(t6, float(cm[i]), float(sd[i])) for i in range(n)])
+    al = np.empty((n, S))
+    be = np.zeros((n, S))
+    al[0] = E[0] - np.log(float(S))
+    for i in range(1, n):
+        al[i] = E[i] + lse(W + al[i - 1][P], 1)
+    for i in range(n - 2, -1, -1):
+        g = E[i + 1] + be[i + 1]
+        be[i] = lse(V + g[Q], 1)
+    lpd = lse(al[n - 1], 0)
+    return lpd, al, be
+
+
+def setup():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "em_2d_drift1.npz"))
+    tabs = [na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")]
+    pm = np.array([1, 0, 0, 1, 1, 1], np.float32)
+    d = dict(z=z, pm=pm, strand=z["strand"].astype(np.int64), off=z["off"], mean=z["mean"], start=z["start"])
+    d["rp"], d["pred"], d["logw"] = na.transitions_fast(0.3, 0.1)
+    d["cm"], d["sd"], d["ls"] = na.events_prepare(z["mean"], z["stdv"], z["start"], 0.0)
+    d["t6"] = [na.scaled_model_table(t, pm) for t in tabs]
+    return d
+
+
+def truth_round0(d):
+    """float64 forward-backward + inner sums of fixture round 0 -> (fit, pm_sums[n,6] f64, params[6] f32)."""
+    cm, sd, off, strand = d["cm"], d["sd"], d["off"], d["strand"]
+    sums = np.zeros((cm.shape[0], 6))
+    fit64 = 0.0
+    for w in range(len(strand)):
+        a, b = int(off[w]), int(off[w + 1])
+        m = d["t6"][strand[w]].astype(np.float64)
+        lpd, al, be = fwbw64(d["t6"][strand[w]], d["rp"], d["pred"], d["logw"], cm[a:b], sd[a:b])
+        fit64 += lpd
+        p = np.exp(al + be - lpd)
+        u0 = 1.0 / (m[:, 1] ** 2)
+        sums[a:b, 0] = p @ u0
+        sums[a:b, 1] = p @ (u0 * m[:, 0])
+        sums[a:b, 2] = p @ (u0 * m[:, 0] ** 2)
+        sums[a:b, 3] = p @ m[:, 4]
+        sums[a:b, 4] = p @ (m[:, 4] / m[:, 3])
+        sums[a:b, 5] = p @ (m[:, 4] / m[:, 3] ** 2)
+    truth, _ = na.train_pm_finish(sums.astype(np.float32), d["mean"], sd, d["start"], d["pm"], train_drift=True)
+    return fit64, sums, truth
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "em_2d_drift1_truth64.json")
+
+
+def main():
+    d = setup()
+    z, pm, strand, off, mean, start = d["z"], d["pm"], d["strand"], d["off"], d["mean"], d["start"]
+    cm, sd, ls, t6 = d["cm"], d["sd"], d["ls"], d["t6"]
+    fit64, sums, truth = truth_round0(d)
+    if "--golden" in sys.argv:      # CPU only: the fixture tests/test_fwbw_gpu.py holds the GPU to
+        with open(GOLDEN, "w") as f:
+            json.dump({"made_by": "tools/fb_truth.py --golden", "fit": fit64, "params": [float(v) for v in truth],
+                       "pm_sums_event_totals": [float(v) for v in sums.sum(axis=0)]}, f, indent=1)
+        print("wrote", GOLDEN)
+        return
+    rp, pred, logw = d["rp"], d["pred"], d["logw"]
+
+    # ---- gpu ----
+    ctx = na.Context(0)
+    for s in range(2):
+        ctx.put_model(12 + s, t6[s])
+        ctx.put_transitions(12 + s, rp, pred, logw)
+    out = ctx.fwbw(off, cm, sd, ls, scaled_slot=12 + strand, pm_params=pm, trans_slot=12 + strand,
+                   st_params=np.tile(np.float32([0.1, 0.3]), (len(strand), 1)))
+    gpu, _ = na.train_pm_finish(out["pm_sums"], mean, sd, start, pm, train_drift=True)
+    sum_err = np.abs(out["pm_sums"] - sums).max(axis=0) / np.abs(sums).max(axis=0)
+
+    oracle = z["rounds"][0][1:7]
+    names = ["scale", "shift", "drift", "var", "scale_sd", "var_sd"]
+    res = {"fit": {"truth": fit64, "oracle": float(z["rounds"][0][0]), "gpu": float(np.sum(out["log_pr_data"], dtype=np.float64))},
+           "pm_sums_max_rel_err_gpu_vs_truth": [float(v) for v in sum_err], "params": {}}
+    for k, nme in enumerate(names):
+        # shift is an offset on a ~60 pA level scale, drift on ~60 pA per read time span
+        den = {"shift": 60.0, "drift": 60.0 / float(start.max())}.get(nme, abs(float(truth[k])))
+        res["params"][nme] = {"truth": float(truth[k]), "oracle": float(oracle[k]), "gpu": float(gpu[k]),
+                              "oracle_rel_err": abs(float(oracle[k]) - float(truth[k])) / den,
+                              "gpu_rel_err": abs(float(gpu[k]) - float(truth[k])) / den}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
