@@ -267,7 +267,8 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* opts, size_t n_
 /* ------------------------------------------------------------------------------------------
  * Counters (what the 8-GPU run gathers with one RCCL all-reduce)
  * out[0]=reads decoded, [1]=events decoded, [2]=back-pointer bytes written, [3]=kernel launches,
- * [4]=windows (FB), [5]=FB event-rounds, [6]=device bytes allocated, [7]=reserved
+ * [4]=windows (FB), [5]=FB event-rounds, [6]=device bytes allocated,
+ * [7]=FB windows the rescaled kernels handed to the exact log-space redo (synchronises the stream)
  * ---------------------------------------------------------------------------------------- */
 int nchmm_counters(const nchmm_ctx* ctx, uint64_t out[8]);
 

@@ -40,106 +40,13 @@
 //             (:451-515; linear-space sums of probabilities, returned as logs).
 #include "nanocall_hip.h"
 #include "nchmm_device.h"
+#include "fwbw_common.hpp"
 
 #pragma clang fp contract(off)
 
 namespace nchmm {
 
-namespace {
-
-constexpr unsigned kFbChunk = 128;   // events staged in LDS at a time
-constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-constexpr float kNegBig = -3.0e38f;
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 is log2
-
-__device__ __forceinline__ float swap1(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
-
-// Pore_Model_State::log_pr_corrected_emission (Pore_Model.hpp:145-149) in base 2, regrouped as
-//   k0 - [ (x - mu)^2 r2 + (y - eta)^2 lq / y + l3 ]
-// with the per-state constants  r2 = log2e / (2 sigma^2),  lq = log2e lambda / (2 eta^2),
-// k0 = log2e (-log sigma + (log lambda - 2 log 2pi) / 2)  and the per-event  l3 = log2e * 3 log(y) / 2.
-// (Same real function; the regrouping moves each cell by a few 1e-7 relative, far inside the 1e-4 FB tolerance.)
-struct StateK { float mu, r2, eta, lq, k0; };
-
-__device__ __forceinline__ StateK make_state(const float* __restrict__ M, unsigned j, float log_2pi)
-{
-    StateK s;
-    const float rsg = M[MF_RSIGMA * kStates + j], reta = M[MF_RETA * kStates + j];
-    s.mu = M[MF_MU * kStates + j];
-    s.eta = M[MF_ETA * kStates + j];
-    s.r2 = (0.5f * kLog2e) * rsg * rsg;
-    s.lq = (0.5f * kLog2e) * M[MF_LAMBDA * kStates + j] * reta * reta;
-    s.k0 = kLog2e * (M[MF_NEG_LOG_SIGMA * kStates + j] + 0.5f * (M[MF_C * kStates + j] - log_2pi));
-    return s;
-}
-
-__device__ __forceinline__ float emission2(float x, float y, float ry, float l3, float mu, float r2, float eta, float lq, float k0)
-{
-    const float dx = x - mu, dy = y - eta;
-    return k0 - __builtin_fmaf(dx * dx, r2, __builtin_fmaf(dy * dy * lq, ry, l3));
-}
-
-struct MaxSum { float m, s; };   // running base-2 log-sum-exp: value = m + log2(s)
-
-__device__ __forceinline__ MaxSum lse_merge(MaxSum a, MaxSum b)
-{
-    const float m = __builtin_fmaxf(__builtin_fmaxf(a.m, b.m), kNegBig);
-    return MaxSum{m, a.s * ex2(a.m - m) + b.s * ex2(b.m - m)};
-}
-__device__ __forceinline__ MaxSum lse4(float a, float b, float c, float d)
-{
-    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)), kNegBig);
-    return MaxSum{m, ex2(a - m) + ex2(b - m) + ex2(c - m) + ex2(d - m)};
-}
-__device__ __forceinline__ float lse3(float a, float b, float c)
-{
-    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a, b), c), kNegBig);
-    return m + lg2(ex2(a - m) + ex2(b - m) + ex2(c - m));
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, d, 64));
-    return v;
-}
-
-// Sum over the 64 lanes of a wave on the DPP path (no LDS traffic): quad swaps, row mirrors, then the two
-// row broadcasts.  Only lane 63 holds the total.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v)
-{
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
-}
-__device__ __forceinline__ float wave_sum_lane63(float v)
-{
-    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane of a row holds the row's sum
-    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-// LDS tables are pair-major: the two floats of thread tau's cell pair `pair` of a table sit at
-// sTab[f][(pair * 512 + tau) * 2 ..]: consecutive lanes read consecutive 8-byte words (conflict-free
-// ds_read_b64) and every access of a thread is ONE base register plus an immediate offset.
-__device__ __forceinline__ unsigned tab_off(unsigned tau, unsigned pair) { return (pair * (unsigned)kThreads + tau) * 2u; }
-
-}  // namespace
+using namespace fb;
 
 // ================================================ forward ================================================
 __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
@@ -155,16 +62,22 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
     const unsigned wave = tau >> 6, lane = tau & 63u;
 
     for (;;) {
-        if (tau == 0) sWork = atomicAdd(P.queue, 1u);
+        // barrier first, then thread 0's fetch: see fwbw_scaled_kernel.hip (keeps the previous window's closing
+        // `if (tau == 0)` and this one from being threaded together across the loop edge)
         __syncthreads();
-        const unsigned w = sWork;
+        if (tau == 0) {
+            const unsigned k = atomicAdd(P.queue, 1u);
+            sWork = P.win_list ? (k < *P.n_list ? P.win_list[k] : 0xFFFFFFFFu) : k;
+        }
         __syncthreads();
+        const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)sWork);   // block-uniform: keep it (and all it indexes) scalar
         if (w >= P.n_win) break;
+        do {    // (early outs `break` out of this block: one loop back edge)
         const uint64_t e0 = P.off[w];
         const unsigned n = (unsigned)(P.off[w + 1] - e0);
         if (n == 0) {
             if (tau == 0) P.out_log_pr_data[w] = __builtin_nanf("");
-            continue;
+            break;
         }
         const int ms = P.scaled_slot ? P.scaled_slot[w] : 0;
         const int ts = P.trans_slot ? P.trans_slot[w] : 0;
@@ -253,6 +166,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
             P.ws_lpd2[w] = l2;
             P.out_log_pr_data[w] = l2 * kLn2;
         }
+        } while (0);
     }
 }
 
@@ -281,16 +195,22 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
     const unsigned j0 = tau * 8u;
 
     for (;;) {
-        if (tau == 0) sWork = atomicAdd(P.queue, 1u);
+        // barrier first, then thread 0's fetch: see fwbw_scaled_kernel.hip (keeps the previous window's closing
+        // `if (tau == 0)` and this one from being threaded together across the loop edge)
         __syncthreads();
-        const unsigned w = sWork;
+        if (tau == 0) {
+            const unsigned k = atomicAdd(P.queue, 1u);
+            sWork = P.win_list ? (k < *P.n_list ? P.win_list[k] : 0xFFFFFFFFu) : k;
+        }
         __syncthreads();
+        const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)sWork);   // block-uniform: keep it (and all it indexes) scalar
         if (w >= P.n_win) break;
+        do {    // (early outs `break` out of this block: one loop back edge)
         const uint64_t e0 = P.off[w];
         const unsigned n = (unsigned)(P.off[w + 1] - e0);
         if (n == 0) {
             if (tau == 0 && P.out_st_sums) { P.out_st_sums[3 * w] = P.out_st_sums[3 * w + 1] = P.out_st_sums[3 * w + 2] = -__builtin_inff(); }
-            continue;
+            break;
         }
         const int ms = P.scaled_slot ? P.scaled_slot[w] : 0;
         const int ts = P.trans_slot ? P.trans_slot[w] : 0;
@@ -480,36 +400,35 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
             P.out_st_sums[3 * w + 1] = lg2(tst) * kLn2;
             P.out_st_sums[3 * w + 2] = lg2(tsk) * kLn2;
         }
+        } while (0);
     }
 }
 
-void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream)
+void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream, bool scaled)
 {
-    // two launches on one stream: the backward sweep reads the alpha rows and log_pr_data of the forward one
+    // forward then backward on one stream: the backward sweep reads the alpha rows and log_pr_data of the forward one
     FwbwArgs f = a, b = a;
-    f.queue = a.queue; b.queue = a.queue + 1;
+    f.win_list = b.win_list = nullptr; f.n_list = b.n_list = nullptr;
+    if (scaled) {
+        launch_fwbw_scaled(a, grid, stream);                  // queue words 0, 1
+        // exact redo, in log space, of whatever windows the scaled kernels flagged (normally none: the blocks
+        // find an empty list and leave)
+        f.win_list = b.win_list = a.fb_list; f.n_list = b.n_list = a.fb_count;
+        f.alpha_natural = b.alpha_natural = 0;
+        f.queue = a.queue + 2; b.queue = a.queue + 3;
+    } else {
+        f.queue = a.queue; b.queue = a.queue + 1;
+    }
     hipLaunchKernelGGL(fwbw_forward_kernel, dim3(grid), dim3(kThreads), 0, stream, f);
     hipLaunchKernelGGL(fwbw_backward_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
 }
 
-static int blocks_per_cu(const void* fn)
-{
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 1;
-    const int by_lds = fa.sharedSizeBytes > 0 ? (int)(163840 / fa.sharedSizeBytes) : 8;
-    const int regs = ((fa.numRegs + 7) / 8) * 8;
-    const int waves_per_simd = regs > 0 ? 512 / regs : 8;
-    int nb = waves_per_simd * 4 / (kThreads / 64);
-    if (by_lds < nb) nb = by_lds;
-    if (nb > 32 / (kThreads / 64)) nb = 32 / (kThreads / 64);
-    return nb < 1 ? 1 : nb;
-}
-
 int fwbw_blocks_per_cu()
 {
-    const int f = blocks_per_cu(reinterpret_cast<const void*>(fwbw_forward_kernel));
-    const int b = blocks_per_cu(reinterpret_cast<const void*>(fwbw_backward_kernel));
-    return f < b ? f : b;
+    const int f = fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_forward_kernel));
+    const int b = fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_backward_kernel));
+    const int s = fwbw_scaled_blocks_per_cu();
+    return f < b ? (f < s ? f : s) : (b < s ? b : s);
 }
 
 }  // namespace nchmm

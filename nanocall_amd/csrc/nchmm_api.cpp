@@ -40,8 +40,10 @@ struct nchmm_ctx {
     size_t last_state_bytes = 0;
     float* d_fb_ws = nullptr;       // FB alpha workspace
     size_t fb_ws_floats = 0;
-    float* d_fb_lpd2 = nullptr;     // FB per-window log2 Pr(data), forward kernel -> backward kernel
-    size_t fb_lpd2_bytes = 0;
+    void* d_fb_aux = nullptr;       // FB per-call scratch: lpd2 | last-row totals | redo list | redo flags | row exponents
+    size_t fb_aux_bytes = 0;
+    unsigned long long* d_fb_total = nullptr;   // windows redone in log space, running total
+    bool fb_force_log = false;      // NCHMM_FB_FORCE_LOG: never take the rescaled linear-space kernels
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -376,11 +378,15 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * (16 + 4096)))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 6200))) return fail(rc);
     if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 6200) != hipSuccess) return fail(NCHMM_E_HIP);
+    if ((rc = dev_alloc(c, (void**)&c->d_fb_total, sizeof(unsigned long long)))) return fail(rc);
+    if (hipMemset(c->d_fb_total, 0, sizeof(unsigned long long)) != hipSuccess) return fail(NCHMM_E_HIP);
     {
         const char* e = std::getenv("NCHMM_PROFILE");
         c->profile = e && e[0] == '1';
         const char* m = std::getenv("NCHMM_TB_MARGIN");
         if (m) c->tb_margin = std::max(0, std::atoi(m));
+        const char* f = std::getenv("NCHMM_FB_FORCE_LOG");
+        c->fb_force_log = f && f[0] == '1';
     }
     if (hipEventCreate(&c->ev_vit0) != hipSuccess || hipEventCreate(&c->ev_vit1) != hipSuccess
         || hipEventCreate(&c->ev_vit2) != hipSuccess
@@ -407,7 +413,8 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_last_state) (void)hipFree(c->d_last_state);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
-    if (c->d_fb_lpd2) (void)hipFree(c->d_fb_lpd2);
+    if (c->d_fb_aux) (void)hipFree(c->d_fb_aux);
+    if (c->d_fb_total) (void)hipFree(c->d_fb_total);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
@@ -737,24 +744,32 @@ int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_e
         if (rc != NCHMM_OK) return rc;
         alpha = c->d_fb_ws;
     }
+    // the rescaled linear-space kernels cannot hand out log matrices: those calls take the log-space pair
+    const bool scaled = !d_out_alpha && !d_out_beta && !c->fb_force_log;
+    auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_lpd = 0, o_zf = o_lpd + al256(4 * n_win), o_list = o_zf + al256(4 * n_win), o_flag = o_list + al256(4 * n_win);
+    const size_t o_exp = o_flag + al256(n_win), aux_need = o_exp + al256(4 * std::max<size_t>(total_events, 1));
     {
-        void* p = c->d_fb_lpd2;
-        int rc = ensure(c, &p, &c->fb_lpd2_bytes, n_win * sizeof(float));
-        c->d_fb_lpd2 = (float*)p;
+        int rc = ensure(c, &c->d_fb_aux, &c->fb_aux_bytes, aux_need);
         if (rc != NCHMM_OK) return rc;
     }
+    char* aux = (char*)c->d_fb_aux;
     FwbwArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.scaled_slot = d_scaled_slot; a.pm_params = d_pm_params; a.trans_slot = d_trans_slot;
     a.st_params = d_st_params; a.models = c->d_models; a.trans_fb = c->d_trans_fb; a.trans = c->d_trans; a.train_mask = c->d_train_mask;
-    a.ws_alpha = alpha; a.ws_lpd2 = c->d_fb_lpd2; a.alpha_natural = d_out_alpha ? 1 : 0; a.out_log_pr_data = d_out_lpd; a.out_pm_sums = d_out_pm; a.out_st_sums = d_out_st;
+    a.ws_alpha = alpha; a.ws_lpd2 = (float*)(aux + o_lpd); a.alpha_natural = d_out_alpha ? 1 : 0;
+    a.ws_zfin = (float*)(aux + o_zf); a.fb_list = (unsigned*)(aux + o_list); a.fb_flag = (uint8_t*)(aux + o_flag);
+    a.ws_exp = (int32_t*)(aux + o_exp); a.fb_count = c->d_queue + 5; a.fb_total = c->d_fb_total; a.win_list = nullptr; a.n_list = nullptr;
+    a.out_log_pr_data = d_out_lpd; a.out_pm_sums = d_out_pm; a.out_st_sums = d_out_st;
     a.out_beta = d_out_beta; a.queue = c->d_queue + 1; a.n_win = (unsigned)n_win;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Forward_Backward.hpp:53
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     const int grid = (int)std::min<size_t>((size_t)c->fb_slots, n_win);
-    HIP_TRY(c, hipMemsetAsync(c->d_queue + 1, 0, 2 * sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue + 1, 0, 5 * sizeof(unsigned), c->stream));   // four work queues + the redo count
+    if (scaled) HIP_TRY(c, hipMemsetAsync(aux + o_flag, 0, n_win, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_fb0, c->stream));
-    launch_fwbw(a, grid, c->stream);
+    launch_fwbw(a, grid, c->stream, scaled);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_fb1, c->stream));
     c->fb_timed = true;
@@ -819,6 +834,14 @@ int nchmm_counters(const nchmm_ctx* c, uint64_t out[8])
 {
     if (!c || !out) return NCHMM_E_INVALID;
     std::memcpy(out, c->counters, sizeof(c->counters));
+    // [7] lives on the device (the kernels count the windows they hand to the log-space redo)
+    unsigned long long redo = 0;
+    if (c->d_fb_total) {
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess
+            || hipMemcpy(&redo, c->d_fb_total, sizeof(redo), hipMemcpyDeviceToHost) != hipSuccess)
+            return NCHMM_E_HIP;
+    }
+    out[7] = redo;
     return NCHMM_OK;
 }
 

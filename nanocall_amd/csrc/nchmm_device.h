@@ -70,6 +70,15 @@ struct FwbwArgs {
     float* ws_alpha;            // alpha rows, one per event of the batch (4096 floats each)
     float* ws_lpd2;             // [n_win] log2 Pr(data | window), forward kernel -> backward kernel
     int alpha_natural;          // rows are natural logs (caller's out_alpha buffer) instead of the internal base 2
+    // rescaled linear-space fast path (fwbw_scaled_kernel.hip) and its exact fallback
+    int32_t* ws_exp;            // [total events] cumulative power-of-two exponent taken out of the alpha rows up to each event
+    float* ws_zfin;             // [n_win] sum of the last (rescaled) alpha row
+    uint8_t* fb_flag;           // [n_win] window left the range the rescaled kernels vouch for -> redo in log space
+    unsigned* fb_list;          // [n_win] those windows, appended by the scaled kernels
+    unsigned* fb_count;         // [1] their number
+    unsigned long long* fb_total;   // [1] running total over the context's lifetime (nchmm_counters)
+    const unsigned* win_list;   // log-space kernels: process windows win_list[0 .. *n_list) instead of [0, n_win)
+    const unsigned* n_list;
     float* out_log_pr_data;
     float* out_pm_sums;
     float* out_st_sums;
@@ -84,7 +93,9 @@ void launch_scale_models(const float* d_states, const int32_t* d_table_idx, cons
                          int32_t* d_model_fast, int first_slot, size_t n, float log_2pi, hipStream_t stream);
 void launch_expand_transitions(const float* d_wm, const uint8_t* d_masks, float* d_trans, float* d_trans_fb, int first_slot,
                                size_t n, hipStream_t stream);
-void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream);
+void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream, bool scaled);
+void launch_fwbw_scaled(const FwbwArgs& a, int grid, hipStream_t stream);
+int fwbw_scaled_blocks_per_cu();
 int fwbw_blocks_per_cu();
 
 }  // namespace nchmm

@@ -327,10 +327,13 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     unsigned done_events = 0;
 
     for (;;) {
+        // barrier first, then thread 0's fetch: it ends the previous read and keeps that read's closing
+        // `if (tau == 0)` apart from this one (back to back across the loop edge LLVM may thread the two tests
+        // together and send every other lane straight to the barrier below -- see fwbw_scaled_kernel.hip)
+        __syncthreads();
         if (tau == 0) sWork = atomicAdd(P.queue, 1u);
         __syncthreads();
         const unsigned widx = sWork;
-        __syncthreads();
         if (widx >= P.n_reads) break;
         const unsigned r = __builtin_amdgcn_readfirstlane(P.order ? P.order[widx] : P.first_read + widx);
         const uint64_t e0 = P.off[r];

@@ -139,3 +139,77 @@ def test_em_round0_against_float64_truth(gpu_ctx):
     # and the fp32 oracle is no closer: this is the noise floor the oracle-vs-GPU tolerances above allow for
     o_err = np.abs(z["rounds"][0][1:7] - t) / den
     assert o_err[3] > err[3] and o_err[5] > err[5], (o_err, err)
+
+
+def _em_window_batch(n_reads=6, n_ev=100, outlier=None):
+    """n_reads x 4 training windows (template, template, complement, complement) of synthetic events."""
+    t0, t1 = na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")
+    e0 = synth.generate(t0, n_reads, 2 * n_ev, first_read=900)
+    e1 = synth.generate(t1, n_reads, 2 * n_ev, first_read=10**6 + 900)
+    pick = lambda k: np.stack([e0[k][:, :n_ev], e0[k][:, n_ev:], e1[k][:, :n_ev], e1[k][:, n_ev:]], 1).reshape(-1)
+    mean, stdv = pick("mean").copy(), pick("stdv")
+    if outlier is not None:
+        mean[outlier] = 135.0          # ~20 sigma above the highest level: every state's emission is below 2^-64 of its bound
+    cm, sd, ls = na.events_prepare(mean, stdv, None, 0.0)
+    n_win = 4 * n_reads
+    off = (np.arange(n_win + 1) * n_ev).astype(np.uint64)
+    strand = np.tile(np.array([0, 0, 1, 1], np.int32), n_reads)
+    return (t0, t1), off, cm, sd, ls, strand
+
+
+def _run_em_batch(ctx, tabs, off, cm, sd, ls, strand, params):
+    for s, t in enumerate(tabs):
+        ctx.put_model(20 + s, na.scaled_model_table(t, params))
+    ctx.put_transitions(20, *na.transitions_fast(0.3, 0.1))
+    n_win = len(strand)
+    return ctx.fwbw(off, cm, sd, ls, scaled_slot=20 + strand, pm_params=params, trans_slot=np.full(n_win, 20),
+                    st_params=np.tile(np.float32([0.1, 0.3]), (n_win, 1)))
+
+
+def test_scaled_and_log_space_kernels_agree(gpu_ctx, monkeypatch):
+    """The EM rounds run the rescaled linear-space kernels (fwbw_scaled_kernel.hip); NCHMM_FB_FORCE_LOG=1 keeps a
+    context on the log-space pair.  Same windows through both: log-likelihoods to 1e-5, every per-event sum and
+    per-window transition sum to 3e-4 (the log-space kernel carries ~3e-5 per posterior from its fp32 exponents),
+    and no window of this ordinary batch may need the log-space redo."""
+    params = (1.01, 0.4, 0.0, 1.03, 0.97, 1.2)
+    tabs, off, cm, sd, ls, strand = _em_window_batch()
+    before = int(gpu_ctx.counters()[7])
+    fast = _run_em_batch(gpu_ctx, tabs, off, cm, sd, ls, strand, params)
+    assert int(gpu_ctx.counters()[7]) == before
+    monkeypatch.setenv("NCHMM_FB_FORCE_LOG", "1")
+    ref_ctx = na.Context(0)
+    try:
+        ref = _run_em_batch(ref_ctx, tabs, off, cm, sd, ls, strand, params)
+    finally:
+        ref_ctx.close()
+    assert rel(fast["log_pr_data"], ref["log_pr_data"]).max() <= 1e-5
+    assert rel(fast["pm_sums"], ref["pm_sums"], floor=1e-3).max() <= 3e-4
+    assert rel(np.exp(fast["st_sums"]), np.exp(ref["st_sums"]), floor=1e-6).max() <= 3e-4
+
+
+def test_outlier_window_is_redone_in_log_space(gpu_ctx):
+    """One event that no state explains (135 pA) takes the column total below the range the rescaled kernels vouch
+    for (it is still far inside fp32 LOG range: the column costs ~200 nats).  The scaled kernels
+    must notice, hand exactly that window to the log-space kernels, and the result must still be the oracle's
+    (which, like the reference, works in log space throughout)."""
+    params = (1.0, 0.0, 0.0, 1.0, 1.0, 1.0)
+    tabs, off, cm, sd, ls, strand = _em_window_batch(n_reads=2, outlier=3 * 100 + 57)      # window 3, event 57
+    before = int(gpu_ctx.counters()[7])
+    out = _run_em_batch(gpu_ctx, tabs, off, cm, sd, ls, strand, params)
+    assert int(gpu_ctx.counters()[7]) == before + 1
+    om = [oracle.Model(t, params) for t in tabs]
+    ot = oracle.Transitions(0.3, 0.1)
+    for w in (2, 3, 4):
+        a, b = int(off[w]), int(off[w + 1])
+        lpd, al, be = oracle.fwbw(om[strand[w]], ot, cm[a:b], sd[a:b], ls[a:b])
+        assert rel(out["log_pr_data"][w], lpd).max() <= 1e-4, w
+        p = np.exp(al.astype(np.float64) + be - lpd)
+        m = na.scaled_model_table(tabs[strand[w]], params).astype(np.float64)
+        s0 = p @ (1.0 / m[:, 1] ** 2)
+        l0 = p @ m[:, 4]
+        # the outlier puts the log-space values of window 3 near 1e3, where one fp32 ulp is already 1e-4 in a
+        # posterior: oracle and GPU (both fp32 log space there) cannot agree tighter than a few of those
+        tol = 2e-3 if w == 3 else 2e-4
+        assert rel(out["pm_sums"][a:b, 0], s0, floor=1e-6).max() <= tol, w
+        assert rel(out["pm_sums"][a:b, 3], l0, floor=1e-6).max() <= tol, w
+    assert np.isfinite(out["st_sums"]).all() and np.isfinite(out["pm_sums"]).all()
