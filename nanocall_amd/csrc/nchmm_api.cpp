@@ -210,18 +210,6 @@ inline void model_image_row(float* img, int j, float level_mean, float level_std
         *fast = 0;
 }
 
-template <typename F>
-void parallel_for(size_t n, F&& f)
-{
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt ? std::min<unsigned>(nt, 32) : 4;
-    if (n < 4 || nt < 2) { f(0, n); return; }
-    nt = (unsigned)std::min<size_t>(nt, n);
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nt; ++i) th.emplace_back([&, i] { f(n * i / nt, n * (i + 1) / nt); });
-    for (auto& t : th) t.join();
-}
-
 // w0 | w1 | w2 of compute_transitions_fast(p_skip, p_stay).  get_trans_prob is a function of the 6-bit
 // overlap mask of (i, j) only, so one representative arc per class gives the class's mask, and the
 // weight is evaluated once per distinct mask (18 of them) instead of once per arc.

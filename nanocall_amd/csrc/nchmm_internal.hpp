@@ -3,11 +3,28 @@
 #ifndef NCHMM_INTERNAL_HPP
 #define NCHMM_INTERNAL_HPP
 
+#include <algorithm>
 #include <cmath>
+#include <thread>
+#include <vector>
 
 #include "nchmm_kmer.hpp"
 
 namespace nchmm {
+
+// f(begin, end) over [0, n) on the host cores (the work items are independent)
+template <typename F>
+void parallel_for(size_t n, F&& f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min<unsigned>(nt, 32) : 4;
+    if (n < 4 || nt < 2) { f(0, n); return; }
+    nt = (unsigned)std::min<size_t>(nt, n);
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; ++i) th.emplace_back([&, i] { f(n * i / nt, n * (i + 1) / nt); });
+    for (auto& t : th) t.join();
+}
+
 
 // State_Transitions::get_trans_prob, State_Transitions.hpp:125-144: float accumulator, double pow terms
 inline float trans_prob(unsigned i, unsigned j, float p_stay, float p_step, float p_skip_1)

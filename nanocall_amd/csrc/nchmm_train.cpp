@@ -8,12 +8,20 @@
 // scale_strands_together mode -- one iteration of the reference's `for m_name...` loops.
 // Pure host C++ over the C ABI (no HIP here).
 #include "nanocall_hip.h"
+#include "nchmm_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <vector>
+
+using nchmm::parallel_for;
 
 namespace {
 
@@ -91,9 +99,17 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         return NCHMM_E_INVALID;
     const float NEG_INF = -std::numeric_limits<float>::infinity();
     const uint64_t total_events = strand_off[2 * n_reads];
-    // Event::update_logs happened at load time in the reference; the log of stdv is what the emission needs
-    std::vector<float> log_stdv(total_events);
-    for (uint64_t e = 0; e < total_events; ++e) log_stdv[e] = std::log(stdv[e]);
+    // Event::update_logs happened at load time in the reference; the log of stdv is what the emission needs.  Only the
+    // training windows (first and last scaling_num_events / 2 events of a strand, nanocall.cpp:333-337) are ever read.
+    std::unique_ptr<float[]> log_stdv(new float[std::max<uint64_t>(total_events, 1)]);
+    parallel_for(2 * n_reads, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) {
+            const uint64_t b = strand_off[k], e = strand_off[k + 1];
+            const uint64_t half = std::min<uint64_t>(o->scaling_num_events, e - b) / 2;
+            for (uint64_t i = b; i < b + half; ++i) log_stdv[i] = std::log(stdv[i]);
+            for (uint64_t i = e - half; i < e; ++i) log_stdv[i] = std::log(stdv[i]);
+        }
+    });
 
     std::vector<Job> jobs(n_jobs);
     for (size_t k = 0; k < n_jobs; ++k) {
@@ -120,70 +136,80 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         if (j.win.empty()) j.active = false;
     }
 
-    // unscaled models: slots [0, n_models) (identity scaling reproduces the loaded table bit for bit)
+    // model slots [0, n_models) stay free (the statistics are taken from the scaled states + pm_params); transition slot 0
+    // holds the default weights
     int rc;
-    {
-        std::vector<int32_t> idx(n_models);
-        std::vector<float> ident(6 * n_models);
-        for (size_t a = 0; a < n_models; ++a) {
-            idx[a] = (int32_t)a;
-            const float id[6] = {1, 0, 0, 1, 1, 1};
-            std::memcpy(&ident[6 * a], id, sizeof(id));
-        }
-        if ((rc = nchmm_put_models_scaled(ctx, 0, n_models, model_states_Sx10, idx.data(), ident.data()))) return rc;
-        if ((rc = nchmm_put_transitions_fast(ctx, 0, 1, &o->default_p_skip, &o->default_p_stay))) return rc;
-    }
+    if ((rc = nchmm_put_transitions_fast(ctx, 0, 1, &o->default_p_skip, &o->default_p_stay))) return rc;
 
+    const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::vector<size_t> act;
     for (;;) {
+        const auto t_0 = now();
         act.clear();
         for (size_t k = 0; k < n_jobs; ++k) if (jobs[k].active) act.push_back(k);
         if (act.empty()) break;
         const size_t na = act.size();
         // ---- Parameter_Trainer::fill_train_data (Parameter_Trainer.hpp:99-155), all active jobs at once ----
-        std::vector<int32_t> m_idx; std::vector<float> m_par;         // scaled models: slot n_models + 2p + s
+        std::vector<int32_t> m_idx(2 * na, 0); std::vector<float> m_par(12 * na, 0.f);   // scaled models: slot n_models + 2p + s
         std::vector<float> t_skip(2 * na, o->default_p_skip), t_stay(2 * na, o->default_p_stay);
-        std::vector<uint64_t> off{0};
-        std::vector<float> cm, sd, ls, raw_mean, raw_start, stp;
-        std::vector<int32_t> s_slot, t_slot;
-        std::vector<float> w_pm;                                      // per window: the parameters behind its scaled model
-        std::vector<size_t> first_win(na + 1, 0);
-        m_idx.assign(2 * na, 0); m_par.assign(12 * na, 0.f);
+        // where each job's windows and events go (prefix sums), then every job fills its own slice
+        std::vector<size_t> first_win(na + 1, 0), first_ev(na + 1, 0);
         for (size_t p = 0; p < na; ++p) {
-            Job& j = jobs[act[p]];
-            std::memcpy(j.old_pm, j.pm, sizeof(j.pm)); std::memcpy(j.old_st, j.st, sizeof(j.st)); j.old_fit = j.fit;
-            for (int s = 0; s < 2; ++s) {
-                m_idx[2 * p + s] = j.m[s] >= 0 ? j.m[s] : std::max(j.m[0], j.m[1]);
-                std::memcpy(&m_par[6 * (2 * p + s)], j.old_pm, sizeof(j.old_pm));
-                t_stay[2 * p + s] = j.old_st[2 * s]; t_skip[2 * p + s] = j.old_st[2 * s + 1];
-            }
-            for (const Window& w : j.win) {
-                for (uint32_t i = 0; i < w.len; ++i) {
-                    const uint64_t e = w.begin + i;
-                    float c = mean[e];
-                    c -= j.old_pm[2] * start[e];   // apply_drift_correction, Event.hpp:77-84
-                    cm.push_back(c); sd.push_back(stdv[e]); ls.push_back(log_stdv[e]);
-                    raw_mean.push_back(mean[e]); raw_start.push_back(start[e]);
-                }
-                off.push_back(cm.size());
-                s_slot.push_back((int32_t)(n_models + 2 * p + w.strand));
-                w_pm.insert(w_pm.end(), j.old_pm, j.old_pm + 6);
-                // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
-                const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
-                t_slot.push_back(dflt ? 0 : (int32_t)(1 + 2 * p + w.strand));
-                stp.push_back(j.old_st[2 * w.strand]); stp.push_back(j.old_st[2 * w.strand + 1]);
-            }
-            first_win[p + 1] = s_slot.size();
+            const Job& j = jobs[act[p]];
+            size_t ev = 0;
+            for (const Window& w : j.win) ev += w.len;
+            first_win[p + 1] = first_win[p] + j.win.size();
+            first_ev[p + 1] = first_ev[p] + ev;
         }
+        const size_t n_win = first_win[na], tot = first_ev[na];
+        std::vector<uint64_t> off(n_win + 1, 0);
+        std::vector<float> cm(tot), sd(tot), ls(tot), raw_mean(tot), raw_start(tot), stp(2 * n_win);
+        std::vector<int32_t> s_slot(n_win), t_slot(n_win);
+        std::vector<float> w_pm(6 * n_win);                           // per window: the parameters behind its scaled model
+        parallel_for(na, [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; ++p) {
+                Job& j = jobs[act[p]];
+                std::memcpy(j.old_pm, j.pm, sizeof(j.pm)); std::memcpy(j.old_st, j.st, sizeof(j.st)); j.old_fit = j.fit;
+                for (int s = 0; s < 2; ++s) {
+                    m_idx[2 * p + s] = j.m[s] >= 0 ? j.m[s] : std::max(j.m[0], j.m[1]);
+                    std::memcpy(&m_par[6 * (2 * p + s)], j.old_pm, sizeof(j.old_pm));
+                    t_stay[2 * p + s] = j.old_st[2 * s]; t_skip[2 * p + s] = j.old_st[2 * s + 1];
+                }
+                size_t wi = first_win[p], k = first_ev[p];
+                for (const Window& w : j.win) {
+                    for (uint32_t i = 0; i < w.len; ++i, ++k) {
+                        const uint64_t e = w.begin + i;
+                        float c = mean[e];
+                        c -= j.old_pm[2] * start[e];   // apply_drift_correction, Event.hpp:77-84
+                        cm[k] = c; sd[k] = stdv[e]; ls[k] = log_stdv[e];
+                        raw_mean[k] = mean[e]; raw_start[k] = start[e];
+                    }
+                    off[wi + 1] = k;
+                    s_slot[wi] = (int32_t)(n_models + 2 * p + w.strand);
+                    std::memcpy(&w_pm[6 * wi], j.old_pm, sizeof(j.old_pm));
+                    // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
+                    const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
+                    t_slot[wi] = dflt ? 0 : (int32_t)(1 + 2 * p + w.strand);
+                    stp[2 * wi] = j.old_st[2 * w.strand]; stp[2 * wi + 1] = j.old_st[2 * w.strand + 1];
+                    ++wi;
+                }
+            }
+        });
+        const auto t_1 = now();
         if ((rc = nchmm_put_models_scaled(ctx, (int)n_models, 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
         if ((rc = nchmm_put_transitions_fast(ctx, 1, 2 * na, t_skip.data(), t_stay.data()))) return rc;
-        const size_t n_win = s_slot.size(), tot = cm.size();
+        const auto t_2 = now();
         std::vector<float> lpd(n_win), pm_sums(6 * tot), st_sums(3 * n_win);
         rc = nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), w_pm.data(), t_slot.data(),
                         stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr);
         if (rc != NCHMM_OK) return rc;
+        const auto t_3 = now();
         // ---- finish the round per job (Parameter_Trainer.hpp:557-578) and apply the stop rules ----
-        for (size_t p = 0; p < na; ++p) {
+        std::atomic<int> first_err{NCHMM_OK};
+        parallel_for(na, [&](size_t p_lo, size_t p_hi) {
+        for (size_t p = p_lo; p < p_hi; ++p) {
             Job& j = jobs[act[p]];
             const size_t w0 = first_win[p], w1 = first_win[p + 1];
             float fit = 0;
@@ -193,9 +219,9 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             if (o->train_scaling) {
                 const size_t e0 = off[w0], e1 = off[w1];
                 int d = 0;
-                rc = nchmm_train_pm_finish(e1 - e0, &pm_sums[6 * e0], &raw_mean[e0], &sd[e0], &raw_start[e0], o->train_drift,
+                const int rc = nchmm_train_pm_finish(e1 - e0, &pm_sums[6 * e0], &raw_mean[e0], &sd[e0], &raw_start[e0], o->train_drift,
                                            j.old_pm, j.pm, &d);
-                if (rc != NCHMM_OK) return rc;
+                if (rc != NCHMM_OK) { first_err = rc; return; }
                 done = d != 0;
             }
             if (done) {
@@ -206,8 +232,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
                     std::vector<float> mine;
                     for (size_t w = w0; w < w1; ++w)
                         if (j.win[w - w0].strand == (uint32_t)s) mine.insert(mine.end(), &st_sums[3 * w], &st_sums[3 * w] + 3);
-                    rc = nchmm_train_st_finish(mine.size() / 3, mine.data(), &j.st[2 * s], &j.st[2 * s + 1]);
-                    if (rc != NCHMM_OK) return rc;
+                    const int rc = nchmm_train_st_finish(mine.size() / 3, mine.data(), &j.st[2 * s], &j.st[2 * s + 1]);
+                    if (rc != NCHMM_OK) { first_err = rc; return; }
                 }
             }
             // nanocall.cpp:394-426 (2D) / :510-542 (1D)
@@ -222,6 +248,11 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             const unsigned limit = two_d ? 2u * o->scaling_max_rounds : o->scaling_max_rounds;
             if (j.round >= limit || (j.round > 1 && j.fit < j.old_fit + o->scaling_min_progress)) j.active = false;
         }
+        });
+        if (first_err != NCHMM_OK) return first_err;
+        if (dbg_time)
+            std::fprintf(stderr, "[nchmm_train_reads] round: %zu jobs, gather %.2f ms, tables %.2f ms, fwbw %.2f ms, finish %.2f ms\n", na,
+                         ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3), ms(t_3, now()));
     }
     for (size_t k = 0; k < n_jobs; ++k) {
         std::memcpy(job_pm + 6 * k, jobs[k].pm, sizeof(jobs[k].pm));
@@ -267,14 +298,10 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
     if (!ctx || !o || !model_states_Sx10 || !strand_off || !mean || !stdv || !start || !job_read || !job_m0 || !job_m1
         || !job_pm || !job_st || !out_state || !out_best_job || !out_best_logp)
         return NCHMM_E_INVALID;
-    const uint64_t total_events = strand_off[2 * n_reads];
-    std::vector<float> log_stdv(total_events);
-    for (uint64_t e = 0; e < total_events; ++e) log_stdv[e] = std::log(stdv[e]);
     // candidate list (nanocall.cpp:696-709 / :790-806): the preferred job if one was selected, else every job
     struct Cand { size_t job; int strand; size_t vread; };
     std::vector<Cand> cands;
     std::vector<uint64_t> off{0};
-    std::vector<float> cm, sd, ls;
     std::vector<int32_t> m_idx, slot_m, slot_t;
     std::vector<float> m_par, t_skip, t_stay;
     for (size_t k = 0; k < n_jobs; ++k) {
@@ -288,13 +315,7 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
             if (m[s] >= (int)n_models) return NCHMM_E_INVALID;
             const uint64_t b = strand_off[2 * r + s], e = strand_off[2 * r + s + 1];
             if (e - b < o->min_ed_events) continue;
-            const float drift = job_pm[6 * k + 2];
-            for (uint64_t i = b; i < e; ++i) {
-                float c = mean[i];
-                c -= drift * start[i];   // corrected_events.apply_drift_correction(pm_params.drift), nanocall.cpp:685-686
-                cm.push_back(c); sd.push_back(stdv[i]); ls.push_back(log_stdv[i]);
-            }
-            off.push_back(cm.size());
+            off.push_back(off.back() + (e - b));
             const size_t v = cands.size();
             cands.push_back(Cand{k, s, v});
             m_idx.push_back(m[s]);
@@ -305,17 +326,40 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
             slot_t.push_back((int32_t)v);
         }
     }
+    // every candidate's events, drift-corrected with ITS parameters; the candidates fill their slices in parallel
+    // (Event::update_logs happened at load time in the reference: log_stdv = log(stdv), float libm)
+    const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    const size_t tot = (size_t)off.back();
+    std::unique_ptr<float[]> cm_b(new float[tot + 1]), sd_b(new float[tot + 1]), ls_b(new float[tot + 1]);   // (no zero fill)
+    float* const cm = cm_b.get(); float* const sd = sd_b.get(); float* const ls = ls_b.get();
+    parallel_for(cands.size(), [&](size_t lo, size_t hi) {
+        for (size_t v = lo; v < hi; ++v) {
+            const size_t k = cands[v].job;
+            const int r = job_read[k];
+            const uint64_t b = strand_off[2 * r + cands[v].strand], e = strand_off[2 * r + cands[v].strand + 1];
+            const float drift = job_pm[6 * k + 2];
+            uint64_t d = off[v];
+            for (uint64_t i = b; i < e; ++i, ++d) {
+                float c = mean[i];
+                c -= drift * start[i];   // corrected_events.apply_drift_correction(pm_params.drift), nanocall.cpp:685-686
+                cm[d] = c; sd[d] = stdv[i]; ls[d] = std::log(stdv[i]);
+            }
+        }
+    });
     for (size_t i = 0; i < 2 * n_reads; ++i) { out_best_job[i] = -1; out_best_logp[i] = std::numeric_limits<float>::quiet_NaN(); }
     if (cands.empty()) return NCHMM_OK;
     int rc;
     if ((rc = nchmm_put_models_scaled(ctx, 0, cands.size(), model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
     if ((rc = nchmm_put_transitions_fast(ctx, 0, cands.size(), t_skip.data(), t_stay.data()))) return rc;
-    std::vector<uint16_t> states(cm.size());
+    std::unique_ptr<uint16_t[]> states_b(new uint16_t[tot + 1]);
+    uint16_t* const states = states_b.get();
     std::vector<float> logp(cands.size());
     std::vector<int32_t> status(cands.size());
-    rc = nchmm_viterbi(ctx, cands.size(), off.data(), cm.data(), sd.data(), ls.data(), slot_m.data(), slot_t.data(), states.data(),
-                       logp.data(), status.data());
+    const auto t_1 = std::chrono::steady_clock::now();
+    rc = nchmm_viterbi(ctx, cands.size(), off.data(), cm, sd, ls, slot_m.data(), slot_t.data(), states, logp.data(), status.data());
     if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) return rc;
+    const auto t_2 = std::chrono::steady_clock::now();
     // choose per read: 2D jobs by the float sum of both strands (:725-739), 1D jobs per strand (:807-825);
     // `sort ... back()` = the highest value, the later candidate among exact ties
     std::vector<float> best_total(2 * n_reads, -std::numeric_limits<float>::infinity());
@@ -341,13 +385,20 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
         const Cand& c = cands[(size_t)v];
         const int r = job_read[c.job];
         const uint64_t b = strand_off[2 * r + c.strand], n = strand_off[2 * r + c.strand + 1] - b;
-        if (status[(size_t)v] == 0) std::memcpy(out_state + b, states.data() + off[(size_t)v], n * sizeof(uint16_t));
+        if (status[(size_t)v] == 0) std::memcpy(out_state + b, states + off[(size_t)v], n * sizeof(uint16_t));
         out_best_job[2 * r + c.strand] = (int32_t)c.job;
         out_best_logp[2 * r + c.strand] = logp[(size_t)v];
     };
-    for (size_t i = 0; i < 2 * n_reads; ++i) {
-        if (best_c0[i] >= 0) emit(best_c0[i]);
-        if (best_c1[i] >= 0) emit(best_c1[i]);
+    parallel_for(n_reads, [&](size_t lo, size_t hi) {     // (per read, in the serial order: its slices belong to no other read)
+        for (size_t i = 2 * lo; i < 2 * hi; ++i) {
+            if (best_c0[i] >= 0) emit(best_c0[i]);
+            if (best_c1[i] >= 0) emit(best_c1[i]);
+        }
+    });
+    if (dbg_time) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[nchmm_basecall_reads] %zu candidates, %zu events: gather+tables %.2f ms, viterbi %.2f ms, choose+copy %.2f ms\n",
+                     cands.size(), tot, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, std::chrono::steady_clock::now()));
     }
     return rc;
 }

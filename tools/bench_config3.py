@@ -69,3 +69,11 @@ print(json.dumps({"viterbi_wall_s_second_call": round(time.perf_counter() - t3, 
 t4 = time.perf_counter()
 out2 = ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
 print(json.dumps({"em_wall_s_second_call": round(time.perf_counter() - t4, 3)}))
+# the drop-in decode stage: nchmm_basecall_reads (candidate gather + tables + Viterbi + best-model choice, host pointers)
+for label in ("basecall_reads_wall_s", "basecall_reads_wall_s_second_call"):
+    t5 = time.perf_counter()
+    bc = ctx.basecall_reads(opts, states, so, mean, stdv, start, jr, j0, j1, out["pm"], out["st"])
+    dt = time.perf_counter() - t5
+    print(json.dumps({label: round(dt, 3), "Mevents_per_s_incl_host": round(2 * nj * n_ev / dt / 1e6, 2),
+                      "kernel_ms": ctx.last_kernel_ms(), "reads_with_a_winner": int((bc["best_job"][:, 0] >= 0).sum())}))
+
