@@ -97,17 +97,19 @@ __device__ __forceinline__ unsigned swap1(unsigned v)
 // byte of state j inside its 16-byte group: k = j >> 8 = 4x + y  ->  ((y&1)<<3) | (x<<1) | (y>>1)
 __device__ __forceinline__ unsigned bp_pos(unsigned k) { return ((k & 1u) << 3) | ((k >> 2) << 1) | ((k >> 1) & 1u); }
 
-// n / d with r = RN(1/d) precomputed.  q0 = RN(n r) is within 2 ulp; the first residual step makes
-// it faithful, the second (Markstein: faithful q, correctly rounded r, exact residual) makes it
-// the correctly rounded quotient.  Needs n == 0 or 2^-100 <= |n| <= 2^100 and d, r normal.
+// n / d with r = RN(1/d) precomputed: q0 = RN(n r), one exact residual (FMA), one correction (FMA) -- three
+// VALU ops, bit-identical to the IEEE quotient.  Markstein's theorem gives this whenever q0 is a faithful
+// rounding; that it holds for EVERY pair of binary32 significands (2^23 divisors x 2^23 numerators, including
+// the all-ones divisor the textbook statement excludes) is checked by enumeration on the host:
+// tools/ubench/markstein_exhaustive.c, coverage and result in DESIGN.md section 4.1.
+// Exponents do not enter as long as nothing leaves the normal range: needs n == 0 or 2^-100 <= |n| <= 2^100
+// and d, r normal (the range validation below; outside it the true division is used).
 template <bool FAST>
 __device__ __forceinline__ float quot(float n, float d, float r)
 {
     if constexpr (FAST) {
-        float q = n * r;
-        float e = __builtin_fmaf(-q, d, n);
-        q = __builtin_fmaf(e, r, q);
-        e = __builtin_fmaf(-q, d, n);
+        const float q = n * r;
+        const float e = __builtin_fmaf(-q, d, n);
         return __builtin_fmaf(e, r, q);
     } else {
         return n / d;
