@@ -213,3 +213,63 @@ def test_outlier_window_is_redone_in_log_space(gpu_ctx):
         assert rel(out["pm_sums"][a:b, 0], s0, floor=1e-6).max() <= tol, w
         assert rel(out["pm_sums"][a:b, 3], l0, floor=1e-6).max() <= tol, w
     assert np.isfinite(out["st_sums"]).all() and np.isfinite(out["pm_sums"]).all()
+
+
+def test_scaled_kernels_on_ragged_and_empty_windows(gpu_ctx, r73t, monkeypatch):
+    """Window lengths 0, 1, 2, 3 ... 400 through the rescaled kernels (no matrices requested) against the log-space
+    pair and, for the log-likelihood, the oracle: an empty window gives NaN / -inf sums as the log-space kernels do,
+    a one-event window has no backward recursion at all, 400 events crosses several 128-event staging chunks."""
+    params = (0.98, 1.1, 0.0, 0.95, 1.04, 0.8)
+    lens = [5, 0, 1, 2, 3, 129, 400, 0, 257, 64]
+    ev = synth.generate(r73t, len(lens), max(lens), first_read=4242)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    cat = lambda k: np.concatenate([ev[k][r, :n] for r, n in enumerate(lens)])
+    cm, sd, ls = na.events_prepare(cat("mean"), cat("stdv"), cat("start"), 0.0)
+    n = len(lens)
+
+    def run(ctx):
+        ctx.put_model(30, na.scaled_model_table(r73t, params))
+        ctx.put_transitions(30, *na.transitions_fast(0.28, 0.11))
+        return ctx.fwbw(off, cm, sd, ls, scaled_slot=np.full(n, 30), pm_params=params, trans_slot=np.full(n, 30),
+                        st_params=np.tile(np.float32([0.11, 0.28]), (n, 1)))
+
+    before = int(gpu_ctx.counters()[7])
+    fast = run(gpu_ctx)
+    assert int(gpu_ctx.counters()[7]) == before
+    monkeypatch.setenv("NCHMM_FB_FORCE_LOG", "1")
+    ref_ctx = na.Context(0)
+    try:
+        ref = run(ref_ctx)
+    finally:
+        ref_ctx.close()
+    om, ot = oracle.Model(r73t, params), oracle.Transitions(0.28, 0.11)
+    for w, ln in enumerate(lens):
+        a, b = int(off[w]), int(off[w + 1])
+        if ln == 0:
+            assert np.isnan(fast["log_pr_data"][w]) and np.isnan(ref["log_pr_data"][w])
+            assert np.all(np.isneginf(fast["st_sums"][w])) and np.all(np.isneginf(ref["st_sums"][w]))
+            continue
+        lpd, _, _ = oracle.fwbw(om, ot, cm[a:b], sd[a:b], ls[a:b], want_matrices=False)
+        assert rel(fast["log_pr_data"][w], lpd).max() <= 1e-5, (w, ln)
+        if ln <= 129:
+            assert rel(fast["pm_sums"][a:b], ref["pm_sums"][a:b], floor=1e-3).max() <= 3e-4, (w, ln)
+        else:
+            # long windows: log-space values reach ~2e3 in base 2, one fp32 ulp of which is 1e-4 in a posterior, so the
+            # log-space kernels (like the fp32 reference) drift to ~1e-3 there.  The rescaled kernels do not: hold
+            # them to the float64 evaluation instead, and the log-space pair only loosely.
+            import fb_truth
+            t6 = na.scaled_model_table(r73t, params)
+            _, al64, be64 = fb_truth.fwbw64(t6, *na.transitions_fast(0.28, 0.11), cm[a:b], sd[a:b])
+            p64 = np.exp(al64 + be64 - fb_truth.lse(al64[-1], 0))
+            u = na.scaled_model_table(r73t).astype(np.float64)          # the unscaled model the sums are taken over
+            s0 = p64 @ (1.0 / u[:, 1] ** 2)
+            l2 = p64 @ (u[:, 4] / u[:, 3] ** 2)
+            assert rel(fast["pm_sums"][a:b, 0], s0, floor=1e-3).max() <= 1e-4, (w, ln)
+            assert rel(fast["pm_sums"][a:b, 5], l2, floor=1e-3).max() <= 1e-4, (w, ln)
+            assert rel(ref["pm_sums"][a:b, 0], s0, floor=1e-3).max() <= 5e-3, (w, ln)
+        if ln >= 2:      # a one-event window has no (i, i+1) pair: both give log(0)
+            assert rel(np.exp(fast["st_sums"][w]), np.exp(ref["st_sums"][w]), floor=1e-6).max() <= (3e-4 if ln <= 129 else 3e-3), (w, ln)
+        else:
+            assert np.all(np.isneginf(fast["st_sums"][w])) and np.all(np.isneginf(ref["st_sums"][w]))
+    # each event's posterior sums to one: s0 / (2 ln2 var^2) ... checked through l2 = sum p lambda_u / eta_u^2 > 0
+    assert np.isfinite(fast["pm_sums"]).all() and (fast["pm_sums"][:, [0, 2, 3, 4, 5]] > 0).all()
