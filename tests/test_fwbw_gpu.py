@@ -273,3 +273,34 @@ def test_scaled_kernels_on_ragged_and_empty_windows(gpu_ctx, r73t, monkeypatch):
             assert np.all(np.isneginf(fast["st_sums"][w])) and np.all(np.isneginf(ref["st_sums"][w]))
     # each event's posterior sums to one: s0 / (2 ln2 var^2) ... checked through l2 = sum p lambda_u / eta_u^2 > 0
     assert np.isfinite(fast["pm_sums"]).all() and (fast["pm_sums"][:, [0, 2, 3, 4, 5]] > 0).all()
+
+
+def test_several_flagged_windows_in_a_larger_batch(gpu_ctx, monkeypatch):
+    """Outliers in the first window, the last window, at event 0 and at the last event of a window: exactly those
+    windows go through the log-space redo, every window (flagged or not) agrees with the all-log-space context."""
+    params = (1.0, 0.0, 0.0, 1.0, 1.0, 1.0)
+    n_reads, n_ev = 16, 100
+    n_win = 4 * n_reads
+    hits = {0: 0, 7: 99, 20: 50, n_win - 1: 99, n_win - 2: 0}          # window -> event index of its outlier
+    tabs, off, cm, sd, ls, strand = _em_window_batch(n_reads=n_reads, n_ev=n_ev)
+    cm = cm.copy()
+    for w, e in hits.items():
+        cm[w * n_ev + e] = 140.0
+    before = int(gpu_ctx.counters()[7])
+    fast = _run_em_batch(gpu_ctx, tabs, off, cm, sd, ls, strand, params)
+    assert int(gpu_ctx.counters()[7]) == before + len(hits)
+    monkeypatch.setenv("NCHMM_FB_FORCE_LOG", "1")
+    ref_ctx = na.Context(0)
+    try:
+        ref = _run_em_batch(ref_ctx, tabs, off, cm, sd, ls, strand, params)
+    finally:
+        ref_ctx.close()
+    assert rel(fast["log_pr_data"], ref["log_pr_data"]).max() <= 1e-5
+    flagged = np.zeros(n_win, bool)
+    flagged[list(hits)] = True
+    ev_flag = np.repeat(flagged, n_ev)
+    # redone windows ran the very same log-space kernels: identical bits
+    assert np.array_equal(fast["pm_sums"][ev_flag], ref["pm_sums"][ev_flag])
+    assert np.array_equal(fast["st_sums"][flagged], ref["st_sums"][flagged])
+    assert rel(fast["pm_sums"][~ev_flag], ref["pm_sums"][~ev_flag], floor=1e-3).max() <= 3e-4
+    assert rel(np.exp(fast["st_sums"][~flagged]), np.exp(ref["st_sums"][~flagged]), floor=1e-6).max() <= 3e-4
