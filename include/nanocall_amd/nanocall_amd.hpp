@@ -382,7 +382,13 @@ public:
 
     void fill(const Pore_Model_Type& pm, const State_Transitions_Type& st, const Event_Sequence_Type& ev, int slot = 0)
     {
-        pm.put(slot); st.put(slot);
+        st.put(slot);
+        fill_with_slot(pm, ev, slot);
+    }
+    // the transitions already sit in device slot `slot` (e.g. nchmm_put_transitions from a transitions file)
+    void fill_with_slot(const Pore_Model_Type& pm, const Event_Sequence_Type& ev, int slot)
+    {
+        pm.put(slot);
         std::vector<float> cm, sd, ls;
         detail::soa(ev, cm, sd, ls);
         const uint64_t off[2] = {0, cm.size()};

@@ -67,3 +67,36 @@ def test_run_viterbi_reports_errors_without_crashing(tool, tmp_path):
     (tmp_path / "e.tsv").write_text("60 1 0 0.01\n")
     r = subprocess.run([tool, "-p", str(tmp_path / "m.tsv"), "-e", str(tmp_path / "e.tsv")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "unexpected number of states" in r.stderr
+
+
+def test_run_fwbw_prints_the_middle_event_posteriors(tmp_path, r73t):
+    """tools/run-fwbw, the shape of the reference's run-fwbw (src/nanocall/run-fwbw.cpp:71-88): k-mers whose
+    posterior at the middle event is >= 0.1, highest first.  Against the oracle's alpha/beta: same k-mers in the
+    same order, posteriors to 1e-4, log Pr(data) to 1e-4; the -o dump holds the matrices."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "run-fwbw"], check=True, capture_output=True)
+    params = (0.97, -1.0, 0.0, 1.05, 1.02, 0.9)
+    scaled = na.model_scale(na.model_load(r73t), params)
+    with open(tmp_path / "model.tsv", "w") as f:
+        f.write("kmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+        for j in range(4096):
+            f.write(_kmer(j) + "\t" + "\t".join(f"{v:.9g}" for v in scaled[j, :4]) + "\n")
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [61], first_read=31)
+    with open(tmp_path / "events.tsv", "w") as f:
+        for m, s, t in zip(mean, stdv, start):
+            f.write(f"{m:.9g}\t{s:.9g}\t{t:.9g}\t0.01\n")
+    om, ot = oracle.Model(scaled[:, :4].copy()), oracle.Transitions(0.25, 0.15)
+    lpd, al, be = oracle.fwbw(om, ot, cm, sd, ls)
+    post = np.exp(al[30].astype(np.float64) + be[30] - lpd)
+    exp = sorted(((p, j) for j, p in enumerate(post) if p >= 0.1), reverse=True)
+    r = subprocess.run([os.path.join(ROOT, "tools", "run-fwbw"), "-p", str(tmp_path / "model.tsv"), "-e", str(tmp_path / "events.tsv"),
+                        "--pr-skip", "0.25", "--pr-stay", "0.15", "-o", str(tmp_path / "mat.tsv")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = [ln.split("\t") for ln in r.stdout.strip().splitlines()]
+    assert [g[0] for g in got] == [_kmer(j) for _, j in exp]
+    assert np.allclose([float(g[1]) for g in got], [p for p, _ in exp], rtol=1e-4)
+    assert abs(float(r.stderr.split()[-1]) - float(lpd)) <= 1e-4 * abs(float(lpd))
+    mat = np.loadtxt(tmp_path / "mat.tsv")
+    assert mat.shape == (61 * 4096, 4)
+    assert np.allclose(mat[:, 2].reshape(61, 4096), al, rtol=1e-4, atol=1e-3)
+    assert np.allclose(mat[:, 3].reshape(61, 4096), be, rtol=1e-4, atol=1e-3)

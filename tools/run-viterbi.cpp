@@ -15,6 +15,7 @@
 #include <sstream>
 
 #include "nanocall_amd/nanocall_amd.hpp"
+#include "text_formats.hpp"
 
 using namespace nanocall_amd;
 typedef Pore_Model<float, 6> Pore_Model_Type;
@@ -36,46 +37,12 @@ int main(int argc, char* argv[])
     }
     if (pm_fn.empty() || ev_fn.empty()) { std::cerr << "usage: run-viterbi -p model -e events [-s transitions | --pr-skip P --pr-stay Q]\n"; return 2; }
     try {
-        // model: rows may come in any order; '#' and header lines are skipped (Pore_Model.hpp:262-266)
-        std::vector<float> table(4096 * 4, 0.f);
-        {
-            std::ifstream is(pm_fn);
-            std::string line; unsigned n = 0;
-            while (std::getline(is, line)) {
-                std::istringstream iss(line); std::string k;
-                iss >> k;
-                if (k.empty() || k[0] == '#' || line.find("kmer") != std::string::npos) continue;
-                size_t j = Kmer<6>::to_int(k);
-                if (j >= 4096) { std::cerr << "bad kmer " << k << std::endl; return 1; }
-                iss >> table[4 * j] >> table[4 * j + 1] >> table[4 * j + 2] >> table[4 * j + 3];
-                ++n;
-            }
-            if (n != 4096) { std::cerr << "unexpected number of states" << std::endl; return 1; }
-        }
         Pore_Model_Type pm;
-        pm.load_from_vector(table);   // "scaled pore model file": used as is, like the reference tool
+        pm.load_from_vector(text_formats::read_model_table(pm_fn));   // "scaled pore model file": used as is, like the reference tool
         State_Transitions_Type st;
-        if (st_fn.empty()) {
-            st.compute_transitions_fast(pr_skip, pr_stay);
-        } else {
-            // arcs (i -> j, log p); the device layer needs from_v order: by destination, predecessors ascending
-            std::ifstream is(st_fn);
-            std::string ki, kj; float p;
-            std::vector<std::tuple<unsigned, unsigned, float>> arcs;
-            while (is >> ki >> kj >> p) arcs.emplace_back((unsigned)Kmer<6>::to_int(kj), (unsigned)Kmer<6>::to_int(ki), p);
-            std::sort(arcs.begin(), arcs.end());
-            std::vector<uint32_t> rp(4097, 0); std::vector<uint16_t> pred; std::vector<float> w;
-            for (auto& a : arcs) { rp[std::get<0>(a) + 1]++; pred.push_back((uint16_t)std::get<1>(a)); w.push_back(std::get<2>(a)); }
-            for (unsigned j = 0; j < 4096; ++j) rp[j + 1] += rp[j];
-            check(nchmm_put_transitions(Device::instance().ctx(), 1, rp.data(), pred.data(), w.data()), "nchmm_put_transitions");
-        }
-        Event_Sequence_Type ev;
-        {
-            std::ifstream is(ev_fn);
-            Event_Type e;
-            while (is >> e.mean >> e.stdv >> e.start >> e.length) { e.corrected_mean = e.mean; e.update_logs(); ev.push_back(e); }
-        }
-        if (ev.empty()) { std::cerr << "no events" << std::endl; return 1; }
+        if (st_fn.empty()) st.compute_transitions_fast(pr_skip, pr_stay);
+        else text_formats::put_transitions_file(st_fn, 1);
+        Event_Sequence_Type ev = text_formats::read_events(ev_fn);
         Viterbi_Type vit;
         if (st_fn.empty()) {
             vit.fill(pm, st, ev);
