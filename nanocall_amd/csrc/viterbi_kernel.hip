@@ -127,10 +127,21 @@ __device__ __forceinline__ float emission(float x, float y, float ry, float ly3,
                                           float rsg, float nls, float eta, float reta, float lam, float c)
 {
     const float a = quot<FAST>(x - mu, sg, rsg);
-    const float n = nls - (log_2pi + a * a) / 2.0f;
     const float b = quot<FAST>(y - eta, eta, reta);
-    const float ig = (c - ly3 - quot<FAST>(lam * b * b, y, ry)) / 2.0f;
-    return n + ig;
+    const float t = log_2pi + a * a;
+    const float u = c - ly3 - quot<FAST>(lam * b * b, y, ry);
+    if constexpr (FAST) {
+        // Halving is exact: t >= log 2pi, and u / 2 is inexact only when |u| < 2^-125 (a subnormal quotient), where
+        // the lost 2^-150 cannot move RN(n + u / 2) unless |n| is itself below 2^-100 -- two O(1) expressions
+        // cancelling to that depth at once.  So the reference's  n = nls - t / 2,  ig = u / 2,  n + ig  are these two
+        // FMAs bit for bit, two ops fewer.
+        const float n = __builtin_fmaf(-0.5f, t, nls);
+        return __builtin_fmaf(0.5f, u, n);
+    } else {
+        const float n = nls - t / 2.0f;
+        const float ig = u / 2.0f;
+        return n + ig;
+    }
 }
 
 struct State {
