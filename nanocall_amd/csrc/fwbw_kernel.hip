@@ -1,5 +1,8 @@
 // fwbw_kernel.hip -- forward-backward over the 4096-state pore HMM fused with the EM sufficient
-// statistics of one training round, gfx950.
+// statistics of one training round, gfx950: the LOG-SPACE implementation.  It is exact for every cell, however
+// improbable, as the reference is; it serves callers that want the alpha / beta matrices, the windows the
+// rescaled linear-space kernels (fwbw_scaled_kernel.hip, the path of the EM rounds) flag as out of their
+// range, and NCHMM_FB_FORCE_LOG=1.
 //
 // Replaces Forward_Backward::fill (src/nanocall/Forward_Backward.hpp:46-135) as driven by
 // Parameter_Trainer::fill_train_data (Parameter_Trainer.hpp:141-155), plus the inner state sums of
@@ -15,9 +18,10 @@
 //
 // Two kernels, one window per 512-thread block each (persistent blocks + work queue), both within
 // 128 VGPRs so that two blocks share a CU (4 waves/SIMD): fwbw_forward_kernel writes the alpha rows
-// and log_pr_data, fwbw_backward_kernel reads them back one event ahead of use.  Per-state tables
-// touched once per cell (-log sigma, log lambda - log 2pi and the stay / step coefficients) live in
-// LDS (64 KiB); the skip coefficient equals the group weight w2 and is added once by the producer.
+// and log_pr_data, fwbw_backward_kernel reads them back one event ahead of use.  The emission is regrouped
+// into five per-state constants (fwbw_common.hpp: make_state / emission2); the backward sweep keeps the
+// stay / step coefficients and the emission constant k0 in LDS (48 KiB, pair-major); the skip coefficient
+// equals the group weight w2 and is added once by the producer.
 //
 // Structure (same k-mer algebra as viterbi_kernel.hip, sums instead of maxima):
 //   forward   alpha_i[j] = e_j(i) + LSE( c0[j] + alpha[j], c1[j] + G1[j>>2], c2[j] + G2[j>>4] )
@@ -34,7 +38,8 @@
 //   (nchmm_api.cpp: fb_weights), so the kernel has no special cases.
 //   statistics, in the backward sweep: p_ij = exp(alpha + beta - log_pr_data);
 //             per event {s0,s1,s2,l0,l1,l2} = sum_j p_ij {1, mu, mu^2}/sigma^2, p_ij lambda {1, 1/eta,
-//             1/eta^2} over the UNSCALED model (Parameter_Trainer.hpp:273-296);
+//             1/eta^2} over the UNSCALED model (Parameter_Trainer.hpp:273-296), accumulated on the scaled
+//             constants and mapped back through pm_params (see the backward kernel);
 //             per window, over the "clean" k-mers (Parameter_Trainer.hpp:30-57) and events i < n-1:
 //             sum p, sum min(p_stay_joint, p), sum (p - min(p_stay_joint + p_step_joint, p))
 //             (:451-515; linear-space sums of probabilities, returned as logs).

@@ -48,7 +48,7 @@ struct nchmm_ctx {
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
     uint8_t* d_masks = nullptr;     // overlap-mask ids of the stay / step-group / skip-group arcs (5376 bytes)
-    void* d_tab_stage = nullptr;    // device staging of unscaled tables + per-slot parameters
+    void* d_tab_stage = nullptr;    // device staging of the loaded (not yet scaled) tables + per-slot parameters
     size_t tab_stage_bytes = 0;
     void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
     size_t h_pin_bytes = 0;
