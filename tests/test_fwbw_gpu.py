@@ -141,9 +141,9 @@ def test_em_round0_against_float64_truth(gpu_ctx):
     assert o_err[3] > err[3] and o_err[5] > err[5], (o_err, err)
 
 
-def _em_window_batch(n_reads=6, n_ev=100, outlier=None):
+def _em_window_batch(n_reads=6, n_ev=100, outlier=None, pore="r73"):
     """n_reads x 4 training windows (template, template, complement, complement) of synthetic events."""
-    t0, t1 = na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")
+    t0, t1 = na.builtin_model(pore + ".t"), na.builtin_model(pore + ".c.p1")
     e0 = synth.generate(t0, n_reads, 2 * n_ev, first_read=900)
     e1 = synth.generate(t1, n_reads, 2 * n_ev, first_read=10**6 + 900)
     pick = lambda k: np.stack([e0[k][:, :n_ev], e0[k][:, n_ev:], e1[k][:, :n_ev], e1[k][:, n_ev:]], 1).reshape(-1)
@@ -166,13 +166,15 @@ def _run_em_batch(ctx, tabs, off, cm, sd, ls, strand, params):
                     st_params=np.tile(np.float32([0.1, 0.3]), (n_win, 1)))
 
 
-def test_scaled_and_log_space_kernels_agree(gpu_ctx, monkeypatch):
+@pytest.mark.parametrize("pore", ["r73", "r9"])
+def test_scaled_and_log_space_kernels_agree(gpu_ctx, monkeypatch, pore):
     """The EM rounds run the rescaled linear-space kernels (fwbw_scaled_kernel.hip); NCHMM_FB_FORCE_LOG=1 keeps a
     context on the log-space pair.  Same windows through both: log-likelihoods to 1e-5, every per-event sum and
-    per-window transition sum to 3e-4 (the log-space kernel carries ~3e-5 per posterior from its fp32 exponents),
+    per-window transition sum to 5e-4 (the log-space kernel carries up to a few 1e-4 per posterior from its fp32
+    exponents: one ulp of a base-2 log near 600 is 6e-5; see the float64 comparisons below),
     and no window of this ordinary batch may need the log-space redo."""
     params = (1.01, 0.4, 0.0, 1.03, 0.97, 1.2)
-    tabs, off, cm, sd, ls, strand = _em_window_batch()
+    tabs, off, cm, sd, ls, strand = _em_window_batch(pore=pore)
     before = int(gpu_ctx.counters()[7])
     fast = _run_em_batch(gpu_ctx, tabs, off, cm, sd, ls, strand, params)
     assert int(gpu_ctx.counters()[7]) == before
@@ -183,8 +185,8 @@ def test_scaled_and_log_space_kernels_agree(gpu_ctx, monkeypatch):
     finally:
         ref_ctx.close()
     assert rel(fast["log_pr_data"], ref["log_pr_data"]).max() <= 1e-5
-    assert rel(fast["pm_sums"], ref["pm_sums"], floor=1e-3).max() <= 3e-4
-    assert rel(np.exp(fast["st_sums"]), np.exp(ref["st_sums"]), floor=1e-6).max() <= 3e-4
+    assert rel(fast["pm_sums"], ref["pm_sums"], floor=1e-3).max() <= 5e-4
+    assert rel(np.exp(fast["st_sums"]), np.exp(ref["st_sums"]), floor=1e-6).max() <= 5e-4
 
 
 def test_outlier_window_is_redone_in_log_space(gpu_ctx):
