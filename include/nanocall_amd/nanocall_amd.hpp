@@ -32,6 +32,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -307,6 +308,19 @@ inline void soa(const ES& ev, std::vector<float>& cm, std::vector<float>& sd, st
 {
     for (const auto& e : ev) { cm.push_back(e.corrected_mean); sd.push_back(e.stdv); ls.push_back(e.log_stdv); }
 }
+// f(begin, end) over [0, n) on the host cores: the AoS <-> SoA loops around a batch launch are per-strand independent
+// (the reference runs them inside its pfor workers, nanocall.cpp:611-621)
+template <typename F>
+inline void parallel_for(size_t n, F&& f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min<unsigned>(nt, 32) : 4;
+    if (n < 4 || nt < 2) { f((size_t)0, n); return; }
+    nt = (unsigned)std::min<size_t>(nt, n);
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; ++i) th.emplace_back([&, i] { f(n * i / nt, n * (i + 1) / nt); });
+    for (auto& t : th) t.join();
+}
 }  // namespace detail
 
 // ---------------------------------------------------------------------------------------------
@@ -337,24 +351,46 @@ public:
                                               const std::vector<Event_Sequence_Type*>& evs, int slot = 0)
     {
         pm.put(slot); st.put(slot);
-        std::vector<uint64_t> off{0};
-        std::vector<float> cm, sd, ls;
-        for (auto* e : evs) { detail::soa(*e, cm, sd, ls); off.push_back(cm.size()); }
-        std::vector<int32_t> slots(evs.size(), slot), status(evs.size());
-        std::vector<uint16_t> states(cm.size());
-        std::vector<Float_Type> pp(evs.size());
-        int rc = nchmm_viterbi(Device::instance().ctx(), evs.size(), off.data(), cm.data(), sd.data(), ls.data(), slots.data(),
-                               slots.data(), states.data(), pp.data(), status.data());
-        if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) check(rc, "nchmm_viterbi");
-        for (size_t r = 0; r < evs.size(); ++r) {
-            auto& ev = *evs[r];
-            if (status[r] != 0) continue;   // reference has undefined behaviour here (Viterbi.hpp:125-141); leave events untouched
-            for (size_t i = 0; i < ev.size(); ++i) {
-                ev[i].model_state_idx = states[off[r] + i];
-                ev[i].set_model_state(Kmer_Type::to_string(ev[i].model_state_idx));
-                ev[i].move = i > 0 ? (int)Kmer_Type::min_skip(ev[i - 1].model_state_idx, ev[i].model_state_idx) : 0;
-            }
+        const size_t n = evs.size();
+        std::vector<uint64_t> off(n + 1, 0);
+        for (size_t r = 0; r < n; ++r) off[r + 1] = off[r] + evs[r]->size();
+        const size_t total = (size_t)off[n];
+        // SoA staging (the three fields the emission reads), filled per strand in parallel.  The buffers live with the
+        // calling thread and only grow: no zero fill, no page-fault storm on every batch.
+        struct Staging { std::unique_ptr<float[]> cm, sd, ls; std::unique_ptr<uint16_t[]> states; size_t cap = 0; };
+        static thread_local Staging stg;
+        if (stg.cap < total + 1) {
+            stg.cap = total + 1 + total / 8;
+            stg.cm.reset(new float[stg.cap]); stg.sd.reset(new float[stg.cap]); stg.ls.reset(new float[stg.cap]);
+            stg.states.reset(new uint16_t[stg.cap]);
         }
+        float* const cm = stg.cm.get(); float* const sd = stg.sd.get(); float* const ls = stg.ls.get();
+        uint16_t* const states = stg.states.get();
+        detail::parallel_for(n, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; ++r) {
+                size_t k = (size_t)off[r];
+                for (const auto& e : *evs[r]) { cm[k] = e.corrected_mean; sd[k] = e.stdv; ls[k] = e.log_stdv; ++k; }
+            }
+        });
+        std::vector<int32_t> slots(n, slot), status(n);
+        std::vector<Float_Type> pp(n);
+        int rc = nchmm_viterbi(Device::instance().ctx(), n, off.data(), cm, sd, ls, slots.data(), slots.data(), states, pp.data(),
+                               status.data());
+        if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) check(rc, "nchmm_viterbi");
+        // fill_state_seq / fill_move_seq write-back (Viterbi.hpp:134-150), per strand in parallel
+        detail::parallel_for(n, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; ++r) {
+                auto& ev = *evs[r];
+                if (status[r] != 0) continue;   // reference has undefined behaviour here (Viterbi.hpp:125-141); leave events untouched
+                const uint16_t* s = states + off[r];
+                for (size_t i = 0; i < ev.size(); ++i) {
+                    const unsigned j = s[i];
+                    ev[i].model_state_idx = j;
+                    for (unsigned c = 0; c < Kmer_Size; ++c) ev[i].model_state[c] = "ACGT"[(j >> (2 * (Kmer_Size - 1 - c))) & 3u];   // Kmer::to_string
+                    ev[i].move = i > 0 ? (int)Kmer_Type::min_skip(s[i - 1], j) : 0;
+                }
+            }
+        });
         return pp;
     }
 private:
