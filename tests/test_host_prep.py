@@ -1,4 +1,6 @@
 """The product's host-side prep (C++ in libnanocall_hip.so, no GPU) against the CPU oracle: bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -89,3 +91,18 @@ def test_error_codes_not_exceptions():
     assert L.nchmm_transitions_fast(0.3, 0.1, None, None, None, None) == -1
     assert b"invalid" in L.nchmm_strerror(-1)
     assert L.nchmm_abi_version() >= 1
+
+
+def test_host_abi_under_sanitizers():
+    """tools/asan_host.cpp: every device-free ABI function (model load/scale/pack, transitions, event prep incl. the
+    threaded path, base sequence, FASTA, train finishes) compiled with -fsanitize=address,undefined and run on edge sizes."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "tools"), "asan-host"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "cannot find -lasan" in (r.stderr + r.stdout):
+        pytest.skip("libasan not installed")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "host ABI under ASan/UBSan: ok" in r.stdout
