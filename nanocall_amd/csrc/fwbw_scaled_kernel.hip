@@ -16,11 +16,12 @@
 // so one exp per cell (the emission) is the only transcendental left; everything else is FMA work.
 //
 // Range.  A state whose share of its column is below 2^-126 / (column total) flushes to zero.  Columns are
-// renormalised one event late, so the total can sag by the emission of one event; while it stays above
-// 2^-64 the flushed share is below 2^-62 of the column and nothing measurable is lost.  A window where a
-// column total falls below 2^-64 (an event no state explains), or where forward and backward mass barely
-// overlap, is FLAGGED and redone by the exact log-space kernels of fwbw_kernel.hip (launch_fwbw does
-// that in the same stream; tests/test_fwbw_gpu.py drives an outlier through it).
+// renormalised one event late, so the total can sag by the emission of one event (a stdv ten times the model's,
+// a level ~10 sigma off every state: 40-50 bits); while it stays above 2^-100 the flushed share is below 2^-26 =
+// 1.5e-8 of the column, four orders under the tolerance of anything computed from the posteriors.  A window
+// where a column total falls below 2^-100 (an event no state explains), or where forward and backward mass
+// barely overlap, is FLAGGED and redone by the exact log-space kernels of fwbw_kernel.hip (launch_fwbw does
+// that in the same stream; tests/test_fwbw_gpu.py drives outliers through it).
 #include "nanocall_hip.h"
 #include "nchmm_device.h"
 #include "fwbw_common.hpp"
@@ -33,7 +34,8 @@ using namespace fb;
 
 namespace {
 
-constexpr float kMinTotal = 0x1p-64f;
+constexpr float kMinTotal = 0x1p-100f;
+constexpr int kMaxKappaExp = 100;     // |Ia + Ib - Ia_final| beyond this: forward and backward mass barely overlap
 
 // binary exponent e of a positive normal float z (2^e <= z < 2^(e+1)) and the exact scale 2^-e
 __device__ __forceinline__ int exponent_of(float z) { return (int)((__builtin_bit_cast(unsigned, z) >> 23) & 255u) - 127; }
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             // statistics of event i-1 are in units of (ahat_{i-1} g): kappa = 2^(Ia_{i-1} + Ib_i - Ia_{n-1}) / Z
             const int kx = nx_ia + Ib - Iaf;
             float sc = 1.0f, kappa = 0.0f;
-            if (Zg >= kMinTotal && kx >= -60 && kx <= 60) {
+            if (Zg >= kMinTotal && kx >= -kMaxKappaExp && kx <= kMaxKappaExp) {
                 const int eg = exponent_of(Zg);
                 sc = pow2i(-eg);
                 Ib += eg;

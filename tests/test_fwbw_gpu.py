@@ -306,3 +306,30 @@ def test_several_flagged_windows_in_a_larger_batch(gpu_ctx, monkeypatch):
     assert np.array_equal(fast["st_sums"][flagged], ref["st_sums"][flagged])
     assert rel(fast["pm_sums"][~ev_flag], ref["pm_sums"][~ev_flag], floor=1e-3).max() <= 3e-4
     assert rel(np.exp(fast["st_sums"][~flagged]), np.exp(ref["st_sums"][~flagged]), floor=1e-6).max() <= 3e-4
+
+
+def test_moderate_outliers_stay_on_the_fast_path(gpu_ctx, monkeypatch):
+    """Events that are bad for every state but not absurd (a level ~8 pA above the highest one, a stdv eight times the
+    model's) cost a column 30-60 bits; the rescaled kernels absorb that without the log-space redo and still agree
+    with it."""
+    params = (1.0, 0.0, 0.0, 1.0, 1.0, 1.0)
+    n_reads, n_ev = 4, 100
+    tabs, off, cm, sd, ls, strand = _em_window_batch(n_reads=n_reads, n_ev=n_ev)
+    cm, sd = cm.copy(), sd.copy()
+    top = [float(t[:, 0].max()) for t in tabs]
+    for w in range(4 * n_reads):
+        cm[w * n_ev + 10 + w] = top[strand[w]] + 8.0
+        sd[w * n_ev + 60 + w] *= 8.0
+    ls = np.log(sd).astype(np.float32)
+    before = int(gpu_ctx.counters()[7])
+    fast = _run_em_batch(gpu_ctx, tabs, off, cm, sd, ls, strand, params)
+    assert int(gpu_ctx.counters()[7]) == before
+    monkeypatch.setenv("NCHMM_FB_FORCE_LOG", "1")
+    ref_ctx = na.Context(0)
+    try:
+        ref = _run_em_batch(ref_ctx, tabs, off, cm, sd, ls, strand, params)
+    finally:
+        ref_ctx.close()
+    assert rel(fast["log_pr_data"], ref["log_pr_data"]).max() <= 1e-5
+    assert rel(fast["pm_sums"], ref["pm_sums"], floor=1e-3).max() <= 1e-3      # log-space noise grows with |log Pr|, see above
+    assert rel(np.exp(fast["st_sums"]), np.exp(ref["st_sums"]), floor=1e-6).max() <= 1e-3
