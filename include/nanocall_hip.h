@@ -105,6 +105,12 @@ int nchmm_train_pm_finish(size_t n_events, const float* pm_sums_nx6, const float
  * {denom, stay_num, skip_num} log-sums of that strand's windows and applies the [.05, .4] reset. */
 int nchmm_train_st_finish(size_t n_win, const float* st_sums_nx3, float* p_stay, float* p_skip);
 
+/* The solve half of nchmm_train_pm_finish (Parameter_Trainer.hpp:314-427) from the thirteen outer sums
+ * {A00, A01, A11, B0, B1, A02, A12, A22, B2, D, V_numer, V_denom, U_pos} of :297-312, which nchmm_em_round
+ * accumulates on the device. */
+int nchmm_train_pm_solve(size_t n_events, const double acc[13], int train_drift, const float crt_pm[6],
+                         float new_pm[6], int* done);
+
 /* ------------------------------------------------------------------------------------------
  * Device context
  * ---------------------------------------------------------------------------------------- */
@@ -208,6 +214,25 @@ int nchmm_fwbw_dev(nchmm_ctx* ctx, size_t n_win, size_t max_events, size_t total
                    const int32_t* d_trans_slot, const float* d_st_params,
                    float* d_out_log_pr_data, float* d_out_pm_sums, float* d_out_st_sums,
                    float* d_out_alpha, float* d_out_beta);
+
+/* ------------------------------------------------------------------------------------------
+ * One EM round with the events resident on the device -- Parameter_Trainer::fill_train_data
+ * (Parameter_Trainer.hpp:99-155) + the event loops of train_pm_params (:273-312), for many jobs at once.
+ * nchmm_em_load_events uploads the raw events of all reads once (stdv after Event::update_logs' 0 -> .01,
+ * log_stdv from the host libm; only the entries training windows cover are ever read).  nchmm_em_round then
+ * takes window w = raw events [win_src[w], win_src[w] + win_len[w]) with its drift, scaling parameters
+ * (win_pm, 6 floats: what produced scaled_slot[w]), model / transition slots and {p_stay, p_skip}; job k owns
+ * windows [job_first_win[k], job_first_win[k+1]).  On the device: drift correction + packing, forward-backward
+ * + inner sums (as nchmm_fwbw_dev), then the outer sums of :297-312 per job.  Back come log Pr(data) per
+ * window, {denom, stay_num, skip_num} per window (nchmm_train_st_finish) and thirteen doubles per job
+ * (nchmm_train_pm_solve).
+ * ---------------------------------------------------------------------------------------- */
+int nchmm_em_load_events(nchmm_ctx* ctx, size_t n_events, const float* mean, const float* stdv, const float* start,
+                         const float* log_stdv);
+int nchmm_em_round(nchmm_ctx* ctx, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift,
+                   const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
+                   size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_log_pr_data,
+                   float* out_st_sums, double* out_job_acc);
 
 /* ------------------------------------------------------------------------------------------
  * EM driver loop -- replaces the body of train_reads (src/nanocall/nanocall.cpp:292-574): window

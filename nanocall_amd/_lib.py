@@ -32,6 +32,7 @@ SIGNATURES = {
     "nchmm_st_train_kmers": (C.c_int, [vp, vp]),
     "nchmm_train_pm_finish": (C.c_int, [C.c_size_t, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
     "nchmm_train_st_finish": (C.c_int, [C.c_size_t, vp, vp, vp]),
+    "nchmm_train_pm_solve": (C.c_int, [C.c_size_t, vp, C.c_int, vp, vp, vp]),
     "nchmm_train_opts_default": (C.c_int, [vp]),
     "nchmm_train_enumerate": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]),
     "nchmm_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),
@@ -50,6 +51,8 @@ SIGNATURES = {
     "nchmm_viterbi_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
     "nchmm_fwbw": (C.c_int, [vp, C.c_size_t] + [vp] * 13),
     "nchmm_fwbw_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 13),
+    "nchmm_em_load_events": (C.c_int, [vp, C.c_size_t, vp, vp, vp, vp]),
+    "nchmm_em_round": (C.c_int, [vp, C.c_size_t] + [vp] * 7 + [C.c_size_t, vp, C.c_int, vp, vp, vp]),
     "nchmm_counters": (C.c_int, [vp, vp]),
     "nchmm_last_kernel_ms": (C.c_int, [vp, vp]),
     "nchmm_profile_ticks": (C.c_int, [vp, vp, C.c_int]),

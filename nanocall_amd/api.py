@@ -116,6 +116,16 @@ def train_pm_finish(pm_sums, mean, stdv, start, crt_pm, train_drift=True):
     return new, bool(done.value)
 
 
+def train_pm_solve(n_events, acc13, crt_pm, train_drift=True):
+    """The solve half of train_pm_finish from the thirteen outer sums -> (new_pm[6], done)."""
+    acc = np.ascontiguousarray(acc13, np.float64).reshape(13)
+    new = np.empty(6, np.float32)
+    done = C.c_int(0)
+    check(lib().nchmm_train_pm_solve(int(n_events), _p(acc), int(train_drift), _p(_f32(crt_pm).reshape(6)), _p(new), C.byref(done)),
+          "nchmm_train_pm_solve")
+    return new, bool(done.value)
+
+
 def train_st_finish(st_sums):
     """train_st_params' host half for one strand -> (p_stay, p_skip)."""
     st = _f32(st_sums).reshape(-1, 3)
@@ -276,6 +286,30 @@ class Context:
                                    _dp(d_lstdv), _dp(d_scaled_slot), _dp(d_pm_params), _dp(d_trans_slot),
                                    _dp(d_st_params), _dp(d_out_lpd), _dp(d_out_pm), _dp(d_out_st),
                                    _dp(d_out_alpha), _dp(d_out_beta)), "nchmm_fwbw_dev")
+
+    # -- one EM round with resident events --
+    def em_load_events(self, mean, stdv, start, log_stdv):
+        mean, stdv, start, ls = _f32(mean), _f32(stdv), _f32(start), _f32(log_stdv)
+        check(lib().nchmm_em_load_events(self._h, mean.shape[0], _p(mean), _p(stdv), _p(start), _p(ls)), "nchmm_em_load_events")
+
+    def em_round(self, win_src, win_len, win_drift, win_pm, scaled_slot, trans_slot, st_params, job_first_win, train_drift=True):
+        """-> dict(log_pr_data[n_win], st_sums[n_win,3], acc[n_jobs,13])"""
+        ws = np.ascontiguousarray(win_src, np.uint64)
+        n = ws.shape[0]
+        wl = np.ascontiguousarray(win_len, np.uint32)
+        wd = _f32(win_drift)
+        wp = np.ascontiguousarray(np.broadcast_to(_f32(win_pm).reshape(-1, 6), (n, 6)))
+        ss = np.ascontiguousarray(scaled_slot, np.int32)
+        ts = np.ascontiguousarray(trans_slot, np.int32)
+        sp = _f32(st_params).reshape(n, 2)
+        jf = np.ascontiguousarray(job_first_win, np.uint32)
+        nj = jf.shape[0] - 1
+        lpd = np.empty(n, np.float32)
+        st = np.empty((n, 3), np.float32)
+        acc = np.empty((nj, 13), np.float64)
+        check(lib().nchmm_em_round(self._h, n, _p(ws), _p(wl), _p(wd), _p(wp), _p(ss), _p(ts), _p(sp), nj, _p(jf), int(train_drift),
+                                   _p(lpd), _p(st), _p(acc)), "nchmm_em_round")
+        return dict(log_pr_data=lpd, st_sums=st, acc=acc)
 
     # -- EM driver --
     def train_reads(self, opts, model_states, strand_off, mean, stdv, start, job_read, job_m0, job_m1, init_pm=None,

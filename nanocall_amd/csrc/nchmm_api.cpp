@@ -43,6 +43,8 @@ struct nchmm_ctx {
     void* d_fb_aux = nullptr;       // FB per-call scratch: lpd2 | last-row totals | redo list | redo flags | row exponents
     size_t fb_aux_bytes = 0;
     unsigned long long* d_fb_total = nullptr;   // windows redone in log space, running total
+    void* d_em_events = nullptr;    // resident raw events of an EM run: mean | stdv | start | log_stdv (nchmm_em_load_events)
+    size_t em_events_bytes = 0, em_n_events = 0;
     bool fb_force_log = false;      // NCHMM_FB_FORCE_LOG: never take the rescaled linear-space kernels
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
@@ -403,6 +405,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_fb_aux) (void)hipFree(c->d_fb_aux);
     if (c->d_fb_total) (void)hipFree(c->d_fb_total);
+    if (c->d_em_events) (void)hipFree(c->d_em_events);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
@@ -814,6 +817,89 @@ int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cme
     if (out_st) HIP_TRY(c, hipMemcpyAsync(out_st, d + o_st, 12 * n_win, hipMemcpyDeviceToHost, s));
     if (out_alpha && total) HIP_TRY(c, hipMemcpyAsync(out_alpha, d + o_al, 4 * total * kStates, hipMemcpyDeviceToHost, s));
     if (out_beta && total) HIP_TRY(c, hipMemcpyAsync(out_beta, d + o_be, 4 * total * kStates, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return NCHMM_OK;
+}
+
+int nchmm_em_load_events(nchmm_ctx* c, size_t n_events, const float* mean, const float* stdv, const float* start,
+                         const float* log_stdv)
+{
+    if (!c || (n_events && (!mean || !stdv || !start || !log_stdv))) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t stride = (n_events + 63) & ~(size_t)63;
+    int rc = ensure(c, &c->d_em_events, &c->em_events_bytes, std::max<size_t>(4 * stride, 64) * sizeof(float));
+    if (rc != NCHMM_OK) return rc;
+    c->em_n_events = n_events;
+    float* d = (float*)c->d_em_events;
+    const float* src[4] = {mean, stdv, start, log_stdv};
+    for (int k = 0; k < 4; ++k)
+        if (n_events) HIP_TRY(c, hipMemcpyAsync(d + k * stride, src[k], n_events * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NCHMM_OK;
+}
+
+int nchmm_em_round(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift,
+                   const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
+                   size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_lpd, float* out_st, double* out_acc)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_win == 0) return NCHMM_OK;
+    if (!win_src || !win_len || !win_drift || !out_lpd || (n_jobs && (!job_first_win || !out_acc)) || n_win > 0xFFFFFFF0ull)
+        return NCHMM_E_INVALID;
+    if (n_jobs && (job_first_win[0] != 0 || job_first_win[n_jobs] != n_win)) return NCHMM_E_INVALID;
+    std::vector<uint64_t> off(n_win + 1, 0);
+    size_t max_events = 0;
+    for (size_t w = 0; w < n_win; ++w) {
+        if (win_src[w] + win_len[w] > c->em_n_events) return NCHMM_E_INVALID;
+        off[w + 1] = off[w] + win_len[w];
+        max_events = std::max<size_t>(max_events, win_len[w]);
+        const int ms = scaled_slot ? scaled_slot[w] : 0, ts = trans_slot ? trans_slot[w] : 0;
+        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts]) return NCHMM_E_INVALID;
+    }
+    const size_t total = (size_t)off[n_win];
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_off = 0, o_src = o_off + al(8 * (n_win + 1)), o_dr = o_src + al(8 * n_win), o_pm = o_dr + al(4 * n_win);
+    size_t o_ss = o_pm + al(24 * n_win), o_ts = o_ss + al(4 * n_win), o_sp = o_ts + al(4 * n_win), o_jf = o_sp + al(8 * n_win);
+    size_t o_cm = o_jf + al(4 * (n_jobs + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total), o_lp = o_ls + al(4 * total);
+    size_t o_ps = o_lp + al(4 * n_win), o_st = o_ps + al(24 * total), o_ac = o_st + al(12 * n_win), need = o_ac + al(104 * std::max<size_t>(n_jobs, 1));
+    int rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
+    if (rc != NCHMM_OK) return rc;
+    char* d = (char*)c->d_stage;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(d + o_off, off.data(), 8 * (n_win + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d + o_src, win_src, 8 * n_win, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d + o_dr, win_drift, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (win_pm) HIP_TRY(c, hipMemcpyAsync(d + o_pm, win_pm, 24 * n_win, hipMemcpyHostToDevice, s));
+    if (scaled_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ss, scaled_slot, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_win, hipMemcpyHostToDevice, s));
+    if (st_params) HIP_TRY(c, hipMemcpyAsync(d + o_sp, st_params, 8 * n_win, hipMemcpyHostToDevice, s));
+    if (n_jobs) HIP_TRY(c, hipMemcpyAsync(d + o_jf, job_first_win, 4 * (n_jobs + 1), hipMemcpyHostToDevice, s));
+    const size_t stride = (c->em_n_events + 63) & ~(size_t)63;
+    const float* ev = (const float*)c->d_em_events;
+    EmGatherArgs g;
+    g.mean = ev; g.stdv = ev + stride; g.start = ev + 2 * stride; g.lstdv = ev + 3 * stride;
+    g.win_src = (const uint64_t*)(d + o_src); g.off = (const uint64_t*)(d + o_off); g.win_drift = (const float*)(d + o_dr);
+    g.cmean = (float*)(d + o_cm); g.out_stdv = (float*)(d + o_sd); g.out_lstdv = (float*)(d + o_ls);
+    launch_em_gather(g, (unsigned)n_win, s);
+    HIP_TRY(c, hipGetLastError());
+    rc = nchmm_fwbw_dev(c, n_win, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
+                        (const float*)(d + o_ls), scaled_slot ? (const int32_t*)(d + o_ss) : nullptr,
+                        win_pm ? (const float*)(d + o_pm) : nullptr, trans_slot ? (const int32_t*)(d + o_ts) : nullptr,
+                        st_params ? (const float*)(d + o_sp) : nullptr, (float*)(d + o_lp), (float*)(d + o_ps), (float*)(d + o_st),
+                        nullptr, nullptr);
+    if (rc != NCHMM_OK) return rc;
+    if (n_jobs) {
+        EmReduceArgs r;
+        r.mean = g.mean; r.stdv = g.stdv; r.start = g.start; r.win_src = g.win_src; r.off = g.off;
+        r.job_first_win = (const uint32_t*)(d + o_jf); r.pm_sums = (const float*)(d + o_ps); r.train_drift = train_drift;
+        r.out = (double*)(d + o_ac);
+        launch_em_reduce(r, (unsigned)n_jobs, s);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(out_acc, d + o_ac, 104 * n_jobs, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(out_lpd, d + o_lp, 4 * n_win, hipMemcpyDeviceToHost, s));
+    if (out_st) HIP_TRY(c, hipMemcpyAsync(out_st, d + o_st, 12 * n_win, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     return NCHMM_OK;
 }

@@ -93,6 +93,23 @@ void launch_scale_models(const float* d_states, const int32_t* d_table_idx, cons
                          int32_t* d_model_fast, int first_slot, size_t n, float log_2pi, hipStream_t stream);
 void launch_expand_transitions(const float* d_wm, const uint8_t* d_masks, float* d_trans, float* d_trans_fb, int first_slot,
                                size_t n, hipStream_t stream);
+struct EmGatherArgs {
+    const float* mean; const float* stdv; const float* start; const float* lstdv;   // resident raw events
+    const uint64_t* win_src;   // [n_win] first raw event of each window
+    const uint64_t* off;       // [n_win + 1] packed offsets
+    const float* win_drift;    // [n_win]
+    float* cmean; float* out_stdv; float* out_lstdv;                                 // packed SoA for the FB kernels
+};
+struct EmReduceArgs {
+    const float* mean; const float* stdv; const float* start;
+    const uint64_t* win_src; const uint64_t* off;
+    const uint32_t* job_first_win;   // [n_jobs + 1]
+    const float* pm_sums;            // packed [events][6]
+    int train_drift;
+    double* out;                     // [n_jobs][13]
+};
+void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream);
+void launch_em_reduce(const EmReduceArgs& a, unsigned n_jobs, hipStream_t stream);
 void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream, bool scaled);
 void launch_fwbw_scaled(const FwbwArgs& a, int grid, hipStream_t stream);
 int fwbw_scaled_blocks_per_cu();

@@ -216,29 +216,40 @@ int nchmm_train_pm_finish(size_t n_events, const float* pm_sums, const float* me
                           const float* start, int train_drift, const float crt_pm[6], float new_pm[6], int* done)
 {
     if (!pm_sums || !mean || !stdv || !crt_pm || !new_pm || !done || (train_drift && !start)) return NCHMM_E_INVALID;
-    *done = 0;
-    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, B[3] = {0, 0, 0};
-    double D = 0, V_numer = 0, V_denom = 0, U_pos = 0;
+    // acc = {A00, A01, A11, B0, B1, A02, A12, A22, B2, D, V_numer, V_denom, U_pos}
+    double acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < n_events; ++i) {
         const float* s = pm_sums + 6 * i;
         const float* l = s + 3;
         const float x_i = mean[i], y_i = stdv[i], t_i = start ? start[i] : 0.0f;
-        A[0][0] += s[0];
-        A[0][1] += s[1];
-        A[1][1] += s[2];
-        B[0] += s[0] * x_i;
-        B[1] += s[1] * x_i;
+        acc[0] += s[0];
+        acc[1] += s[1];
+        acc[2] += s[2];
+        acc[3] += s[0] * x_i;
+        acc[4] += s[1] * x_i;
         if (train_drift) {
-            A[0][2] += s[0] * t_i;
-            A[1][2] += s[1] * t_i;
-            A[2][2] += s[0] * t_i * t_i;
-            B[2] += s[0] * x_i * t_i;
+            acc[5] += s[0] * t_i;
+            acc[6] += s[1] * t_i;
+            acc[7] += s[0] * t_i * t_i;
+            acc[8] += s[0] * x_i * t_i;
         }
-        D += s[0] * x_i * x_i;
-        V_numer += l[2] * y_i;
-        V_denom += l[1];
-        U_pos += l[0] / y_i;
+        acc[9] += s[0] * x_i * x_i;
+        acc[10] += l[2] * y_i;
+        acc[11] += l[1];
+        acc[12] += l[0] / y_i;
     }
+    return nchmm_train_pm_solve(n_events, acc, train_drift, crt_pm, new_pm, done);
+}
+
+// The solve half of train_pm_params (Parameter_Trainer.hpp:314-427) from the thirteen outer sums
+// {A00, A01, A11, B0, B1, A02, A12, A22, B2, D, V_numer, V_denom, U_pos} (nchmm_train_pm_finish above, or the
+// device reduction of nchmm_em_round).
+int nchmm_train_pm_solve(size_t n_events, const double acc[13], int train_drift, const float crt_pm[6], float new_pm[6], int* done)
+{
+    if (!acc || !crt_pm || !new_pm || !done) return NCHMM_E_INVALID;
+    *done = 0;
+    double A[3][3] = {{acc[0], acc[1], acc[5]}, {0, acc[2], acc[6]}, {0, 0, acc[7]}}, B[3] = {acc[3], acc[4], acc[8]};
+    const double D = acc[9], V_numer = acc[10], V_denom = acc[11], U_pos = acc[12];
     A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
     if (!train_drift) A[2][2] = 1.0;
     double Ac[3][3], Bc[3], C[3];

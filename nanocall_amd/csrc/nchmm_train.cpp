@@ -99,15 +99,28 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         return NCHMM_E_INVALID;
     const float NEG_INF = -std::numeric_limits<float>::infinity();
     const uint64_t total_events = strand_off[2 * n_reads];
-    // Event::update_logs happened at load time in the reference; the log of stdv is what the emission needs.  Only the
-    // training windows (first and last scaling_num_events / 2 events of a strand, nanocall.cpp:333-337) are ever read.
-    std::unique_ptr<float[]> log_stdv(new float[std::max<uint64_t>(total_events, 1)]);
+    // Only the training windows (first and last scaling_num_events / 2 events of a strand, nanocall.cpp:333-337) are
+    // ever read: they are compacted strand by strand -- [head window | tail window] at position 2 * half * k of the
+    // compact arrays for strand k -- and only those go to the device.  log_stdv: Event::update_logs happened at load
+    // time in the reference (float libm).
+    (void)total_events;
+    std::vector<uint64_t> cbase(2 * n_reads + 1, 0);
+    for (size_t k = 0; k < 2 * n_reads; ++k)
+        cbase[k + 1] = cbase[k] + 2 * (std::min<uint64_t>(o->scaling_num_events, strand_off[k + 1] - strand_off[k]) / 2);
+    const size_t n_compact = (size_t)cbase[2 * n_reads];
+    std::unique_ptr<float[]> c_mean(new float[n_compact + 1]), c_stdv(new float[n_compact + 1]), c_start(new float[n_compact + 1]),
+        c_lstdv(new float[n_compact + 1]);
     parallel_for(2 * n_reads, [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; ++k) {
             const uint64_t b = strand_off[k], e = strand_off[k + 1];
-            const uint64_t half = std::min<uint64_t>(o->scaling_num_events, e - b) / 2;
-            for (uint64_t i = b; i < b + half; ++i) log_stdv[i] = std::log(stdv[i]);
-            for (uint64_t i = e - half; i < e; ++i) log_stdv[i] = std::log(stdv[i]);
+            const uint64_t half = (cbase[k + 1] - cbase[k]) / 2;
+            uint64_t d = cbase[k];
+            for (int part = 0; part < 2; ++part) {
+                const uint64_t from = part == 0 ? b : e - half;
+                for (uint64_t i = from; i < from + half; ++i, ++d) {
+                    c_mean[d] = mean[i]; c_stdv[d] = stdv[i]; c_start[d] = start[i]; c_lstdv[d] = std::log(stdv[i]);
+                }
+            }
         }
     });
 
@@ -129,8 +142,10 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             // nanocall.cpp:333-337: first and last num_train_events / 2 events
             const uint64_t num = std::min<uint64_t>(o->scaling_num_events, n_ev);
             const uint32_t half = (uint32_t)(num / 2);
-            j.win.push_back(Window{b, half, (uint32_t)s});
-            j.win.push_back(Window{e - half, half, (uint32_t)s});
+            (void)b; (void)e;
+            const uint64_t cb = cbase[2 * j.read + s];                       // the strand's two windows in the compact arrays
+            j.win.push_back(Window{cb, half, (uint32_t)s});
+            j.win.push_back(Window{cb + half, half, (uint32_t)s});
             j.have[s] = true;
         }
         if (j.win.empty()) j.active = false;
@@ -140,6 +155,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     // holds the default weights
     int rc;
     if ((rc = nchmm_put_transitions_fast(ctx, 0, 1, &o->default_p_skip, &o->default_p_stay))) return rc;
+    // the events of every read go to the device once; each round only sends per-window descriptors
+    if ((rc = nchmm_em_load_events(ctx, n_compact, c_mean.get(), c_stdv.get(), c_start.get(), c_lstdv.get()))) return rc;
 
     const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -154,56 +171,45 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         // ---- Parameter_Trainer::fill_train_data (Parameter_Trainer.hpp:99-155), all active jobs at once ----
         std::vector<int32_t> m_idx(2 * na, 0); std::vector<float> m_par(12 * na, 0.f);   // scaled models: slot n_models + 2p + s
         std::vector<float> t_skip(2 * na, o->default_p_skip), t_stay(2 * na, o->default_p_stay);
-        // where each job's windows and events go (prefix sums), then every job fills its own slice
-        std::vector<size_t> first_win(na + 1, 0), first_ev(na + 1, 0);
-        for (size_t p = 0; p < na; ++p) {
-            const Job& j = jobs[act[p]];
-            size_t ev = 0;
-            for (const Window& w : j.win) ev += w.len;
-            first_win[p + 1] = first_win[p] + j.win.size();
-            first_ev[p + 1] = first_ev[p] + ev;
-        }
-        const size_t n_win = first_win[na], tot = first_ev[na];
-        std::vector<uint64_t> off(n_win + 1, 0);
-        std::vector<float> cm(tot), sd(tot), ls(tot), raw_mean(tot), raw_start(tot), stp(2 * n_win);
+        // per-window descriptors (the drift correction and SoA packing of :130-140 happen on the device)
+        std::vector<uint32_t> first_win(na + 1, 0);
+        for (size_t p = 0; p < na; ++p) first_win[p + 1] = first_win[p] + (uint32_t)jobs[act[p]].win.size();
+        const size_t n_win = first_win[na];
+        std::vector<uint64_t> w_src(n_win);
+        std::vector<uint32_t> w_len(n_win);
+        std::vector<float> w_drift(n_win), stp(2 * n_win), w_pm(6 * n_win);   // w_pm: the parameters behind the window's scaled model
         std::vector<int32_t> s_slot(n_win), t_slot(n_win);
-        std::vector<float> w_pm(6 * n_win);                           // per window: the parameters behind its scaled model
-        parallel_for(na, [&](size_t lo, size_t hi) {
-            for (size_t p = lo; p < hi; ++p) {
-                Job& j = jobs[act[p]];
-                std::memcpy(j.old_pm, j.pm, sizeof(j.pm)); std::memcpy(j.old_st, j.st, sizeof(j.st)); j.old_fit = j.fit;
-                for (int s = 0; s < 2; ++s) {
-                    m_idx[2 * p + s] = j.m[s] >= 0 ? j.m[s] : std::max(j.m[0], j.m[1]);
-                    std::memcpy(&m_par[6 * (2 * p + s)], j.old_pm, sizeof(j.old_pm));
-                    t_stay[2 * p + s] = j.old_st[2 * s]; t_skip[2 * p + s] = j.old_st[2 * s + 1];
-                }
-                size_t wi = first_win[p], k = first_ev[p];
-                for (const Window& w : j.win) {
-                    for (uint32_t i = 0; i < w.len; ++i, ++k) {
-                        const uint64_t e = w.begin + i;
-                        float c = mean[e];
-                        c -= j.old_pm[2] * start[e];   // apply_drift_correction, Event.hpp:77-84
-                        cm[k] = c; sd[k] = stdv[e]; ls[k] = log_stdv[e];
-                        raw_mean[k] = mean[e]; raw_start[k] = start[e];
-                    }
-                    off[wi + 1] = k;
-                    s_slot[wi] = (int32_t)(n_models + 2 * p + w.strand);
-                    std::memcpy(&w_pm[6 * wi], j.old_pm, sizeof(j.old_pm));
-                    // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
-                    const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
-                    t_slot[wi] = dflt ? 0 : (int32_t)(1 + 2 * p + w.strand);
-                    stp[2 * wi] = j.old_st[2 * w.strand]; stp[2 * wi + 1] = j.old_st[2 * w.strand + 1];
-                    ++wi;
-                }
+        std::vector<size_t> job_events(na, 0);
+        for (size_t p = 0; p < na; ++p) {
+            Job& j = jobs[act[p]];
+            std::memcpy(j.old_pm, j.pm, sizeof(j.pm)); std::memcpy(j.old_st, j.st, sizeof(j.st)); j.old_fit = j.fit;
+            for (int s = 0; s < 2; ++s) {
+                m_idx[2 * p + s] = j.m[s] >= 0 ? j.m[s] : std::max(j.m[0], j.m[1]);
+                std::memcpy(&m_par[6 * (2 * p + s)], j.old_pm, sizeof(j.old_pm));
+                t_stay[2 * p + s] = j.old_st[2 * s]; t_skip[2 * p + s] = j.old_st[2 * s + 1];
             }
-        });
+            size_t wi = first_win[p];
+            for (const Window& w : j.win) {
+                w_src[wi] = w.begin; w_len[wi] = w.len; w_drift[wi] = j.old_pm[2];   // apply_drift_correction, Event.hpp:77-84
+                job_events[p] += w.len;
+                s_slot[wi] = (int32_t)(n_models + 2 * p + w.strand);
+                std::memcpy(&w_pm[6 * wi], j.old_pm, sizeof(j.old_pm));
+                // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
+                const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
+                t_slot[wi] = dflt ? 0 : (int32_t)(1 + 2 * p + w.strand);
+                stp[2 * wi] = j.old_st[2 * w.strand]; stp[2 * wi + 1] = j.old_st[2 * w.strand + 1];
+                ++wi;
+            }
+        }
         const auto t_1 = now();
         if ((rc = nchmm_put_models_scaled(ctx, (int)n_models, 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
         if ((rc = nchmm_put_transitions_fast(ctx, 1, 2 * na, t_skip.data(), t_stay.data()))) return rc;
         const auto t_2 = now();
-        std::vector<float> lpd(n_win), pm_sums(6 * tot), st_sums(3 * n_win);
-        rc = nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), w_pm.data(), t_slot.data(),
-                        stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr);
+        // forward-backward, inner and outer sums on the device: 13 doubles per job come back
+        std::vector<float> lpd(n_win), st_sums(3 * n_win);
+        std::vector<double> acc(13 * na);
+        rc = nchmm_em_round(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
+                            na, first_win.data(), o->train_drift, lpd.data(), st_sums.data(), acc.data());
         if (rc != NCHMM_OK) return rc;
         const auto t_3 = now();
         // ---- finish the round per job (Parameter_Trainer.hpp:557-578) and apply the stop rules ----
@@ -217,10 +223,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             j.fit = fit;
             bool done = false;
             if (o->train_scaling) {
-                const size_t e0 = off[w0], e1 = off[w1];
                 int d = 0;
-                const int rc = nchmm_train_pm_finish(e1 - e0, &pm_sums[6 * e0], &raw_mean[e0], &sd[e0], &raw_start[e0], o->train_drift,
-                                           j.old_pm, j.pm, &d);
+                const int rc = nchmm_train_pm_solve(job_events[p], &acc[13 * p], o->train_drift, j.old_pm, j.pm, &d);
                 if (rc != NCHMM_OK) { first_err = rc; return; }
                 done = d != 0;
             }

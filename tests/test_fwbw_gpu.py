@@ -333,3 +333,47 @@ def test_moderate_outliers_stay_on_the_fast_path(gpu_ctx, monkeypatch):
     assert rel(fast["log_pr_data"], ref["log_pr_data"]).max() <= 1e-5
     assert rel(fast["pm_sums"], ref["pm_sums"], floor=1e-3).max() <= 1e-3      # log-space noise grows with |log Pr|, see above
     assert rel(np.exp(fast["st_sums"]), np.exp(ref["st_sums"]), floor=1e-6).max() <= 1e-3
+
+
+def test_em_round_equals_fwbw_plus_host_finish(gpu_ctx):
+    """nchmm_em_round (events resident on the device: drift correction, packing, forward-backward, inner sums and the
+    per-job outer sums of train_pm_params all on the GPU) against the same round done through nchmm_fwbw on
+    host-prepared windows + nchmm_train_pm_finish: identical log-likelihoods and transition sums (same kernels, same
+    inputs), trained parameters equal up to the order of a double accumulation."""
+    from nanocall_amd import api
+    t0, t1 = na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")
+    n_reads, n_ev = 3, 600
+    e0 = synth.generate(t0, n_reads, n_ev, first_read=77)
+    e1 = synth.generate(t1, n_reads, n_ev, first_read=10**6 + 77)
+    mean = np.stack([e0["mean"], e1["mean"]], 1).reshape(-1)
+    stdv = np.stack([e0["stdv"], e1["stdv"]], 1).reshape(-1)
+    start = np.stack([e0["start"], e1["start"]], 1).reshape(-1)
+    _, stdv, lsd = na.events_prepare(mean, stdv, None, 0.0)
+    pm = np.array([[1.01, 0.3, 0.002, 1.02, 0.98, 1.1], [0.99, -0.4, -0.001, 0.97, 1.03, 0.9], [1.0, 0.0, 0.0, 1.0, 1.0, 1.0]], np.float32)
+    stp = np.float32([0.11, 0.29])
+    # job r = read r: windows = first / last 100 events of both strands, its own parameters
+    win_src, win_len, win_drift, win_pm, s_slot, t_slot, jf = [], [], [], [], [], [], [0]
+    for r in range(n_reads):
+        for s, tab in enumerate((t0, t1)):
+            gpu_ctx.put_model(40 + 2 * r + s, na.scaled_model_table(tab, pm[r]))
+            base = (2 * r + s) * n_ev
+            for b in (base, base + n_ev - 100):
+                win_src.append(b); win_len.append(100); win_drift.append(pm[r, 2]); win_pm.append(pm[r]); s_slot.append(40 + 2 * r + s); t_slot.append(40)
+        jf.append(len(win_src))
+    gpu_ctx.put_transitions(40, *na.transitions_fast(0.29, 0.11))
+    n_win = len(win_src)
+    gpu_ctx.em_load_events(mean, stdv, start, lsd)
+    got = gpu_ctx.em_round(win_src, win_len, win_drift, np.array(win_pm), s_slot, t_slot, np.tile(stp, (n_win, 1)), jf, train_drift=True)
+    # the same round through host-prepared windows
+    off = np.arange(n_win + 1, dtype=np.uint64) * 100
+    idx = np.concatenate([np.arange(b, b + 100) for b in win_src])
+    cm = np.concatenate([na.events_prepare(mean[b:b + 100], stdv[b:b + 100], start[b:b + 100], float(d))[0] for b, d in zip(win_src, win_drift)])
+    ref = gpu_ctx.fwbw(off, cm, stdv[idx], lsd[idx], scaled_slot=s_slot, pm_params=np.array(win_pm), trans_slot=t_slot, st_params=np.tile(stp, (n_win, 1)))
+    assert np.array_equal(got["log_pr_data"], ref["log_pr_data"])
+    assert np.array_equal(got["st_sums"], ref["st_sums"])
+    for r in range(n_reads):
+        a, b = jf[r] * 100, jf[r + 1] * 100
+        exp, exp_done = na.train_pm_finish(ref["pm_sums"][a:b], mean[idx[a:b]], stdv[idx[a:b]], start[idx[a:b]], pm[r], train_drift=True)
+        new, done = api.train_pm_solve(b - a, got["acc"][r], pm[r], train_drift=True)
+        assert done == exp_done
+        assert np.allclose(new, exp, rtol=1e-6, atol=1e-9), (r, new, exp)
