@@ -335,8 +335,17 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
     const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     const size_t tot = (size_t)off.back();
-    std::unique_ptr<float[]> cm_b(new float[tot + 1]), sd_b(new float[tot + 1]), ls_b(new float[tot + 1]);   // (no zero fill)
-    float* const cm = cm_b.get(); float* const sd = sd_b.get(); float* const ls = ls_b.get();
+    // host staging lives with the calling thread and only grows: a fresh 290 MB per call costs more in page faults
+    // and unmapping than the gather itself (no zero fill either)
+    struct Staging { std::unique_ptr<float[]> cm, sd, ls; std::unique_ptr<uint16_t[]> states; size_t cap = 0; };
+    static thread_local Staging stg;
+    if (stg.cap < tot + 1) {
+        stg.cap = tot + 1 + tot / 8;
+        stg.cm.reset(); stg.sd.reset(); stg.ls.reset(); stg.states.reset();
+        stg.cm.reset(new float[stg.cap]); stg.sd.reset(new float[stg.cap]); stg.ls.reset(new float[stg.cap]);
+        stg.states.reset(new uint16_t[stg.cap]);
+    }
+    float* const cm = stg.cm.get(); float* const sd = stg.sd.get(); float* const ls = stg.ls.get();
     parallel_for(cands.size(), [&](size_t lo, size_t hi) {
         for (size_t v = lo; v < hi; ++v) {
             const size_t k = cands[v].job;
@@ -356,8 +365,7 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
     int rc;
     if ((rc = nchmm_put_models_scaled(ctx, 0, cands.size(), model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
     if ((rc = nchmm_put_transitions_fast(ctx, 0, cands.size(), t_skip.data(), t_stay.data()))) return rc;
-    std::unique_ptr<uint16_t[]> states_b(new uint16_t[tot + 1]);
-    uint16_t* const states = states_b.get();
+    uint16_t* const states = stg.states.get();
     std::vector<float> logp(cands.size());
     std::vector<int32_t> status(cands.size());
     const auto t_1 = std::chrono::steady_clock::now();
