@@ -50,3 +50,32 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"#\s*include[^\n]*oracle|import\s+nc_oracle|from\s+nc_oracle|libnc_oracle|libnc_ref|dlopen[^\n]*oracle", t):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/nanocall_hip.h must compile as C99 (-pedantic) and a C program must link against
+    the library and call a device-free entry point."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "nanocall_hip.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include <stdio.h>\n#include "nanocall_hip.h"\n'
+                   'int main(void) { unsigned short km[4096]; unsigned n = 0; int rc = nchmm_st_train_kmers(km, &n);\n'
+                   '  printf("%d %d %u %s\\n", nchmm_abi_version(), rc, n, nchmm_strerror(NCHMM_E_NO_DEVICE)); return rc; }\n')
+    exe = tmp_path / "use_abi"
+    libdir = os.path.join(root, "nanocall_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-L", libdir, "-lnanocall_hip",
+                        "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ver, rc, n, *msg = r.stdout.split()
+    import nanocall_amd as na
+    assert int(ver) == 1 and int(rc) == 0 and int(n) == len(na.st_train_kmers())
+    assert "no CPU fallback" in r.stdout
