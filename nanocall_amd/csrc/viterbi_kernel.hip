@@ -162,7 +162,9 @@ __device__ __forceinline__ unsigned tab_off(unsigned tau, unsigned chunk)
 // (value, index) merge: take b if b.v > a.v, or equal and lower index
 __device__ __forceinline__ void merge_lower(float& av, unsigned& ai, float bv, unsigned bi)
 {
-    const mask_t m = ballot(bv > av || (bv == av && bi < ai));
+    // three compares into SGPR masks combined on the scalar unit (a short-circuit expression makes the compiler branch
+    // and round-trip the mask through a VGPR)
+    const mask_t m = ballot(bv > av) | (ballot(bv == av) & ballot(bi < ai));
     av = selm(m, bv, av);
     ai = selm(m, bi, ai);
 }
@@ -211,8 +213,8 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
         const float c = 0x1.8p-24f;   // 0.75 ulp relative: RN(m + m*c) is the next float below a negative m
         const float p0 = __builtin_fmaf(m4[0], c, m4[0]), p1 = __builtin_fmaf(m4[1], c, m4[1]);
         const float p2 = __builtin_fmaf(m16, c, m16);
-        const bool unsafe = (S.w1[0] + p0 >= s1[0]) || (S.w1[1] + p1 >= s1[1]) || (S.w2 + p2 >= s2);
-        if (ballot(unsafe) != 0) {
+        const mask_t unsafe = ballot(S.w1[0] + p0 >= s1[0]) | ballot(S.w1[1] + p1 >= s1[1]) | ballot(S.w2 + p2 >= s2);
+        if (unsafe != 0) {
             // exact scan on the sums themselves (Viterbi.hpp:79-89 restricted to one class)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
