@@ -74,6 +74,18 @@ def measured_traffic(n_reads, n_events):
     return None
 
 
+def measured_valu(n_reads, n_events):
+    """VALU wave-instructions per thread and event of viterbi_kernel from the same committed PMC pass (SQ_INSTS_VALU /
+    (events x 8 waves per block)): the kernel is bound by VALU issue, not by HBM -- reported next to the contract's HBM roofline."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_c2.json")))
+        if t["workload"] == {"reads": n_reads, "events": n_events}:
+            return round(t["viterbi_kernel"]["SQ_INSTS_VALU"] / (n_reads * n_events * 8.0), 1)
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,7 +208,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(n_reads, n_events),
                          "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3), "traceback_kernel_ms": round(tb_ms, 3),
-                         "bytes_per_event": BYTES_PER_EVENT, "events_per_launch": total},
+                         "bytes_per_event": BYTES_PER_EVENT, "events_per_launch": total,
+                         "valu_instructions_per_thread_event": measured_valu(n_reads, n_events)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
         }
         if world == 1 and not args.no_cpu_baseline:
