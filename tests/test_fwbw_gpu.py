@@ -377,3 +377,33 @@ def test_em_round_equals_fwbw_plus_host_finish(gpu_ctx):
         new, done = api.train_pm_solve(b - a, got["acc"][r], pm[r], train_drift=True)
         assert done == exp_done
         assert np.allclose(new, exp, rtol=1e-6, atol=1e-9), (r, new, exp)
+
+
+def test_em_round_edge_shapes(gpu_ctx, r73t):
+    """nchmm_em_round with windows of 0, 1 and 2 events, a job of a single window, and no jobs at all."""
+    from nanocall_amd import api
+    ev = synth.generate(r73t, 1, 300, first_read=4)
+    mean, stdv, start = ev["mean"][0], ev["stdv"][0], ev["start"][0]
+    _, stdv, lsd = na.events_prepare(mean, stdv, None, 0.0)
+    pm = np.float32([1.0, 0.2, 0.001, 1.0, 1.0, 1.0])
+    gpu_ctx.put_model(50, na.scaled_model_table(r73t, pm))
+    gpu_ctx.put_transitions(50, *na.transitions_fast(0.3, 0.1))
+    gpu_ctx.em_load_events(mean, stdv, start, lsd)
+    src, ln = [0, 10, 20, 100, 299], [1, 2, 57, 0, 1]
+    n_win = len(src)
+    stp = np.tile(np.float32([0.1, 0.3]), (n_win, 1))
+    got = gpu_ctx.em_round(src, ln, np.full(n_win, pm[2]), pm, np.full(n_win, 50), np.full(n_win, 50), stp, [0, 3, 4, 5])
+    assert got["acc"].shape == (3, 13)
+    off = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+    idx = np.concatenate([np.arange(b, b + n) for b, n in zip(src, ln)])
+    cm = (mean[idx] - pm[2] * start[idx]).astype(np.float32)
+    ref = gpu_ctx.fwbw(off, cm, stdv[idx], lsd[idx], scaled_slot=np.full(n_win, 50), pm_params=pm, trans_slot=np.full(n_win, 50), st_params=stp)
+    assert np.array_equal(got["log_pr_data"], ref["log_pr_data"], equal_nan=True)
+    assert np.array_equal(got["st_sums"], ref["st_sums"], equal_nan=True)
+    # job 1 is the empty window: all sums zero; job 2 the one-event window at the end of the read
+    assert np.all(got["acc"][1] == 0.0)
+    s = ref["pm_sums"][-1].astype(np.float64)
+    assert np.isclose(got["acc"][2][0], s[0]) and np.isclose(got["acc"][2][3], np.float32(ref["pm_sums"][-1][0] * mean[299]))
+    # no jobs: only log-likelihoods / transition sums come back
+    only = gpu_ctx.em_round(src[:3], ln[:3], np.full(3, pm[2]), pm, np.full(3, 50), np.full(3, 50), stp[:3], [0])
+    assert only["acc"].shape == (0, 13) and np.array_equal(only["log_pr_data"], ref["log_pr_data"][:3])
