@@ -15,6 +15,9 @@ def pytest_configure(config):
     # the oracle is the checker: build it if its .so is absent (gcc only, ~2 s)
     if not os.path.exists(os.path.join(ROOT, "oracle", "libnc_oracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True, capture_output=True)
+    # the reference's own Kmer.hpp / Builtin_Model.cpp compiled as they lie (only where /root/reference exists)
+    if os.path.isdir("/root/reference/src/nanocall") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libnc_ref.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=False, capture_output=True)
     # the product library must already be built (python -c 'import __graft_entry__ as g; g.build()');
     # build it here only when hipcc is available and the .so is missing
     so = os.path.join(ROOT, "nanocall_amd", "libnanocall_hip.so")
