@@ -119,9 +119,15 @@ int nchmm_train_pm_solve(size_t n_events, const double acc[13], int train_drift,
 int nchmm_create(nchmm_ctx** out, int device_id);
 int nchmm_destroy(nchmm_ctx* ctx);
 int nchmm_last_hip_error(const nchmm_ctx* ctx); /* raw hipError_t of the last failure */
-/* run later launches on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
- * context's own stream */
+/* Run later launches on a caller-owned hipStream_t, taken as is: the handle 0 IS the legacy default
+ * (null) stream -- which is what torch.cuda.current_stream().cuda_stream returns unless the caller made
+ * its own stream.  Ordering contract of the *_dev entry points: they enqueue on the context's current
+ * stream and return; their inputs must be complete on that stream (or synchronised) before the call and
+ * their outputs are valid once that stream reaches the end of the enqueued work.  The context's own stream
+ * is hipStreamNonBlocking, i.e. NOT ordered against the null stream: either hand the library the stream your
+ * producers / consumers use, or call nchmm_synchronize().  nchmm_use_own_stream() goes back to the private one. */
 int nchmm_set_stream(nchmm_ctx* ctx, void* hip_stream);
+int nchmm_use_own_stream(nchmm_ctx* ctx);
 int nchmm_synchronize(nchmm_ctx* ctx);
 
 /* Register a scaled pore model in `slot` (0 <= slot < reserved slots, 64 by default): what basecall_strand builds with
@@ -306,7 +312,9 @@ int nchmm_last_kernel_ms(nchmm_ctx* ctx, float out[4]);
 /* Phase counters of the Viterbi kernel, accumulated over launches while the environment variable
  * NCHMM_PROFILE=1 was set at nchmm_create time: out[0] = forward-sweep ticks summed over blocks,
  * [1] = unused, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks), [4] = traceback
- * segments that had to be re-walked, [5] = speculative traceback segments, [6..7] reserved. */
+ * segments that had to be re-walked, [5] = speculative traceback segments, [6] = wave-columns of the forward sweep
+ * that took the exact sum-by-sum group rescan (a smaller alpha could round to the winner's sum), [7] = 3-way combines
+ * (per wave and cell) that took the exact lowest-predecessor-index rule because two class winners were equal. */
 int nchmm_profile_ticks(nchmm_ctx* ctx, uint64_t out[8], int reset);
 /* (start, end) wall_clock64 ticks of the first 2048 blocks of the last profiled Viterbi launch */
 int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "nchmm_destroy": (C.c_int, [vp]),
     "nchmm_last_hip_error": (C.c_int, [vp]),
     "nchmm_set_stream": (C.c_int, [vp, vp]),
+    "nchmm_use_own_stream": (C.c_int, [vp]),
     "nchmm_synchronize": (C.c_int, [vp]),
     "nchmm_put_model": (C.c_int, [vp, C.c_int, vp]),
     "nchmm_put_transitions": (C.c_int, [vp, C.c_int, vp, vp, vp]),

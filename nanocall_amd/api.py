@@ -223,7 +223,11 @@ class Context:
               "nchmm_put_transitions_fast")
 
     def set_stream(self, hip_stream_ptr):
+        """Launch on the caller's hipStream_t; 0 is the legacy default stream (torch's default stream)."""
         check(lib().nchmm_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)), "nchmm_set_stream")
+
+    def use_own_stream(self):
+        check(lib().nchmm_use_own_stream(self._h), "nchmm_use_own_stream")
 
     def synchronize(self):
         check(lib().nchmm_synchronize(self._h), "nchmm_synchronize")

@@ -20,6 +20,7 @@ struct nchmm_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    bool external_stream = false;   // stream was set by the caller (0 is then the legacy default stream)
     int last_hip = 0;
     int n_cu = 0;
     int vit_slots = 0;
@@ -287,7 +288,7 @@ int pinned(nchmm_ctx* c, size_t bytes, void** out)
 int reserve_slots(nchmm_ctx* c, int n)
 {
     if (n <= c->n_slots) return NCHMM_OK;
-    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
     auto grow = [&](void** p, size_t elem_bytes) -> int {
         void* q = nullptr;
         int rc = dev_alloc(c, &q, elem_bytes * (size_t)n);
@@ -392,7 +393,7 @@ int nchmm_destroy(nchmm_ctx* c)
 {
     if (!c) return NCHMM_E_INVALID;
     if (c->device >= 0) (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_trans) (void)hipFree(c->d_trans);
     if (c->d_trans_fb) (void)hipFree(c->d_trans_fb);
@@ -425,7 +426,16 @@ int nchmm_last_hip_error(const nchmm_ctx* c) { return c ? c->last_hip : 0; }
 int nchmm_set_stream(nchmm_ctx* c, void* s)
 {
     if (!c) return NCHMM_E_INVALID;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;   // 0 = the legacy default stream, not "mine" (nchmm_use_own_stream)
+    c->external_stream = true;
+    return NCHMM_OK;
+}
+
+int nchmm_use_own_stream(nchmm_ctx* c)
+{
+    if (!c) return NCHMM_E_INVALID;
+    c->stream = c->own_stream;
+    c->external_stream = false;
     return NCHMM_OK;
 }
 

@@ -42,7 +42,7 @@ const char* nchmm_strerror(int code)
     }
 }
 
-int nchmm_abi_version(void) { return 1; }
+int nchmm_abi_version(void) { return 2; }
 
 // Pore_Model::load_from_vector, Pore_Model.hpp:220-239 (+ update_sd_lambda :112, update_logs :118-124)
 int nchmm_model_load(const float* table, float* state)

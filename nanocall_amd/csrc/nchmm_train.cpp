@@ -380,15 +380,19 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
         const size_t k = cands[v].job;
         const int r = job_read[k];
         const bool two_d = job_m0[k] >= 0 && job_m1[k] >= 0;
+        // A candidate that failed to decode (status != 0, NaN log-probability) must not shadow a later valid one: the
+        // reference's `sort` has no defined order with a NaN key, here a NaN ranks below everything (-INF) and is kept
+        // only while nothing else has been seen.
+        auto key = [](float x) { return std::isnan(x) ? -std::numeric_limits<float>::infinity() : x; };
         if (two_d && v + 1 < cands.size() && cands[v + 1].job == k) {
-            const float tot = logp[v] + logp[v + 1];
+            const float tot = key(logp[v] + logp[v + 1]);
             if (tot >= best_total[2 * r] || best_c0[2 * r] < 0) { best_total[2 * r] = tot; best_c0[2 * r] = (long)v; best_c1[2 * r] = (long)v + 1; }
             v += 2;
         } else {
             const int s = cands[v].strand;
-            if (!two_d && (logp[v] >= best_total[2 * r + s] || best_c0[2 * r + s] < 0)) {
+            if (!two_d && (key(logp[v]) >= best_total[2 * r + s] || best_c0[2 * r + s] < 0)) {
                 // a 1D job on a read that also has a 2D winner is a different mode; the caller passes one mode per read
-                best_total[2 * r + s] = logp[v]; best_c0[2 * r + s] = (long)v; best_c1[2 * r + s] = -1;
+                best_total[2 * r + s] = key(logp[v]); best_c0[2 * r + s] = (long)v; best_c1[2 * r + s] = -1;
             }
             v += 1;
         }

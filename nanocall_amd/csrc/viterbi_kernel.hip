@@ -149,6 +149,9 @@ struct State {
     float mu[8], sg[8], rsg[8], eta[8], reta[8], lam[8], alpha[8];
     float w1[2];   // step groups r = (y<<8)|t for y = h, h+2
     float w2;      // skip group q = t
+    // wave-uniform tallies (SGPRs) of the two exactness branches, reported through P.prof[6..7]:
+    // columns that took the sum-by-sum rescan, cells' 3-way combines that took the lowest-index rule
+    unsigned n_rescan, n_tie;
 };
 
 // Three per-state tables that are touched once per cell (-log sigma, log lambda - log 2pi, stay weight)
@@ -215,6 +218,7 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
         const float p2 = __builtin_fmaf(m16, c, m16);
         const mask_t unsafe = ballot(S.w1[0] + p0 >= s1[0]) | ballot(S.w1[1] + p1 >= s1[1]) | ballot(S.w2 + p2 >= s2);
         if (unsafe != 0) {
+            ++S.n_rescan;
             // exact scan on the sums themselves (Viterbi.hpp:79-89 restricted to one class)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -278,6 +282,7 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
             // matters: the read is then reported NCHMM_E_NUMERIC by the final arg-max)
             const mask_t tie = (e0 & e1) | ((e0 | e1) & e2);
             if (tie != 0) {
+                ++S.n_tie;
                 // exact rule: first maximum in ascending predecessor order (strict >, NaN never wins)
                 const unsigned j = t + 256u * k;
                 const unsigned p1 = ((a.s - 1u) << 10) | r1;
@@ -392,6 +397,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         S.w1[0] = W[kStates + (h << 8) + t];
         S.w1[1] = W[kStates + ((2u + h) << 8) + t];
         S.w2 = W[kStates + 1024 + t];
+        S.n_rescan = 0; S.n_tie = 0;
 
         for (unsigned base = 0; base < n; base += kChunk) {
             {
@@ -486,6 +492,10 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
             const unsigned long long c2 = wall_clock64();
             t_fwd += c1 - c0;
             t_tb += c2 - c1;
+            if ((tau & 63u) == 0) {   // per wave: the branches are wave-uniform
+                atomicAdd(&P.prof[6], (unsigned long long)S.n_rescan);
+                atomicAdd(&P.prof[7], (unsigned long long)S.n_tie);
+            }
         }
         // the other waves wait for the traceback at the top-of-loop barrier; the workspace is reused
     }
@@ -526,7 +536,7 @@ constexpr int kTbWaves = 8;      // traceback segments per read (one wave each)
 template <int LEVELS>
 __device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsigned s, int ev_hi, int ev_lo, int ev_write_hi,
                                           int mark, unsigned* mark_state, unsigned lane, uint8_t (*sStage)[16],
-                                          uint16_t* sOut, unsigned& bad)
+                                          uint16_t* sOut, unsigned& bad, int bad_hi)
 {
     unsigned rowoff, sh, msk, hi;
     if (lane == 0) { rowoff = 0; sh = 0; msk = 255; hi = 0; }
@@ -547,22 +557,24 @@ __device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsig
         __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
         __builtin_amdgcn_wave_barrier();
         unsigned sc0, sc1, sc2;
+        // an unreachable cell (no predecessor: every candidate -INF/NaN) carries no back-pointer.  It only counts when the
+        // walk is known to be on the true path: rows above bad_hi belong to the speculative run-in of a segment.
         unsigned slot = sStage[0][bp_pos(s >> 8)];
-        bad |= slot > 20u;
+        bad |= (slot > 20u) & (unsigned)(cur <= bad_hi);
         s = pred_uniform(s, slot > 20u ? 0u : slot, sc0);
         const unsigned s_a = s;
         unsigned s_b = s, s_c = s;
         int done = 1;
         if (cur - 1 > ev_lo) {
             slot = sStage[1 + sc0][bp_pos(s >> 8)];
-            bad |= slot > 20u;
+            bad |= (slot > 20u) & (unsigned)(cur - 1 <= bad_hi);
             s = pred_uniform(s, slot > 20u ? 0u : slot, sc1);
             s_b = s; done = 2;
             if (LEVELS == 3 && cur - 2 > ev_lo) {
                 const unsigned tot = sc0 + sc1;
                 const unsigned ln = tot <= 2 ? 4u + tot : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
                 slot = sStage[ln][bp_pos(s >> 8)];
-                bad |= slot > 20u;
+                bad |= (slot > 20u) & (unsigned)(cur - 2 <= bad_hi);
                 s = pred_uniform(s, slot > 20u ? 0u : slot, sc2);
                 s_c = s; done = 3;
             }
@@ -632,8 +644,8 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
         const int lo = (int)wave * L;
         if ((int)wave == K - 1) {
             if (lane == 0) os[n - 1] = (uint16_t)s_last;
-            const unsigned s_lo = K == 1 ? chase<3>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad)
-                                         : chase<2>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad);
+            const unsigned s_lo = K == 1 ? chase<3>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad, n)
+                                         : chase<2>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad, n);
             if (lane == 0) sLow[wave] = s_lo;
         } else {
             const int own_hi = lo + L - 1;             // highest event this segment owns
@@ -641,7 +653,10 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
             if (start > n - 1) start = n - 1;
             unsigned tent = 0xFFFFFFFFu;
             // the state at event own_hi+1 is the first one compared with the segment above
-            const unsigned s_lo = chase<2>(ws, os, 0u, start, lo, own_hi, own_hi + 1, &tent, lane, sStage[wave], sOut[wave], bad);
+            // `bad` of this walk is only meaningful from the boundary row down, and only if the walk turns out to have
+            // merged with the true path there (wave 0 decides; otherwise the segment is walked again)
+            const unsigned s_lo = chase<2>(ws, os, 0u, start, lo, own_hi, own_hi + 1, &tent, lane, sStage[wave], sOut[wave], bad,
+                                           own_hi + 1);
             if (start == own_hi + 1) tent = 0u;        // no margin left: the guess itself sits on the boundary
             if (lane == 0) { sLow[wave] = s_lo; sTent[wave] = tent; }
         }
@@ -649,16 +664,17 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
     if (lane == 0) sBad[wave] = bad;
     __syncthreads();
     if (wave == 0) {
-        unsigned any_bad = 0;
-        for (int w = 0; w < K; ++w) any_bad |= sBad[w];
+        unsigned any_bad = sBad[K - 1];                // the top segment starts from the true last state
         unsigned refix = 0;
         for (int w = K - 2; w >= 0; --w) {
             const unsigned truth = sLow[w + 1];        // true state at event (w+1)*L
-            if (sTent[w] != truth) {
+            if (sTent[w] == truth) {
+                any_bad |= sBad[w];                    // merged: what it walked from the boundary down was the true path
+            } else {
                 // speculation had not merged: walk this segment again from the true state
                 unsigned b2 = 0;
                 const unsigned s_lo = chase<3>(ws, os, truth, (w + 1) * L, w * L, (w + 1) * L - 1, -1, nullptr, lane, sStage[0],
-                                            sOut[0], b2);
+                                            sOut[0], b2, n);
                 any_bad |= b2;
                 if (lane == 0) sLow[w] = s_lo;
                 __builtin_amdgcn_s_waitcnt(0);

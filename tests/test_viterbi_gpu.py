@@ -245,3 +245,68 @@ def test_batched_uploads_equal_single_uploads(gpu_ctx, r73t, r9t):
         s_b, lp_b, _ = gpu_ctx.viterbi(off, cm, sd, ls, model_slot=slot, trans_slot=slot)
         s_s, lp_s, _ = _run(gpu_ctx, tables[k], params[k], trans[k][0], trans[k][1], off, cm, sd, ls, slot=7)
         assert np.array_equal(s_b, s_s) and lp_b.tobytes() == lp_s.tobytes()
+
+
+def _profiled_ctx():
+    import os
+    os.environ["NCHMM_PROFILE"] = "1"
+    try:
+        return na.Context(0)
+    finally:
+        del os.environ["NCHMM_PROFILE"]
+
+
+def test_exactness_branches_are_exercised(r73t):
+    """The raw-alpha group scans and the max3 combine are bit-exact only because of two rare branches: the
+    sum-by-sum rescan (a smaller alpha could round to the winner's sum) and the lowest-predecessor-index rule
+    (two class winners equal).  Count them (nchmm_profile_ticks()[6..7]) on inputs where they must fire and on
+    an ordinary read where at least the tie rule does (866 exact ties in a 3k-event read)."""
+    ctx = _profiled_ctx()
+    try:
+        # (1) every state identical: every 3-way combine is a tie
+        t = r73t.copy()
+        t[:, :] = t[0, :]
+        n = 50
+        cm, sd, ls = na.events_prepare(np.full(n, t[0, 0], np.float32), np.full(n, t[0, 2], np.float32), None, 0.0)
+        off = np.array([0, n], np.uint64)
+        states, logp, _ = _run(ctx, t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        tk = ctx.profile_ticks()
+        assert tk[7] > 0, "the exact tie rule never ran on all-equal alphas"
+        ostates, ologp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        assert np.array_equal(states, ostates)
+        assert_bits_equal(logp, ologp, "path probability")
+        # (2) an ordinary 5000-event read: alphas of order -1e4 have an ulp of ~1e-3, exact ties happen
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [5000], first_read=0)
+        states, logp, _ = _run(ctx, r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        tk = ctx.profile_ticks()
+        assert tk[7] > 0, "no exact tie in a 5000-event read"
+        assert tk[6] > 0, "no rescan in a 5000-event read"
+        ostates, ologp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        assert np.array_equal(states, ostates)
+        assert_bits_equal(logp, ologp, "path probability")
+    finally:
+        ctx.close()
+
+
+def test_unreachable_state_off_the_true_path_is_not_an_error(r73t):
+    """The speculative traceback segments start from state 0.  Make state 0 unreachable -- every predecessor of
+    AAAAAA (the 16 states 256*k) gets a -INF emission -- so that its back-pointer cell is empty at every event:
+    a speculative walk sits on it until it is discarded, while the true path never goes near it.  The read must
+    decode (status 0) exactly as the oracle does."""
+    t = r73t.copy()
+    t[np.arange(16) * 256, 0] = np.inf        # level_mean = +INF: (x - mu) / sigma = -INF, log_normal_pdf = -INF
+    lens = [4100, 1500, 700]                   # 8, 2 and 1 traceback segments
+    off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=77)
+    ctx = _profiled_ctx()
+    try:
+        with np.errstate(all="ignore"):
+            states, logp, status = _run(ctx, t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+            ostates, ologp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        tk = ctx.profile_ticks()
+    finally:
+        ctx.close()
+    assert tk[5] > 0, "no speculative segment ran"
+    assert (status == 0).all(), status
+    assert np.array_equal(states, ostates)
+    assert_bits_equal(logp, ologp, "path probability")
+    assert not np.isin(states, np.arange(16) * 256).any()

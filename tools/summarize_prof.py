@@ -17,6 +17,7 @@ print("== kernel stats (rocprofv3 --kernel-trace --stats, same command) ==")
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+traffic = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -30,3 +31,24 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             acc[(kn.split("(")[0], row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (kn, cn), v in sorted(acc.items()):
         print(f"  {kn:28s} {cn:24s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+        short = kn.split("::")[-1]
+        if cn in ("FETCH_SIZE", "WRITE_SIZE"):
+            traffic[short][cn + "_KiB"] = sum(v) / len(v)
+        elif cn == "SQ_INSTS_VALU":
+            traffic[short][cn] = sum(v) / len(v)
+# the figures bench.py replays for roofline.traffic / valu_floor_ms, keyed on the kernel source so they cannot go stale
+if "viterbi_kernel" in traffic and "FETCH_SIZE_KiB" in traffic["viterbi_kernel"] and "WRITE_SIZE_KiB" in traffic["viterbi_kernel"]:
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("viterbi_kernel.hip", "nchmm_device.h"):
+        h.update(open(os.path.join(root, "nanocall_amd", "csrc", f), "rb").read())
+    reads, events = int(os.environ.get("PROF_READS", 1024)), int(os.environ.get("PROF_EVENTS", 5000))
+    doc = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_INSTS_VALU (separate passes, tools/gpu_profile.sh), per-dispatch means. "
+                       "FETCH_SIZE as reported: the forward kernel's reads are scalar/uniform loads and 12 B/event, not the 16-B/lane streaming "
+                       "pattern the microarch guide's 2x under-count applies to; writes are 8-byte-per-lane coalesced stores.",
+           "workload": {"reads": reads, "events": events}, "kernel_source_sha256_16": h.hexdigest()[:16]}
+    doc.update(traffic)
+    json.dump(doc, open(os.path.join(out, "hbm_traffic_c2.json"), "w"), indent=1)
+    print("== wrote", os.path.join(out, "hbm_traffic_c2.json"))
