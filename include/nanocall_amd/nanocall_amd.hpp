@@ -28,11 +28,16 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
 #include <map>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -55,7 +60,10 @@ public:
         static thread_local Device d;
         return d;
     }
-    static int& device_id() { static int id = 0; return id; }
+    // the GPU this thread's context lives on: per thread, so that a host with one worker thread per device (the
+    // read-parallel pfor of nanocall.cpp:282,611, one GPU per worker) can drive every GPU of the node.  Set it before
+    // the thread's first ctx() call.
+    static int& device_id() { static thread_local int id = 0; return id; }
     nchmm_ctx* ctx()
     {
         if (!_ctx) check(nchmm_create(&_ctx, device_id()), "nchmm_create");
@@ -133,6 +141,18 @@ public:
         log_stdv = std::log(stdv);
     }
     void set_model_state(const std::string& s) { std::copy_n(s.begin(), Kmer_Size, model_state.begin()); }
+    friend std::ostream& operator<<(std::ostream& os, const Event& ev)   // Event.hpp:51-58
+    {
+        os << ev.mean << '\t' << ev.stdv << '\t' << ev.start << '\t' << ev.length;
+        return os;
+    }
+    friend std::istream& operator>>(std::istream& is, Event& ev)   // Event.hpp:59-68
+    {
+        is >> ev.mean >> ev.stdv >> ev.start >> ev.length;
+        ev.corrected_mean = ev.mean;
+        ev.update_logs();
+        return is;
+    }
 };
 
 template <typename Float_Type = float, unsigned Kmer_Size = 6>
@@ -165,6 +185,17 @@ struct Event_Sequence : std::vector<Event<Float_Type, Kmer_Size>> {
 template <typename Float_Type = float>
 struct Pore_Model_Parameters {
     Float_Type scale = 1, shift = 0, drift = 0, var = 1, scale_sd = 1, var_sd = 1;
+    friend std::ostream& operator<<(std::ostream& os, const Pore_Model_Parameters& p)   // Pore_Model.hpp:66-71
+    {
+        os << "[scale=" << p.scale << " shift=" << p.shift << " drift=" << p.drift << " var=" << p.var << " scale_sd=" << p.scale_sd
+           << " var_sd=" << p.var_sd << "]";
+        return os;
+    }
+    void write_tsv(std::ostream& os) const   // Pore_Model.hpp:72-76 (the manipulators stay set on the stream, as there)
+    {
+        os << std::fixed << std::setprecision(5) << scale << '\t' << shift << '\t' << drift << '\t' << var << '\t' << scale_sd << '\t'
+           << var_sd;
+    }
 };
 
 template <typename Float_Type = float, unsigned Kmer_Size = 6>
@@ -186,6 +217,9 @@ public:
     void clear() { _state.clear(); }
     const Pore_Model_State_Type& state(unsigned i) const { return _state.at(i); }
     Pore_Model_State_Type& state(unsigned i) { return _state.at(i); }
+    const std::vector<Pore_Model_State_Type>& get_state_vector() const { return _state; }   // Pore_Model.hpp:183
+    // the library's S x 10 layout (nchmm_put_models_scaled, nchmm_train_reads, ... take tables in this form)
+    const float* data() const { return reinterpret_cast<const float*>(_state.data()); }
     const unsigned& strand() const { return _strand; }
     unsigned& strand() { return _strand; }
     Float_Type mean() const { return _mean; }
@@ -218,6 +252,40 @@ public:
                         / static_cast<Float_Type>(2.0);
         return n + ig;
     }
+    // Pore_Model.hpp:241-249: one line per state, "kmer level_mean level_stdv sd_mean sd_stdv"
+    friend std::ostream& operator<<(std::ostream& os, const Pore_Model& pm)
+    {
+        for (unsigned i = 0; i < pm._state.size(); ++i) {
+            const auto& s = pm._state[i];
+            os << Kmer<Kmer_Size>::to_string(i) << '\t' << s.level_mean << '\t' << s.level_stdv << '\t' << s.sd_mean << '\t' << s.sd_stdv
+               << std::endl;
+        }
+        return os;
+    }
+    // Pore_Model.hpp:251-287: rows in any order ('#' and header lines skipped), sorted by k-mer; anything but 4096
+    // distinct k-mers is an error (the reference logs and exits; this throws)
+    friend std::istream& operator>>(std::istream& is, Pore_Model& pm)
+    {
+        std::vector<float> table(n_states * 4, 0.f);
+        std::vector<char> seen(n_states, 0);
+        unsigned n = 0;
+        std::string line;
+        while (std::getline(is, line)) {
+            std::istringstream iss(line);
+            std::string k;
+            iss >> k;
+            if (k.empty() || k[0] == '#') continue;
+            if (line.find("kmer") != std::string::npos) continue;
+            const size_t j = k.size() == Kmer_Size ? Kmer<Kmer_Size>::to_int(k) : n_states;
+            if (j >= n_states || seen[j]) throw Error(NCHMM_E_INVALID, "Pore_Model >>: unexpected k-mer");
+            seen[j] = 1;
+            iss >> table[4 * j] >> table[4 * j + 1] >> table[4 * j + 2] >> table[4 * j + 3];
+            ++n;
+        }
+        if (n != n_states) throw Error(NCHMM_E_INVALID, "Pore_Model >>: unexpected number of states");
+        pm.load_from_vector(table);
+        return is;
+    }
     // upload as the library's S x 6 table into `slot`
     void put(int slot) const
     {
@@ -229,13 +297,23 @@ private:
     std::vector<Pore_Model_State_Type> _state;
     Float_Type _mean = 0, _stdv = 0;
     unsigned _strand;
-    void update_statistics()   // Pore_Model.hpp:307-313; alg::mean_stdv_of is hpptools (absent): mean + sample stdv
+    void update_statistics()   // Pore_Model.hpp:307-313; alg::mean_stdv_of is hpptools (absent): nchmm_mean_stdv states what is assumed
     {
-        double s = 0, s2 = 0;
-        for (const auto& st : _state) { s += st.level_mean; s2 += (double)st.level_mean * st.level_mean; }
-        const double n = (double)_state.size();
-        _mean = (Float_Type)(s / n);
-        _stdv = (Float_Type)std::sqrt(std::max(0.0, (s2 - s * s / n) / (n - 1)));
+        std::vector<float> lv(_state.size());
+        for (size_t i = 0; i < _state.size(); ++i) lv[i] = _state[i].level_mean;
+        check(nchmm_mean_stdv(lv.size(), lv.data(), &_mean, &_stdv), "nchmm_mean_stdv");
+    }
+};
+
+// Builtin_Model (Builtin_Model.hpp:7-13): the same four members, served by the library
+struct Builtin_Model {
+    static unsigned num() { return (unsigned)nchmm_builtin_count(); }
+    static std::string names(unsigned i) { const char* n = nchmm_builtin_name((int)i); return n ? n : ""; }
+    static unsigned strands(unsigned i) { return (unsigned)nchmm_builtin_strand((int)i); }
+    static std::vector<float> init_lists(unsigned i)
+    {
+        const float* t = nchmm_builtin_table((int)i);
+        return t ? std::vector<float>(t, t + 4096 * 4) : std::vector<float>();
     }
 };
 template <typename Float_Type, unsigned Kmer_Size>
@@ -251,6 +329,15 @@ struct State_Transition_Parameters {
     static Float_Type& default_p_skip() { static Float_Type v = .28; return v; }
     State_Transition_Parameters() : p_stay(default_p_stay()), p_skip(default_p_skip()) {}
     bool is_default() const { return p_stay == default_p_stay() && p_skip == default_p_skip(); }
+    friend std::ostream& operator<<(std::ostream& os, const State_Transition_Parameters& stp)   // State_Transitions.hpp:39-44
+    {
+        os << "[p_stay=" << stp.p_stay << " p_skip=" << stp.p_skip << "]";
+        return os;
+    }
+    void write_tsv(std::ostream& os) const   // :45-50
+    {
+        os << std::fixed << std::setprecision(5) << p_stay << '\t' << p_skip;
+    }
 };
 
 template <typename Float_Type = float>
@@ -274,6 +361,7 @@ public:
         check(nchmm_transitions_fast(p_skip_default, p_stay, _row_ptr.data(), _pred.data(), _logw.data(), &n),
               "nchmm_transitions_fast");
         _pred.resize(n); _logw.resize(n); _nb.clear();
+        _p_skip = p_skip_default; _p_stay = p_stay;
     }
     void compute_transitions_fast(const State_Transition_Parameters_Type& stp) { compute_transitions_fast(stp.p_skip, stp.p_stay); }
 
@@ -295,7 +383,41 @@ public:
         check(nchmm_put_transitions(Device::instance().ctx(), slot, _row_ptr.data(), _pred.data(), _logw.data()),
               "nchmm_put_transitions");
     }
+    // State_Transitions.hpp:226-236: "kmer_i kmer_j log_p" per arc, by source state
+    friend std::ostream& operator<<(std::ostream& os, const State_Transitions& st)
+    {
+        for (unsigned i = 0; i < n_states && !st.empty(); ++i)
+            for (const auto& p : st.neighbours(i).to_v)
+                os << Kmer<Kmer_Size>::to_string(i) << '\t' << Kmer<Kmer_Size>::to_string(p.first) << '\t' << p.second << std::endl;
+        return os;
+    }
+    // State_Transitions.hpp:237-252 (+ update_fields :79-104: from_v by ascending source).  The arcs are kept as read;
+    // the device accepts them (put) only if they form the stay/step/skip-1 graph (NCHMM_E_TOPOLOGY otherwise).
+    friend std::istream& operator>>(std::istream& is, State_Transitions& st)
+    {
+        std::vector<std::tuple<unsigned, unsigned, Float_Type>> arcs;   // (destination, source, log p)
+        std::string ki, kj;
+        Float_Type p;
+        while (is >> ki >> kj >> p) arcs.emplace_back((unsigned)Kmer<Kmer_Size>::to_int(kj), (unsigned)Kmer<Kmer_Size>::to_int(ki), p);
+        std::stable_sort(arcs.begin(), arcs.end(), [](const std::tuple<unsigned, unsigned, Float_Type>& a,
+                                                      const std::tuple<unsigned, unsigned, Float_Type>& b) {
+            return std::get<0>(a) != std::get<0>(b) ? std::get<0>(a) < std::get<0>(b) : std::get<1>(a) < std::get<1>(b);
+        });
+        st._row_ptr.assign(n_states + 1, 0); st._pred.clear(); st._logw.clear(); st._nb.clear();
+        for (const auto& a : arcs) {
+            if (std::get<0>(a) >= n_states || std::get<1>(a) >= n_states) throw Error(NCHMM_E_INVALID, "State_Transitions >>: bad k-mer");
+            st._row_ptr[std::get<0>(a) + 1]++;
+            st._pred.push_back((uint16_t)std::get<1>(a));
+            st._logw.push_back(std::get<2>(a));
+        }
+        for (unsigned j = 0; j < n_states; ++j) st._row_ptr[j + 1] += st._row_ptr[j];
+        return is;
+    }
+    // the (p_skip, p_stay) this table was computed from by compute_transitions_fast (NaN after operator>>)
+    Float_Type p_skip() const { return _p_skip; }
+    Float_Type p_stay() const { return _p_stay; }
 private:
+    Float_Type _p_skip = std::numeric_limits<Float_Type>::quiet_NaN(), _p_stay = std::numeric_limits<Float_Type>::quiet_NaN();
     std::vector<uint32_t> _row_ptr;
     std::vector<uint16_t> _pred;
     std::vector<float> _logw;

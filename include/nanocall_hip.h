@@ -55,6 +55,14 @@ int nchmm_abi_version(void);
  * Host prep (no GPU).  Bit-exact with the reference's host code.
  * ---------------------------------------------------------------------------------------- */
 
+/* Builtin_Model (src/nanocall/Builtin_Model.hpp:7-13, Builtin_Model.cpp:3-17): num, names[i], strands[i] and
+ * init_lists[i] = S x 4 {level_mean, level_stdv, sd_mean, sd_stdv} in k-mer order.  The tables are data carried inside
+ * the library (nanocall_amd/data/builtin_models.f32). */
+int nchmm_builtin_count(void);
+const char* nchmm_builtin_name(int i);
+int nchmm_builtin_strand(int i);
+const float* nchmm_builtin_table(int i);
+
 /* Pore_Model::load_from_vector, src/nanocall/Pore_Model.hpp:220-239.
  * table: S x 4 {level_mean, level_stdv, sd_mean, sd_stdv}.
  * state: S x 10 {level_mean, level_stdv, sd_mean, sd_stdv, sd_lambda, log_level_mean,
@@ -110,6 +118,60 @@ int nchmm_train_st_finish(size_t n_win, const float* st_sums_nx3, float* p_stay,
  * accumulates on the device. */
 int nchmm_train_pm_solve(size_t n_events, const double acc[13], int train_drift, const float crt_pm[6],
                          float new_pm[6], int* done);
+
+/* ------------------------------------------------------------------------------------------
+ * Read summary: strand segmentation, event filter, initial scaling (host).
+ * Replaces the arithmetic of Fast5_Summary (src/nanocall/Fast5_Summary.hpp) on the EventDetection table of a
+ * read, wherever that table came from (FAST5 through nanocall_fast5.h, or the events text form).
+ * fast5::EventDetection_Event_Entry is declared in the un-vendored fast5 submodule; the layout here (two
+ * doubles, two 64-bit integers: level mean, level stdv, start and length in samples) is what the FAST5
+ * EventDetection dataset stores.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct nchmm_ed_event {
+    double mean, stdv;
+    int64_t start, length;
+} nchmm_ed_event;
+
+typedef struct nchmm_segment_opts {
+    uint32_t min_ed_events;             /* --min-ed-events 10        Fast5_Summary.hpp:74-78 */
+    uint32_t max_ed_events;             /* --max-ed-events 100000    :80-84 */
+    double abasic_level_top_percent;    /* :93-97, set per pore at nanocall.cpp:943-964 */
+    double abasic_level_top_offset;     /* :100-104 */
+    uint32_t template_only;             /* --1d                      :121-125 */
+    uint32_t trim_margins[4];           /* --trim-ed-{sq-start,sq-end,hp-start,hp-end} 50   :128-132 */
+} nchmm_segment_opts;
+
+typedef struct nchmm_read_summary {
+    uint32_t num_ed_events;             /* 0 = the read is skipped (Fast5_Summary.hpp:185-209) */
+    float abasic_level;
+    uint32_t strand_bounds[4];          /* [template begin, end, complement begin, end) in the EventDetection table */
+    int32_t scale_strands_together;
+    float time_length[2];
+} nchmm_read_summary;
+
+/* pore = "r9" or "r73": the presets of nanocall.cpp:943-964; anything else is NCHMM_E_INVALID */
+int nchmm_segment_opts_default(nchmm_segment_opts* opts, const char* pore);
+
+/* alg::mean_stdv_of<float> as the callers use it (Fast5_Summary.hpp:225-230,256-258, Pore_Model.hpp:307-313,
+ * nanocall.cpp:633-635).  hpptools is un-vendored: float accumulation of sum and sum of squares, sample (n-1) stdv. */
+int nchmm_mean_stdv(size_t n, const float* v, float* mean, float* stdv);
+
+/* Fast5_Summary::summarize, Fast5_Summary.hpp:160-219: event cap, abasic level (:528-543), strand detection
+ * (:545-571,653-731), scale_strands_together (:210-212), time lengths.  double_strand_scaling = the constructor's
+ * `sst` argument (opts::double_strand_scaling, nanocall.cpp:269). */
+int nchmm_read_summarize(const nchmm_segment_opts* opts, size_t n_ed, const nchmm_ed_event* ed, float sampling_rate,
+                         int double_strand_scaling, nchmm_read_summary* out);
+
+/* Fast5_Summary::load_events, :348-365: the filtered (:734-745) events of strand st as Event fields (stdv after
+ * Event::update_logs' 0 -> .01; start relative to the strand's -- or, scaled together, the read's -- first event,
+ * in seconds).  The arrays must hold strand_bounds[2st+1] - strand_bounds[2st] entries; *n receives the count. */
+int nchmm_read_load_events(const nchmm_read_summary* s, const nchmm_ed_event* ed, float sampling_rate, int st, float* mean,
+                           float* stdv, float* start, float* length, size_t* n);
+
+/* Initial model scaling, :223-278.  r0 / r1 = {mean, stdv} of the strand's event means, m0 / m1 = {mean, stdv} of the
+ * models' level means.  together != 0: the 2D form (:237-241); else the single-strand form on r0 / m0 (:265-267). */
+int nchmm_initial_scaling(int together, const float r0[2], const float r1[2], const float m0[2], const float m1[2],
+                          float* scale, float* shift);
 
 /* ------------------------------------------------------------------------------------------
  * Device context
@@ -321,6 +383,46 @@ int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);
 
 /* number of resident thread-block slots (persistent grid size) the Viterbi kernel launches */
 int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
+
+/* ------------------------------------------------------------------------------------------
+ * Device pool -- the reference's read-parallel pfor loops (src/nanocall/nanocall.cpp:282-579, :611-866; `-t`
+ * worker threads, one read each) become: one context + one host thread per GPU of the node, reads assigned to
+ * devices by total event count (longest-processing-time first), every device working through its shard with the
+ * batched entry points above.  Reads are independent, so there is no collective on the data path; the only
+ * exchange is the counter reduction of nchmm_pool_counters.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct nchmm_pool nchmm_pool;
+
+int nchmm_device_count(int* n);   /* HIP devices visible to this process (0 and NCHMM_E_NO_DEVICE when none) */
+
+/* device_ids NULL = 0 .. n_devices-1.  An id may repeat (several contexts on one GPU: the host-thread / sharding logic
+ * can then be exercised on a single-GPU machine; the counter reduction then runs on the host instead of RCCL). */
+int nchmm_pool_create(nchmm_pool** out, int n_devices, const int* device_ids);
+int nchmm_pool_destroy(nchmm_pool* pool);
+int nchmm_pool_size(const nchmm_pool* pool);
+nchmm_ctx* nchmm_pool_ctx(nchmm_pool* pool, int i);
+
+/* LPT: items in descending weight (stable) each go to the least-loaded shard (lowest index on ties);
+ * equal weights throughout (BASELINE config 4) give contiguous slices.  shard_of_item[i] in [0, n_shards). */
+int nchmm_lpt_partition(size_t n_items, const uint64_t* weight, int n_shards, int32_t* shard_of_item);
+
+/* nchmm_train_reads / nchmm_basecall_reads over the pool: same arguments and results (job and read indices are the
+ * caller's), the reads sharded across the devices by their event counts, one host thread per device. */
+int nchmm_pool_train_reads(nchmm_pool* pool, const nchmm_train_opts* opts, size_t n_models, const float* model_states_Sx10,
+                           size_t n_reads, const uint64_t* strand_off, const float* mean, const float* stdv, const float* start,
+                           size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1, float* job_pm,
+                           float* job_st, float* job_fit, uint32_t* job_rounds, int32_t* read_preferred);
+int nchmm_pool_basecall_reads(nchmm_pool* pool, const nchmm_train_opts* opts, size_t n_models, const float* model_states_Sx10,
+                              size_t n_reads, const uint64_t* strand_off, const float* mean, const float* stdv, const float* start,
+                              size_t n_jobs, const int32_t* job_read, const int32_t* job_m0, const int32_t* job_m1,
+                              const float* job_pm, const float* job_st, const int32_t* read_preferred, uint16_t* out_state,
+                              int32_t* out_best_job, float* out_best_logp);
+
+/* nchmm_counters summed over the pool's contexts.  With two or more DISTINCT devices the sum is one RCCL all-reduce
+ * (ncclCommInitAll over the pool's devices, single process; librccl is loaded at run time) and *used_rccl = 1;
+ * otherwise (one device, repeated ids, librccl missing) it is a host sum and *used_rccl = 0.  NCHMM_POOL_FORCE_RCCL=1
+ * takes the RCCL path even for a single device.  used_rccl may be NULL. */
+int nchmm_pool_counters(nchmm_pool* pool, uint64_t out[8], int* used_rccl);
 
 #ifdef __cplusplus
 }

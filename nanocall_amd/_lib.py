@@ -22,6 +22,10 @@ vp = C.c_void_p
 SIGNATURES = {
     "nchmm_strerror": (C.c_char_p, [C.c_int]),
     "nchmm_abi_version": (C.c_int, []),
+    "nchmm_builtin_count": (C.c_int, []),
+    "nchmm_builtin_name": (C.c_char_p, [C.c_int]),
+    "nchmm_builtin_strand": (C.c_int, [C.c_int]),
+    "nchmm_builtin_table": (C.POINTER(C.c_float), [C.c_int]),
     "nchmm_model_load": (C.c_int, [vp, vp]),
     "nchmm_model_scale": (C.c_int, [vp, vp]),
     "nchmm_model_pack6": (C.c_int, [vp, vp]),
@@ -33,6 +37,16 @@ SIGNATURES = {
     "nchmm_train_pm_finish": (C.c_int, [C.c_size_t, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
     "nchmm_train_st_finish": (C.c_int, [C.c_size_t, vp, vp, vp]),
     "nchmm_train_pm_solve": (C.c_int, [C.c_size_t, vp, C.c_int, vp, vp, vp]),
+    "nchmm_segment_opts_default": (C.c_int, [vp, C.c_char_p]),
+    "nchmm_mean_stdv": (C.c_int, [C.c_size_t, vp, vp, vp]),
+    "nchmm_read_summarize": (C.c_int, [vp, C.c_size_t, vp, C.c_float, C.c_int, vp]),
+    "nchmm_read_load_events": (C.c_int, [vp, vp, C.c_float, C.c_int, vp, vp, vp, vp, vp]),
+    "nchmm_initial_scaling": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp]),
+    "nchmm_fast5_available": (C.c_int, []),
+    "nchmm_fast5_is_valid_file": (C.c_int, [C.c_char_p]),
+    "nchmm_fast5_load": (C.c_int, [C.c_char_p, C.c_char_p, vp]),
+    "nchmm_fast5_release": (None, [vp]),
+    "nchmm_fast5_last_error": (C.c_char_p, []),
     "nchmm_train_opts_default": (C.c_int, [vp]),
     "nchmm_train_enumerate": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]),
     "nchmm_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),
@@ -59,6 +73,15 @@ SIGNATURES = {
     "nchmm_profile_ticks": (C.c_int, [vp, vp, C.c_int]),
     "nchmm_profile_blocks": (C.c_int, [vp, vp]),
     "nchmm_grid_slots": (C.c_int, [vp, vp]),
+    "nchmm_device_count": (C.c_int, [vp]),
+    "nchmm_pool_create": (C.c_int, [C.POINTER(vp), C.c_int, vp]),
+    "nchmm_pool_destroy": (C.c_int, [vp]),
+    "nchmm_pool_size": (C.c_int, [vp]),
+    "nchmm_pool_ctx": (vp, [vp, C.c_int]),
+    "nchmm_lpt_partition": (C.c_int, [C.c_size_t, vp, C.c_int, vp]),
+    "nchmm_pool_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),
+    "nchmm_pool_basecall_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 9),
+    "nchmm_pool_counters": (C.c_int, [vp, vp, vp]),
 }
 
 
@@ -70,10 +93,31 @@ class TrainOpts(C.Structure):
                 ("default_p_skip", C.c_float)]
 
 
+class SegmentOpts(C.Structure):
+    """nchmm_segment_opts"""
+    _fields_ = [("min_ed_events", C.c_uint32), ("max_ed_events", C.c_uint32), ("abasic_level_top_percent", C.c_double),
+                ("abasic_level_top_offset", C.c_double), ("template_only", C.c_uint32), ("trim_margins", C.c_uint32 * 4)]
+
+
+class ReadSummary(C.Structure):
+    """nchmm_read_summary"""
+    _fields_ = [("num_ed_events", C.c_uint32), ("abasic_level", C.c_float), ("strand_bounds", C.c_uint32 * 4),
+                ("scale_strands_together", C.c_int32), ("time_length", C.c_float * 2)]
+
+
+class Fast5Read(C.Structure):
+    """nchmm_fast5_read"""
+    _fields_ = [("have_sampling_rate", C.c_int32), ("have_events", C.c_int32), ("sampling_rate", C.c_double),
+                ("ed_group", C.c_char * 32), ("read_name", C.c_char * 64), ("read_id", C.c_char * 256),
+                ("n_events", C.c_size_t), ("events", C.c_void_p)]
+
+
 class NchmmError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
         msg = lib().nchmm_strerror(code).decode()
+        if code == -7:
+            msg += ": " + lib().nchmm_fast5_last_error().decode()
         super().__init__(f"{where}: {msg} (code {code})")
 
 

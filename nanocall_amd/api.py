@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import lib, check, NchmmError, TrainOpts  # noqa: F401
+from ._lib import lib, check, NchmmError, TrainOpts, SegmentOpts, ReadSummary, Fast5Read  # noqa: F401
 
 S = 4096
 MAX_ARCS = S * 21
@@ -156,6 +156,81 @@ def train_enumerate(opts, model_strand, strand_off, together):
     check(lib().nchmm_train_enumerate(C.byref(opts), ms.shape[0], _p(ms), n_reads, _p(so), _p(tg), C.byref(n), _p(jr), _p(j0), _p(j1)),
           "nchmm_train_enumerate")
     return jr, j0, j1
+
+
+# ------------------------------------------------------------------------------------------------
+# read summary (Fast5_Summary arithmetic on an EventDetection table)
+# ------------------------------------------------------------------------------------------------
+ED_DTYPE = np.dtype([("mean", "<f8"), ("stdv", "<f8"), ("start", "<i8"), ("length", "<i8")])   # nchmm_ed_event
+
+
+def segment_opts(pore="r9", **kw):
+    o = SegmentOpts()
+    check(lib().nchmm_segment_opts_default(C.byref(o), pore.encode()), "nchmm_segment_opts_default")
+    for k, v in kw.items():
+        if k == "trim_margins":
+            o.trim_margins[:] = list(v)
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def mean_stdv(v):
+    v = _f32(v)
+    m, s = C.c_float(0), C.c_float(0)
+    check(lib().nchmm_mean_stdv(v.shape[0], _p(v), C.byref(m), C.byref(s)), "nchmm_mean_stdv")
+    return np.float32(m.value), np.float32(s.value)
+
+
+def read_summarize(opts, ed, sampling_rate, double_strand_scaling=True):
+    ed = np.ascontiguousarray(ed, ED_DTYPE)
+    out = ReadSummary()
+    check(lib().nchmm_read_summarize(C.byref(opts), ed.shape[0], _p(ed), C.c_float(sampling_rate), int(double_strand_scaling),
+                                     C.byref(out)), "nchmm_read_summarize")
+    return out
+
+
+def read_load_events(summary, ed, sampling_rate, st):
+    """-> (mean, stdv, start, length) float32 arrays of the filtered events of strand st."""
+    ed = np.ascontiguousarray(ed, ED_DTYPE)
+    cap = max(0, int(summary.strand_bounds[2 * st + 1]) - int(summary.strand_bounds[2 * st]))
+    bufs = [np.empty(max(cap, 1), np.float32) for _ in range(4)]
+    n = C.c_size_t(0)
+    check(lib().nchmm_read_load_events(C.byref(summary), _p(ed), C.c_float(sampling_rate), st, *[_p(b) for b in bufs], C.byref(n)),
+          "nchmm_read_load_events")
+    return tuple(b[: n.value].copy() for b in bufs)
+
+
+def initial_scaling(together, r0, r1, m0, m1):
+    a = [None if x is None else _f32(x) for x in (r0, r1, m0, m1)]
+    sc, sh = C.c_float(0), C.c_float(0)
+    check(lib().nchmm_initial_scaling(int(together), *[_p(x) for x in a], C.byref(sc), C.byref(sh)), "nchmm_initial_scaling")
+    return np.float32(sc.value), np.float32(sh.value)
+
+
+# ------------------------------------------------------------------------------------------------
+# FAST5 ingest (include/nanocall_fast5.h)
+# ------------------------------------------------------------------------------------------------
+def fast5_available():
+    return bool(lib().nchmm_fast5_available())
+
+
+def fast5_is_valid_file(path):
+    return bool(lib().nchmm_fast5_is_valid_file(str(path).encode()))
+
+
+def fast5_load(path, ed_group=""):
+    """-> dict(have_sampling_rate, have_events, sampling_rate, ed_group, read_name, read_id, events[ED_DTYPE])"""
+    r = Fast5Read()
+    check(lib().nchmm_fast5_load(str(path).encode(), ed_group.encode(), C.byref(r)), "nchmm_fast5_load")
+    try:
+        ev = np.zeros(r.n_events, ED_DTYPE)
+        if r.n_events:
+            C.memmove(ev.ctypes.data, r.events, r.n_events * ED_DTYPE.itemsize)
+        return dict(have_sampling_rate=bool(r.have_sampling_rate), have_events=bool(r.have_events), sampling_rate=r.sampling_rate,
+                    ed_group=r.ed_group.decode(), read_name=r.read_name.decode(), read_id=r.read_id.decode(), events=ev)
+    finally:
+        lib().nchmm_fast5_release(C.byref(r))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -380,3 +455,85 @@ class Context:
         v = C.c_int(0)
         check(lib().nchmm_grid_slots(self._h, C.byref(v)), "nchmm_grid_slots")
         return v.value
+
+
+# ------------------------------------------------------------------------------------------------
+# device pool (one context + host thread per GPU, reads sharded by event count)
+# ------------------------------------------------------------------------------------------------
+def device_count():
+    n = C.c_int(0)
+    lib().nchmm_device_count(C.byref(n))
+    return n.value
+
+
+def lpt_partition(weights, n_shards):
+    """nchmm_lpt_partition -> shard index per item (int32)."""
+    w = np.ascontiguousarray(weights, np.uint64)
+    out = np.empty(w.shape[0], np.int32)
+    check(lib().nchmm_lpt_partition(w.shape[0], _p(w), int(n_shards), _p(out)), "nchmm_lpt_partition")
+    return out
+
+
+class Pool:
+    """nchmm_pool: device_ids may repeat (several contexts on one GPU) to exercise the sharding on one device."""
+
+    def __init__(self, device_ids):
+        ids = np.ascontiguousarray(device_ids, np.int32)
+        self._h = C.c_void_p()
+        check(lib().nchmm_pool_create(C.byref(self._h), ids.shape[0], _p(ids)), "nchmm_pool_create")
+
+    def close(self):
+        if self._h:
+            lib().nchmm_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __len__(self):
+        return lib().nchmm_pool_size(self._h)
+
+    def train_reads(self, opts, model_states, strand_off, mean, stdv, start, job_read, job_m0, job_m1, init_pm=None, init_st=None):
+        st10 = _f32(model_states).reshape(-1, S, 10)
+        so = np.ascontiguousarray(strand_off, np.uint64)
+        n_reads = (so.shape[0] - 1) // 2
+        jr, j0, j1 = (np.ascontiguousarray(a, np.int32) for a in (job_read, job_m0, job_m1))
+        nj = jr.shape[0]
+        pm = np.tile(np.float32([1, 0, 0, 1, 1, 1]), (nj, 1)) if init_pm is None else _f32(init_pm).reshape(nj, 6).copy()
+        st = (np.tile(np.float32([opts.default_p_stay, opts.default_p_skip] * 2), (nj, 1)) if init_st is None
+              else _f32(init_st).reshape(nj, 4).copy())
+        fit = np.empty(nj, np.float32)
+        rounds = np.empty(nj, np.uint32)
+        pref = np.empty((n_reads, 3), np.int32)
+        check(lib().nchmm_pool_train_reads(self._h, C.byref(opts), st10.shape[0], _p(st10), n_reads, _p(so), _p(_f32(mean)),
+                                           _p(_f32(stdv)), _p(_f32(start)), nj, _p(jr), _p(j0), _p(j1), _p(pm), _p(st), _p(fit),
+                                           _p(rounds), _p(pref)), "nchmm_pool_train_reads")
+        return dict(pm=pm, st=st, fit=fit, rounds=rounds, preferred=pref)
+
+    def basecall_reads(self, opts, model_states, strand_off, mean, stdv, start, job_read, job_m0, job_m1, job_pm, job_st,
+                       preferred=None):
+        st10 = _f32(model_states).reshape(-1, S, 10)
+        so = np.ascontiguousarray(strand_off, np.uint64)
+        n_reads = (so.shape[0] - 1) // 2
+        jr, j0, j1 = (np.ascontiguousarray(a, np.int32) for a in (job_read, job_m0, job_m1))
+        pm, st = _f32(job_pm).reshape(-1, 6), _f32(job_st).reshape(-1, 4)
+        pref = None if preferred is None else np.ascontiguousarray(preferred, np.int32).reshape(n_reads, 3)
+        states = np.zeros(int(so[-1]), np.uint16)
+        bj = np.empty((n_reads, 2), np.int32)
+        bl = np.empty((n_reads, 2), np.float32)
+        rc = lib().nchmm_pool_basecall_reads(self._h, C.byref(opts), st10.shape[0], _p(st10), n_reads, _p(so), _p(_f32(mean)),
+                                             _p(_f32(stdv)), _p(_f32(start)), jr.shape[0], _p(jr), _p(j0), _p(j1), _p(pm), _p(st),
+                                             _p(pref), _p(states), _p(bj), _p(bl))
+        if rc not in (0, -6):
+            check(rc, "nchmm_pool_basecall_reads")
+        return dict(states=states, best_job=bj, best_logp=bl)
+
+    def counters(self):
+        """-> (summed counters uint64[8], used_rccl bool)"""
+        out = np.zeros(8, np.uint64)
+        used = C.c_int(0)
+        check(lib().nchmm_pool_counters(self._h, _p(out), C.byref(used)), "nchmm_pool_counters")
+        return out, bool(used.value)

@@ -1,0 +1,738 @@
+// nanocall.cpp -- the `nanocall` command line on the MI355X-native HMM core.
+//
+// Counterpart of the reference driver (src/nanocall/nanocall.cpp): same option table (:50-95), pore presets
+// (:943-970), option checks (:995-1059), model / transition / file / read initialisation (:97-273), training,
+// basecalling, FASTA (:584-591, names :764-768,837-842) and --stats TSV (:893-903).  What differs is HOW the two
+// read loops run: the reference gives one read at a time to each of `-t` worker threads (pfor, :282,611); here the
+// reads of a chunk are sharded over the GPUs of the node (one host thread + context per device, nchmm_pool_*) and every
+// device decodes its shard in batched launches.  Output order is input order.
+//
+// Not provided (fails with a message): --write-fast5 (HDF5 write-back), -s/--trans with a graph other than the
+// stay/step/skip-1 one (the device tables are built from (pr_skip, pr_stay)), gzip-compressed model files.
+// Extra options: --gpus N (devices to use, default all), --chunk-events N (events decoded per batch and device).
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <deque>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <mutex>
+#include <sstream>
+#include <string>
+
+#include "nanocall_amd/fast5_summary.hpp"
+#include "nanocall_amd/nanocall_amd.hpp"
+
+using namespace nanocall_amd;
+
+#ifndef NANOCALL_AMD_VERSION
+#define NANOCALL_AMD_VERSION "0.7.4-amd"
+#endif
+
+typedef State_Transitions<float, 6> State_Transitions_Type;
+typedef State_Transition_Parameters<float> State_Transition_Parameters_Type;
+typedef Pore_Model<float, 6> Pore_Model_Type;
+typedef Pore_Model_Dict<float, 6> Pore_Model_Dict_Type;
+typedef Pore_Model_Parameters<float> Pore_Model_Parameters_Type;
+typedef Event<float, 6> Event_Type;
+typedef Event_Sequence<float, 6> Event_Sequence_Type;
+typedef Fast5_Summary<float, 6> Fast5_Summary_Type;
+
+// ---------------------------------------------------------------------------------------------------------------
+// logging: LOG(level) << ... as the reference uses it (hpptools logger.hpp is un-vendored; only the level filter and
+// the message bodies are reproduced)
+// ---------------------------------------------------------------------------------------------------------------
+namespace logger {
+enum level { error = 0, warning, info, debug, debug1, debug2 };
+inline int& threshold() { static int t = info; return t; }
+inline std::mutex& mutex() { static std::mutex m; return m; }
+inline const char* name(int l) { static const char* n[] = {"error", "warning", "info", "debug", "debug1", "debug2"}; return n[std::min(l, 5)]; }
+struct Line {
+    std::ostringstream os;
+    int lvl;
+    explicit Line(int l) : lvl(l) { os << "= nanocall " << name(l) << ": "; }
+    ~Line() { std::lock_guard<std::mutex> g(mutex()); std::clog << os.str(); }
+};
+inline int parse_level(const std::string& s)
+{
+    for (int l = 0; l <= debug2; ++l) if (s == name(l)) return l;
+    try { return std::stoi(s); } catch (...) { return info; }
+}
+}  // namespace logger
+#define LOG(l) if (logger::l > logger::threshold()) {} else logger::Line(logger::l).os
+
+// ---------------------------------------------------------------------------------------------------------------
+// options: the reference's TCLAP table (nanocall.cpp:50-95) on a small parser with TCLAP's conventions
+// (`--name value`, `-x value`, switches, repeatable args, positional inputs, `--`, -h/--help, --version)
+// ---------------------------------------------------------------------------------------------------------------
+namespace opts {
+struct Arg_Base;
+inline std::vector<Arg_Base*>& registry() { static std::vector<Arg_Base*> r; return r; }
+struct Arg_Base {
+    std::string flag, name, desc, type_desc;
+    bool is_switch = false, is_set = false;
+    Arg_Base(const std::string& f, const std::string& n, const std::string& d, const std::string& t, bool sw)
+        : flag(f), name(n), desc(d), type_desc(t), is_switch(sw) { registry().push_back(this); }
+    virtual ~Arg_Base() {}
+    virtual void assign(const std::string& v) = 0;
+    bool isSet() const { return is_set; }
+};
+template <typename T> bool convert(const std::string& s, T& out)
+{
+    std::istringstream is(s);
+    is >> out;
+    return !is.fail() && is.eof();
+}
+template <> inline bool convert<std::string>(const std::string& s, std::string& out) { out = s; return true; }
+template <typename T> struct ValueArg : Arg_Base {
+    T value;
+    ValueArg(const std::string& f, const std::string& n, const std::string& d, bool, T dflt, const std::string& t)
+        : Arg_Base(f, n, d, t, false), value(dflt) {}
+    void assign(const std::string& v) override
+    {
+        if (is_set) throw std::runtime_error("Argument already set: --" + name);
+        if (!convert(v, value)) throw std::runtime_error("Couldn't read argument value from string '" + v + "' for --" + name);
+        is_set = true;
+    }
+    T& get() { return value; }
+    const T& get() const { return value; }
+    operator const T&() const { return value; }
+};
+struct SwitchArg : Arg_Base {
+    bool value = false;
+    SwitchArg(const std::string& f, const std::string& n, const std::string& d) : Arg_Base(f, n, d, "", true) {}
+    void assign(const std::string&) override { value = true; is_set = true; }
+    bool get() const { return value; }
+    void set(bool v) { value = v; }
+    operator bool() const { return value; }
+};
+template <typename T> struct MultiArg : Arg_Base {
+    std::vector<T> values;
+    MultiArg(const std::string& f, const std::string& n, const std::string& d, bool, const std::string& t) : Arg_Base(f, n, d, t, false) {}
+    void assign(const std::string& v) override
+    {
+        T x;
+        if (!convert(v, x)) throw std::runtime_error("Couldn't read argument value from string '" + v + "' for --" + name);
+        values.push_back(x);
+        is_set = true;
+    }
+    const std::vector<T>& get() const { return values; }
+    typename std::vector<T>::const_iterator begin() const { return values.begin(); }
+    typename std::vector<T>::const_iterator end() const { return values.end(); }
+};
+
+std::string description = "Call bases in Oxford Nanopore reads.";
+std::string program_name = "nanocall", orig_argv;
+//
+ValueArg<std::string> ed_group("", "ed-group", "EventDetection group to use. (default: smallest available)", false, "", "000|001|...");
+ValueArg<unsigned> chunk_size("", "chunk-size", "Thread chunk size.", false, 1, "int");
+MultiArg<std::string> log_level("", "log", "Log level. (default: info)", false, "string");
+ValueArg<std::string> stats_fn("", "stats", "Stats.", false, "", "file");
+ValueArg<std::string> train_drift("", "train-drift", "Train drift parameter. (default: yes for R73, no for R9)", false, "", "0|1");
+ValueArg<unsigned> trim_ed_hp_end("", "trim-ed-hp-end", "Number of events to trim after hairpin end.", false, 50, "int");
+ValueArg<unsigned> trim_ed_hp_start("", "trim-ed-hp-start", "Number of events to trim before hairpin start.", false, 50, "int");
+ValueArg<unsigned> trim_ed_sq_end("", "trim-ed-sq-end", "Number of events to trim before sequence end.", false, 50, "int");
+ValueArg<unsigned> trim_ed_sq_start("", "trim-ed-sq-start", "Number of events to trim after sequence start.", false, 50, "int");
+ValueArg<unsigned> max_ed_events("", "max-ed-events", "Maximum EventDetection events.", false, 100000, "int");
+ValueArg<unsigned> min_ed_events("", "min-ed-events", "Minimum EventDetection events.", false, 10, "int");
+ValueArg<unsigned> fasta_line_width("", "fasta-line-width", "Maximum fasta line width.", false, 80, "int");
+//
+ValueArg<float> scaling_select_threshold("", "scaling-select-threshold", "Select best model per strand during scaling if log score better by threshold.", false, 20.0, "float");
+ValueArg<float> scaling_min_progress("", "scaling-min-progress", "Minimum scaling fit progress.", false, 1.0, "float");
+ValueArg<unsigned> scaling_max_rounds("", "scaling-max-rounds", "Maximum scaling rounds.", false, 10, "int");
+ValueArg<unsigned> scaling_num_events("", "scaling-num-events", "Number of events used for model scaling.", false, 200, "int");
+//
+SwitchArg template_only("", "1d", "Interpret entire read as 1D template only.");
+SwitchArg single_strand_scaling("", "single-strand-scaling", "Train scaling parameters per strand.");
+SwitchArg double_strand_scaling("", "double-strand-scaling", "Train scaling parameters per read. (default)");
+SwitchArg no_train_transitions("", "no-train-transitions", "Do not train state transitions.");
+SwitchArg no_train_scaling("", "no-train-scaling", "Do not train pore model scaling.");
+SwitchArg train("", "train", "Enable training. (default)");
+SwitchArg no_train("", "no-train", "Disable all training.");
+SwitchArg basecall("", "basecall", "Enable basecalling (default).");
+SwitchArg no_basecall("", "no-basecall", "Disable basecalling.");
+//
+ValueArg<float> pr_skip("", "pr-skip", "Transition probability of skipping at least 1 state.", false, .3, "float");
+ValueArg<float> pr_stay("", "pr-stay", "Transition probability of staying in the same state.", false, .1, "float");
+ValueArg<std::string> trans_fn("s", "trans", "Custom initial state transitions.", false, "", "file");
+ValueArg<std::string> model_fofn("", "model-fofn", "File of pore models.", false, "", "file");
+MultiArg<std::string> model_fn("m", "model", "Custom pore model for strand (0=template, 1=complement, 2=both).", false, "strand:file");
+//
+ValueArg<std::string> pore("", "pore", "Pore name, used to select builtin pore model.", false, "r9", "r73|r9");
+SwitchArg write_fast5("", "write-fast5", "Write basecalls to fast5 files.");
+ValueArg<std::string> output_fn("o", "output", "Output.", false, "", "file");
+ValueArg<unsigned> num_threads("t", "threads", "Number of parallel threads.", false, 1, "int");
+// MI355X additions
+ValueArg<int> gpus("", "gpus", "Number of GPUs to shard the reads over. (default: all visible)", false, 0, "int");
+ValueArg<unsigned long> chunk_events("", "chunk-events", "Events decoded per batch and GPU.", false, 32000000ul, "int");
+ValueArg<std::string> dump_params_fn("", "dump-params", "Write the exact (hex float) parameters and path log-probability of every basecalled strand.", false, "", "file");
+std::vector<std::string> input_fn;   // UnlabeledMultiArg "inputs"
+
+void usage(std::ostream& os)
+{
+    os << "\nUSAGE:\n\n   " << program_name << "  [options] <path> ...\n\nWhere:\n\n";
+    for (const Arg_Base* a : registry()) {
+        os << "   ";
+        if (!a->flag.empty()) os << "-" << a->flag << (a->is_switch ? "" : " <" + a->type_desc + ">") << ",  ";
+        os << "--" << a->name << (a->is_switch ? "" : " <" + a->type_desc + ">") << "\n     " << a->desc << "\n\n";
+    }
+    os << "   <path>  (accepted multiple times)\n     (required)  Inputs: directories, fast5 files, or files of fast5 file names (use \"-\" to read fofn from stdin).\n\n"
+       << "   " << description << "\n\n";
+}
+
+// returns false when the program should exit (code in *rc)
+bool parse(int argc, char* argv[], int* rc)
+{
+    program_name = argv[0];
+    for (int i = 0; i < argc; ++i) orig_argv += std::string(i ? " " : "") + argv[i];
+    try {
+        bool rest_positional = false;
+        for (int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (rest_positional || a == "-" || a.empty() || a[0] != '-') { input_fn.push_back(a); continue; }
+            if (a == "--") { rest_positional = true; continue; }
+            if (a == "-h" || a == "--help") { usage(std::cout); *rc = EXIT_SUCCESS; return false; }
+            if (a == "--version") { std::cout << "\n" << program_name << "  version: " << NANOCALL_AMD_VERSION << "\n\n"; *rc = EXIT_SUCCESS; return false; }
+            Arg_Base* hit = nullptr;
+            for (Arg_Base* r : registry())
+                if ((a.size() > 2 && a[1] == '-' && a.substr(2) == r->name) || (a.size() == 2 && !r->flag.empty() && a.substr(1) == r->flag)) hit = r;
+            if (!hit) throw std::runtime_error("Couldn't find match for argument: " + a);
+            if (hit->is_switch) { hit->assign(""); continue; }
+            if (i + 1 >= argc) throw std::runtime_error("Missing a value for this argument: " + a);
+            hit->assign(argv[++i]);
+        }
+        if (input_fn.empty()) throw std::runtime_error("Required argument missing: inputs");
+    } catch (const std::exception& e) {
+        std::cerr << "PARSE ERROR: " << e.what() << "\n\nFor complete USAGE and HELP type: \n   " << program_name << " --help\n\n";
+        *rc = EXIT_FAILURE;
+        return false;
+    }
+    return true;
+}
+}  // namespace opts
+
+// ---------------------------------------------------------------------------------------------------------------
+// file-system helpers (fs_support.hpp:15-45)
+// ---------------------------------------------------------------------------------------------------------------
+static bool is_directory(const std::string& fn)
+{
+    struct stat st;
+    return stat(fn.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+static std::vector<std::string> list_directory(const std::string& fn)
+{
+    std::vector<std::string> res;
+    if (DIR* d = opendir(fn.c_str())) {
+        while (struct dirent* e = readdir(d)) {
+            const std::string n = e->d_name;
+            if (n != "." && n != "..") res.push_back(n);
+        }
+        closedir(d);
+    }
+    return res;   // readdir order, as the reference (compare FASTA per record, or feed a fofn)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// init_models / init_transitions / init_files / init_reads  (nanocall.cpp:97-273)
+// ---------------------------------------------------------------------------------------------------------------
+static void init_models(Pore_Model_Dict_Type& models)
+{
+    auto parse_model_name = [](const std::string& s) {
+        if (s.size() < 3 || (s[0] != '0' && s[0] != '1' && s[0] != '2') || s[1] != ':') {
+            LOG(error) << "could not parse model name: \"" << s << "\"; format should be \"[0|1|2]:<file>\"" << std::endl;
+            std::exit(EXIT_FAILURE);
+        }
+        return std::make_pair((unsigned)(s[0] - '0'), s.substr(2));
+    };
+    std::map<unsigned, std::list<std::string>> model_list;
+    for (const auto& s : opts::model_fn.get()) {
+        auto p = parse_model_name(s);
+        model_list[p.first].push_back(p.second);
+    }
+    if (!opts::model_fofn.get().empty()) {
+        std::ifstream ifs(opts::model_fofn.get());
+        if (!ifs) { LOG(error) << "cannot open model fofn [" << opts::model_fofn.get() << "]" << std::endl; std::exit(EXIT_FAILURE); }
+        std::string s;
+        while (std::getline(ifs, s)) {
+            auto p = parse_model_name(s);
+            model_list[p.first].push_back(p.second);
+        }
+    }
+    if (model_list[2].empty() && (model_list[0].empty() != model_list[1].empty())) {
+        LOG(error) << "models were specified only for strand " << (int)model_list[0].empty() << "! give models for both strands, or for neither." << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    if (!(model_list[0].empty() && model_list[1].empty() && model_list[2].empty())) {
+        for (unsigned st = 0; st < 3; ++st)
+            for (const auto& e : model_list[st]) {
+                Pore_Model_Type pm;
+                std::ifstream ifs(e, std::ios::binary);
+                if (!ifs) { LOG(error) << "cannot open model file [" << e << "]" << std::endl; std::exit(EXIT_FAILURE); }
+                if (ifs.peek() == 0x1f) { LOG(error) << "model file [" << e << "] is gzip-compressed: decompress it first" << std::endl; std::exit(EXIT_FAILURE); }
+                try { ifs >> pm; } catch (const std::exception& x) { LOG(error) << e << ": " << x.what() << std::endl; std::exit(EXIT_FAILURE); }
+                pm.strand() = st;
+                LOG(info) << "loaded module [" << e << "] for strand [" << st << "] statistics [mean=" << pm.mean() << ", stdv=" << pm.stdv() << "]" << std::endl;
+                models[e] = std::move(pm);
+            }
+    } else {
+        for (unsigned i = 0; i < Builtin_Model::num(); ++i) {
+            const std::string pm_name = Builtin_Model::names(i);
+            if (pm_name.compare(0, opts::pore.get().size() + 1, opts::pore.get() + ".")) continue;
+            Pore_Model_Type pm;
+            pm.load_from_vector(Builtin_Model::init_lists(i));
+            pm.strand() = Builtin_Model::strands(i);
+            LOG(info) << "loaded builtin module [" << pm_name << "] for strand [" << pm.strand() << "] statistics [mean=" << pm.mean() << ", stdv=" << pm.stdv() << "]" << std::endl;
+            models[pm_name] = std::move(pm);
+        }
+        if (models.empty()) {
+            LOG(error) << "no builtin models found for pore [" << opts::pore.get() << "]" << std::endl;
+            std::exit(EXIT_FAILURE);
+        }
+    }
+}
+
+static void init_transitions(State_Transitions_Type& transitions)
+{
+    if (!opts::trans_fn.get().empty()) {
+        LOG(error) << "custom initial state transitions (-s/--trans) are not supported by the GPU core: its transition tables are "
+                      "built from (--pr-skip, --pr-stay)" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    transitions.compute_transitions_fast(opts::pr_skip, opts::pr_stay);
+    LOG(info) << "init_state_transitions pr_skip=[" << opts::pr_skip.get() << "], pr_stay=[" << opts::pr_stay.get() << "]" << std::endl;
+}
+
+static void init_files(std::list<std::string>& files)
+{
+    for (const auto& f : opts::input_fn) {
+        if (is_directory(f)) {
+            for (const auto& g : list_directory(f)) {
+                const std::string f2 = f + (f[f.size() - 1] != '/' ? "/" : "") + g;
+                if (is_directory(f2)) LOG(info) << "ignoring subdirectory [" << f2 << "]" << std::endl;
+                else if (is_valid_read_file(f2)) { files.push_back(f2); LOG(info) << "adding input file [" << f2 << "]" << std::endl; }
+                else LOG(info) << "ignoring file [" << f2 << "]" << std::endl;
+            }
+        } else if (f != "-" && is_valid_read_file(f)) {
+            files.push_back(f);
+            LOG(info) << "adding input file [" << f << "]" << std::endl;
+        } else {
+            LOG(info) << "interpreting [" << f << "] as fofn" << std::endl;
+            std::ifstream ifs;
+            std::istream* is_p = &std::cin;
+            if (f != "-") {
+                ifs.open(f);
+                if (!ifs) { LOG(error) << "cannot open [" << f << "]" << std::endl; std::exit(EXIT_FAILURE); }
+                is_p = &ifs;
+            }
+            std::string g;
+            while (std::getline(*is_p, g))
+                if (is_valid_read_file(g)) { files.push_back(g); LOG(info) << "adding input file [" << g << "]" << std::endl; }
+        }
+    }
+    if (files.empty()) {
+        LOG(error) << "no fast5 files to process" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+}
+
+// f(i) for i in [0, n) on `nt` host threads (the summaries / event loads of different reads are independent)
+template <typename F> static void host_parallel(size_t n, unsigned nt, F&& f)
+{
+    nt = std::max(1u, std::min<unsigned>(nt, (unsigned)std::max<size_t>(n, 1)));
+    if (nt == 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&] { for (size_t i; (i = next++) < n;) f(i); });
+    for (auto& t : th) t.join();
+}
+
+static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, std::deque<Fast5_Summary_Type>& reads)
+{
+    const std::vector<std::string> fv(files.begin(), files.end());
+    reads.resize(fv.size());
+    host_parallel(fv.size(), opts::num_threads, [&](size_t i) { reads[i].summarize(fv[i], models, opts::double_strand_scaling); });
+    for (const auto& s : reads) LOG(info) << "summary: " << s << std::endl;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// train_reads + basecall_reads (nanocall.cpp:275-582, 593-869), batched: the reads of a chunk -> SoA events -> job list
+// -> nchmm_pool_train_reads -> nchmm_pool_basecall_reads -> FASTA records in input order
+// ---------------------------------------------------------------------------------------------------------------
+static void write_fasta(std::ostream& os, const std::string& name, const std::string& seq)   // nanocall.cpp:584-591
+{
+    os << ">" << name << std::endl;
+    for (unsigned pos = 0; pos < seq.size(); pos += opts::fasta_line_width) os << seq.substr(pos, opts::fasta_line_width) << std::endl;
+}
+
+struct Model_Table {
+    std::vector<std::string> names;        // std::map order
+    std::vector<int32_t> strand;
+    std::vector<float> states;             // n_models x S x 10 (unscaled)
+    std::vector<float> mean;               // Pore_Model::mean() per model
+};
+
+static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, std::deque<Fast5_Summary_Type>& reads, std::ostream* os_p,
+                          uint64_t counters[4])
+{
+    std::ofstream dump;
+    if (!opts::dump_params_fn.get().empty()) {
+        dump.open(opts::dump_params_fn.get());
+        dump << "#read_id\tstrand\tmodel\tscale\tshift\tdrift\tvar\tscale_sd\tvar_sd\tp_stay\tp_skip\tlog_path_prob\trounds\tfit" << std::endl;
+        dump << std::hexfloat;
+    }
+    Model_Table M;
+    for (const auto& p : models) {
+        M.names.push_back(p.first);
+        M.strand.push_back((int32_t)p.second.strand());
+        M.states.insert(M.states.end(), p.second.data(), p.second.data() + (size_t)4096 * 10);
+        M.mean.push_back(p.second.mean());
+    }
+    const size_t n_models = M.names.size();
+    nchmm_train_opts o;
+    check(nchmm_train_opts_default(&o), "nchmm_train_opts_default");
+    o.scaling_num_events = opts::scaling_num_events; o.scaling_max_rounds = opts::scaling_max_rounds;
+    o.scaling_min_progress = opts::scaling_min_progress; o.scaling_select_threshold = opts::scaling_select_threshold;
+    o.min_ed_events = opts::min_ed_events; o.train_scaling = !opts::no_train_scaling; o.train_transitions = !opts::no_train_transitions;
+    o.train_drift = opts::train_drift.get() == "1"; o.default_p_stay = opts::pr_stay; o.default_p_skip = opts::pr_skip;
+
+    const uint64_t chunk_cap = std::max<uint64_t>(1, opts::chunk_events.get()) * (uint64_t)nchmm_pool_size(pool);
+    size_t next = 0;
+    while (next < reads.size()) {
+        // ---- the chunk: consecutive reads up to the event budget (at least one) ----
+        std::vector<size_t> idx;
+        uint64_t budget = 0;
+        while (next < reads.size()) {
+            const Fast5_Summary_Type& r = reads[next];
+            const uint64_t ev = r.num_ed_events ? (r.strand_bounds[1] - r.strand_bounds[0]) + (r.strand_bounds[3] > r.strand_bounds[2] ? r.strand_bounds[3] - r.strand_bounds[2] : 0) : 0;
+            if (!idx.empty() && budget + ev > chunk_cap) break;
+            if (r.num_ed_events) { idx.push_back(next); budget += ev; }   // (reads without events are skipped, nanocall.cpp:294,623)
+            ++next;
+        }
+        if (idx.empty()) continue;
+        const size_t nr = idx.size();
+        host_parallel(nr, opts::num_threads, [&](size_t i) { reads[idx[i]].load_events(); });
+        std::vector<uint64_t> strand_off(2 * nr + 1, 0);
+        std::vector<uint8_t> together(nr);
+        for (size_t i = 0; i < nr; ++i) {
+            const Fast5_Summary_Type& r = reads[idx[i]];
+            strand_off[2 * i + 1] = strand_off[2 * i] + r.events(0).size();
+            strand_off[2 * i + 2] = strand_off[2 * i + 1] + r.events(1).size();
+            together[i] = r.scale_strands_together ? 1 : 0;
+        }
+        const size_t total = (size_t)strand_off[2 * nr];
+        std::vector<float> mean(total + 1), stdv(total + 1), start(total + 1);
+        host_parallel(nr, opts::num_threads, [&](size_t i) {
+            const Fast5_Summary_Type& r = reads[idx[i]];
+            for (unsigned st = 0; st < 2; ++st) {
+                size_t k = (size_t)strand_off[2 * i + st];
+                for (const Event_Type& e : r.events(st)) { mean[k] = e.mean; stdv[k] = e.stdv; start[k] = e.start; ++k; }
+            }
+        });
+        // mean of the events' levels per strand, for the means_apart check (nanocall.cpp:628-641,673-683)
+        std::vector<float> r_mean(2 * nr, 0.f);
+        for (size_t i = 0; i < nr; ++i)
+            for (unsigned st = 0; st < 2; ++st) {
+                const size_t b = (size_t)strand_off[2 * i + st], n = (size_t)(strand_off[2 * i + st + 1] - strand_off[2 * i + st]);
+                if (n < opts::min_ed_events) continue;
+                float sd;
+                check(nchmm_mean_stdv(n, &mean[b], &r_mean[2 * i + st], &sd), "nchmm_mean_stdv");
+            }
+        // ---- jobs: one per iteration of the reference's model loops (nanocall.cpp:300-323,356-358,474) ----
+        size_t n_jobs = 0;
+        check(nchmm_train_enumerate(&o, n_models, M.strand.data(), nr, strand_off.data(), together.data(), &n_jobs, nullptr, nullptr, nullptr),
+              "nchmm_train_enumerate");
+        std::vector<int32_t> job_read(n_jobs), job_m0(n_jobs), job_m1(n_jobs);
+        check(nchmm_train_enumerate(&o, n_models, M.strand.data(), nr, strand_off.data(), together.data(), &n_jobs, job_read.data(), job_m0.data(),
+                                    job_m1.data()), "nchmm_train_enumerate");
+        std::vector<float> job_pm(6 * n_jobs), job_st(4 * n_jobs), job_fit(n_jobs, -INFINITY);
+        std::vector<uint32_t> job_rounds(n_jobs, 0);
+        std::vector<int32_t> preferred(3 * nr, -1);
+        auto key_of = [&](size_t k) {
+            std::array<std::string, 2> key;
+            if (job_m0[k] >= 0) key[0] = M.names[(size_t)job_m0[k]];
+            if (job_m1[k] >= 0) key[1] = M.names[(size_t)job_m1[k]];
+            return key;
+        };
+        for (size_t k = 0; k < n_jobs; ++k) {
+            const Fast5_Summary_Type& r = reads[idx[(size_t)job_read[k]]];
+            const auto key = key_of(k);
+            const Pore_Model_Parameters_Type& pm = r.pm_params_m.at(key);
+            const auto& stp = r.st_params_m.at(key);
+            const float p6[6] = {pm.scale, pm.shift, pm.drift, pm.var, pm.scale_sd, pm.var_sd};
+            std::copy(p6, p6 + 6, &job_pm[6 * k]);
+            for (int s = 0; s < 2; ++s) { job_st[4 * k + 2 * s] = stp[s].p_stay; job_st[4 * k + 2 * s + 1] = stp[s].p_skip; }
+        }
+        // ---- training ----
+        if (opts::train && n_jobs) {
+            const auto t0 = std::chrono::steady_clock::now();
+            check(nchmm_pool_train_reads(pool, &o, n_models, M.states.data(), nr, strand_off.data(), mean.data(), stdv.data(), start.data(), n_jobs,
+                                         job_read.data(), job_m0.data(), job_m1.data(), job_pm.data(), job_st.data(), job_fit.data(),
+                                         job_rounds.data(), preferred.data()), "nchmm_pool_train_reads");
+            counters[2] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            for (size_t k = 0; k < n_jobs; ++k) {
+                Fast5_Summary_Type& r = reads[idx[(size_t)job_read[k]]];
+                const auto key = key_of(k);
+                Pore_Model_Parameters_Type& pm = r.pm_params_m.at(key);
+                pm.scale = job_pm[6 * k]; pm.shift = job_pm[6 * k + 1]; pm.drift = job_pm[6 * k + 2]; pm.var = job_pm[6 * k + 3];
+                pm.scale_sd = job_pm[6 * k + 4]; pm.var_sd = job_pm[6 * k + 5];
+                auto& stp = r.st_params_m.at(key);
+                const bool two_d = job_m0[k] >= 0 && job_m1[k] >= 0;
+                for (int s = 0; s < 2; ++s)
+                    if (s == 0 ? job_m0[k] >= 0 : job_m1[k] >= 0) { stp[s].p_stay = job_st[4 * k + 2 * s]; stp[s].p_skip = job_st[4 * k + 2 * s + 1]; }
+                const int strand_tag = two_d ? 2 : (job_m0[k] >= 0 ? 0 : 1);
+                const std::string m_name = two_d ? key[0] + "+" + key[1] : key[strand_tag];
+                if (logger::info <= logger::threshold()) {   // nanocall.cpp:427-434 / :543-550
+                    std::ostringstream stp_s;
+                    if (two_d) stp_s << stp[0] << "," << stp[1]; else stp_s << stp[(size_t)strand_tag];
+                    LOG(info) << "scaling_result read [" << r.read_id << "] strand [" << strand_tag << "] model [" << m_name << "] pm_params [" << pm
+                              << "] st_params [" << stp_s.str() << "] fit [" << job_fit[k] << "] rounds [" << job_rounds[k] << "]" << std::endl;
+                }
+            }
+            for (size_t i = 0; i < nr; ++i) {   // model selection, nanocall.cpp:437-459,552-570
+                Fast5_Summary_Type& r = reads[idx[i]];
+                for (int kind = 0; kind < 3; ++kind) {
+                    const int32_t k = preferred[3 * i + kind];
+                    if (k < 0) continue;
+                    const auto key = key_of((size_t)k);
+                    if (kind == 2) { r.preferred_model[2] = key; LOG(info) << "selected_model read [" << r.read_id << "] strand [2] model [" << key[0] << "+" << key[1] << "]" << std::endl; }
+                    else { r.preferred_model[(size_t)kind][(size_t)kind] = key[(size_t)kind]; LOG(info) << "selected_model read [" << r.read_id << "] strand [" << kind << "] model [" << key[(size_t)kind] << "]" << std::endl; }
+                }
+            }
+        }
+        // ---- basecalling ----
+        if (opts::basecall && n_jobs) {
+            std::vector<uint16_t> states(total + 1);
+            std::vector<int32_t> best_job(2 * nr, -1);
+            std::vector<float> best_logp(2 * nr, NAN);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = nchmm_pool_basecall_reads(pool, &o, n_models, M.states.data(), nr, strand_off.data(), mean.data(), stdv.data(), start.data(),
+                                                     n_jobs, job_read.data(), job_m0.data(), job_m1.data(), job_pm.data(), job_st.data(),
+                                                     preferred.data(), states.data(), best_job.data(), best_logp.data());
+            if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) check(rc, "nchmm_pool_basecall_reads");
+            counters[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            // base sequences + FASTA records, built per read in parallel, emitted in input order (pfor's output_chunk, :858-861)
+            std::vector<std::string> record(nr), dump_rec(nr);
+            host_parallel(nr, opts::num_threads, [&](size_t i) {
+                Fast5_Summary_Type& r = reads[idx[i]];
+                std::ostringstream oss;
+                for (unsigned st = 0; st < 2; ++st) {
+                    const int32_t k = best_job[2 * i + st];
+                    if (k < 0) continue;
+                    const size_t b = (size_t)strand_off[2 * i + st], n = (size_t)(strand_off[2 * i + st + 1] - strand_off[2 * i + st]);
+                    const auto key = key_of((size_t)k);
+                    const bool two_d = job_m0[(size_t)k] >= 0 && job_m1[(size_t)k] >= 0;
+                    Pore_Model_Parameters_Type best_pm;
+                    best_pm.scale = job_pm[6 * (size_t)k]; best_pm.shift = job_pm[6 * (size_t)k + 1]; best_pm.drift = job_pm[6 * (size_t)k + 2];
+                    best_pm.var = job_pm[6 * (size_t)k + 3]; best_pm.scale_sd = job_pm[6 * (size_t)k + 4]; best_pm.var_sd = job_pm[6 * (size_t)k + 5];
+                    State_Transition_Parameters_Type best_st;
+                    best_st.p_stay = job_st[4 * (size_t)k + 2 * st]; best_st.p_skip = job_st[4 * (size_t)k + 2 * st + 1];
+                    // means_apart warning, :673-683: model mean after scaling = mean * scale + shift only approximately; the reference
+                    // recomputes the statistics of the scaled model, so do that
+                    if (logger::warning <= logger::threshold() && n >= opts::min_ed_events) {
+                        Pore_Model_Type pm(models.at(key[st]));
+                        pm.scale(best_pm);
+                        if (std::abs(r_mean[2 * i + st] - pm.mean()) > 5.0) {
+                            LOG(warning) << "means_apart read [" << r.read_id << "] strand [" << st << "] model [" << key[st] << "] parameters [" << best_pm
+                                         << "] model_mean=[" << pm.mean() << "] events_mean=[" << r_mean[2 * i + st] << "]" << std::endl;
+                        }
+                    }
+                    LOG(info) << "best_model read [" << r.read_id << "] strand [" << st << "] model [" << key[st] << "] pm_params [" << best_pm << "] st_params ["
+                              << best_st << "] log_path_prob [" << best_logp[2 * i + st] << "]" << std::endl;
+                    // nanocall.cpp:761-763 (2D) / :836 (1D)
+                    r.preferred_model[st][st] = key[st];
+                    if (two_d) {
+                        r.pm_params_m[r.preferred_model[st]] = best_pm;
+                        r.st_params_m[r.preferred_model[st]][st] = best_st;
+                    }
+                    std::string seq(6 * n + 1, '\0');
+                    size_t len = 0;
+                    check(nchmm_base_seq(n, &states[b], nullptr, &seq[0], &len), "nchmm_base_seq");
+                    seq.resize(len);
+                    std::ostringstream nm;
+                    nm << r.read_id << ":" << r.base_file_name << ":" << st;
+                    write_fasta(oss, nm.str(), seq);
+                    if (dump.is_open()) {
+                        std::ostringstream d;
+                        d << std::hexfloat << r.read_id << '\t' << st << '\t' << key[st] << '\t' << best_pm.scale << '\t' << best_pm.shift << '\t' << best_pm.drift
+                          << '\t' << best_pm.var << '\t' << best_pm.scale_sd << '\t' << best_pm.var_sd << '\t' << best_st.p_stay << '\t' << best_st.p_skip << '\t'
+                          << best_logp[2 * i + st] << '\t' << std::dec << job_rounds[(size_t)k] << '\t' << std::hexfloat << job_fit[(size_t)k] << '\n';
+                        dump_rec[i] += d.str();
+                    }
+                }
+                record[i] = oss.str();
+            });
+            for (size_t i = 0; i < nr; ++i) {
+                *os_p << record[i];
+                if (dump.is_open()) dump << dump_rec[i];
+                bool header = false;
+                for (char c : record[i]) {   // bases = sequence characters (header lines excluded)
+                    if (c == '>') header = true;
+                    else if (c == '\n') header = false;
+                    else if (!header) ++counters[1];
+                }
+            }
+        }
+        counters[0] += nr;
+        for (size_t i = 0; i < nr; ++i) reads[idx[i]].drop_events();
+    }
+}
+
+static int real_main()
+{
+    Pore_Model_Dict_Type models;
+    State_Transitions_Type default_transitions;
+    std::deque<Fast5_Summary_Type> reads;
+    std::list<std::string> files;
+    init_models(models);
+    init_transitions(default_transitions);
+    init_files(files);
+    init_reads(models, files, reads);
+    // devices: one context + host thread per GPU
+    int n_dev = 0;
+    if (nchmm_device_count(&n_dev) != NCHMM_OK || n_dev < 1) {
+        LOG(error) << "no usable GPU: this build of nanocall decodes on MI355X only (there is no CPU path)" << std::endl;
+        return EXIT_FAILURE;
+    }
+    int use = opts::gpus.get() > 0 ? opts::gpus.get() : n_dev;
+    if (use > n_dev) { LOG(error) << "--gpus " << use << " requested but only " << n_dev << " visible" << std::endl; return EXIT_FAILURE; }
+    nchmm_pool* pool = nullptr;
+    std::vector<int> ids;
+    if (const char* e = std::getenv("NANOCALL_DEVICE_IDS")) {   // e.g. "0,0": several contexts on one GPU (test hook)
+        std::istringstream is(e);
+        std::string tok;
+        while (std::getline(is, tok, ',')) ids.push_back(std::atoi(tok.c_str()));
+        use = (int)ids.size();
+    }
+    check(nchmm_pool_create(&pool, use, ids.empty() ? nullptr : ids.data()), "nchmm_pool_create");
+    LOG(info) << "devices=" << use << " (of " << n_dev << " visible)" << std::endl;
+
+    std::ofstream ofs;
+    std::ostream* os_p = &std::cout;
+    if (!opts::output_fn.get().empty()) {
+        ofs.open(opts::output_fn.get());
+        if (!ofs) { LOG(error) << "cannot open output [" << opts::output_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+        os_p = &ofs;
+    }
+    uint64_t counters[4] = {0, 0, 0, 0};   // reads, bases, training us, basecalling us
+    if (opts::train || opts::basecall) process_reads(pool, models, reads, os_p, counters);
+    os_p->flush();
+    uint64_t dev[8];
+    int used_rccl = 0;
+    check(nchmm_pool_counters(pool, dev, &used_rccl), "nchmm_pool_counters");
+    LOG(info) << "counters reads=" << counters[0] << " bases=" << counters[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
+              << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " gathered_by=" << (used_rccl ? "rccl_allreduce" : "host_sum")
+              << " training_secs=" << counters[2] / 1e6 << " basecalling_secs=" << counters[3] / 1e6 << std::endl;
+    nchmm_pool_destroy(pool);
+    if (!opts::stats_fn.get().empty()) {   // nanocall.cpp:893-903
+        std::ofstream sfs(opts::stats_fn.get());
+        if (!sfs) { LOG(error) << "cannot open stats file [" << opts::stats_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+        Fast5_Summary_Type::write_tsv_header(sfs);
+        sfs << std::endl;
+        for (const auto& s : reads) {
+            s.write_tsv(sfs);
+            sfs << std::endl;
+        }
+    }
+    return EXIT_SUCCESS;
+}
+
+int main(int argc, char* argv[])
+{
+    int rc = 0;
+    if (!opts::parse(argc, argv, &rc)) return rc;
+    logger::threshold() = logger::info;
+    for (const auto& l : opts::log_level.get()) {   // "level" or "facility:level" (facilities are not separated here)
+        const auto p = l.find(':');
+        logger::threshold() = std::max(logger::threshold(), logger::parse_level(p == std::string::npos ? l : l.substr(p + 1)));
+        if (p == std::string::npos) logger::threshold() = logger::parse_level(l);
+    }
+    Fast5_Summary_Type::verbose() = logger::threshold() >= logger::info;
+    LOG(info) << "program: " << opts::program_name << std::endl;
+    LOG(info) << "version: " << NANOCALL_AMD_VERSION << std::endl;
+    LOG(info) << "args: " << opts::orig_argv << std::endl;
+    LOG(info) << "num_threads=" << opts::num_threads.get() << std::endl;
+    State_Transition_Parameters_Type::default_p_stay() = opts::pr_stay;
+    State_Transition_Parameters_Type::default_p_skip() = opts::pr_skip;
+    Fast5_Summary_Type::min_ed_events() = opts::min_ed_events;
+    Fast5_Summary_Type::max_ed_events() = opts::max_ed_events;
+    Fast5_Summary_Type::eventdetection_group() = opts::ed_group;
+    Fast5_Summary_Type::template_only() = opts::template_only;
+    Fast5_Summary_Type::trim_margins() = {{opts::trim_ed_sq_start, opts::trim_ed_sq_end, opts::trim_ed_hp_start, opts::trim_ed_hp_end}};
+    LOG(info) << "eventdetection_group=" << (Fast5_Summary_Type::eventdetection_group().empty() ? std::string("smallest") : Fast5_Summary_Type::eventdetection_group()) << std::endl;
+    // pore-related options, nanocall.cpp:936-970
+    if (!opts::train_drift.get().empty() && opts::train_drift.get() != "0" && opts::train_drift.get() != "1") {
+        LOG(error) << "train-drift not understdood: " << opts::train_drift.get() << std::endl;
+        return EXIT_FAILURE;
+    }
+    if (opts::pore.get() == "r9") {
+        Fast5_Summary_Type::abasic_level_top_percent() = 1.0;
+        Fast5_Summary_Type::abasic_level_top_offset() = 0.0;
+        Fast5_Summary_Type::hairpin_island_window_size() = 10;
+        Fast5_Summary_Type::hairpin_island_window_load() = 5;
+        if (opts::train_drift.get().empty()) opts::train_drift.get() = "0";
+    } else if (opts::pore.get() == "r73") {
+        Fast5_Summary_Type::abasic_level_top_percent() = 1.0;
+        Fast5_Summary_Type::abasic_level_top_offset() = 5.0;
+        Fast5_Summary_Type::hairpin_island_window_size() = 5;
+        Fast5_Summary_Type::hairpin_island_window_load() = 5;
+        if (opts::train_drift.get().empty()) opts::train_drift.get() = "1";
+    } else {
+        LOG(error) << "unknown pore type: " << opts::pore.get() << std::endl;
+        return EXIT_FAILURE;
+    }
+    Parameter_Trainer<float, 6>::pm_train_drift() = opts::train_drift.get() == "1";
+    LOG(info) << "ed_event_trimming: " << " sq_start=" << Fast5_Summary_Type::trim_margins()[0] << " sq_end=" << Fast5_Summary_Type::trim_margins()[1]
+              << " hp_start=" << Fast5_Summary_Type::trim_margins()[2] << " hp_end=" << Fast5_Summary_Type::trim_margins()[3] << std::endl;
+    if (!opts::template_only.get())
+        LOG(info) << "hairpin_detection:" << " abasic_level_top_percent=" << Fast5_Summary_Type::abasic_level_top_percent()
+                  << " abasic_level_top_offset=" << Fast5_Summary_Type::abasic_level_top_offset()
+                  << " hairpin_island_window_size=" << Fast5_Summary_Type::hairpin_island_window_size()
+                  << " hairpin_island_window_load=" << Fast5_Summary_Type::hairpin_island_window_load() << std::endl;
+    else
+        LOG(info) << "hairpin_detection: disabled" << std::endl;
+    // training / basecalling switches, nanocall.cpp:995-1038
+    if (opts::train && opts::no_train) { LOG(error) << "either --train or --no-train may be used, but not both" << std::endl; return EXIT_FAILURE; }
+    else if (!opts::train && !opts::no_train) opts::train.set(true);
+    if (opts::basecall && opts::no_basecall) { LOG(error) << "either --basecall or --no-basecall may be used, but not both" << std::endl; return EXIT_FAILURE; }
+    else if (!opts::basecall && !opts::no_basecall) opts::basecall.set(true);
+    if (opts::train && !opts::no_train_scaling) {
+        if (opts::single_strand_scaling && opts::double_strand_scaling) {
+            LOG(error) << "either --single-strand-scaling or --double-strand-scaling may be used, but not both" << std::endl;
+            return EXIT_FAILURE;
+        } else if (!opts::single_strand_scaling && !opts::double_strand_scaling) {
+            opts::double_strand_scaling.set(true);
+        }
+    }
+    if (opts::scaling_select_threshold.get() < 0.0) { LOG(error) << "invalid scaling_select_threshold: " << opts::scaling_select_threshold.get() << std::endl; return EXIT_FAILURE; }
+    if (opts::scaling_min_progress.get() < 0.0) { LOG(error) << "invalid scaling_min_progress: " << opts::scaling_min_progress.get() << std::endl; return EXIT_FAILURE; }
+    if (!opts::output_fn.get().empty() && opts::write_fast5) {
+        LOG(error) << "output may be written to fast5 files or to a single output file, but not both" << std::endl;
+        return EXIT_FAILURE;
+    }
+    if (opts::write_fast5) { LOG(error) << "--write-fast5 is not supported by this build (FASTA output only)" << std::endl; return EXIT_FAILURE; }
+    LOG(info) << "train=" << opts::train.get() << std::endl;
+    if (opts::train) {
+        LOG(info) << "train_scaling=" << !opts::no_train_scaling.get() << std::endl;
+        LOG(info) << "train_transitions=" << !opts::no_train_transitions.get() << std::endl;
+        if (!opts::no_train_scaling) {
+            LOG(info) << "double_strands_scaling=" << opts::double_strand_scaling.get() << std::endl;
+            LOG(info) << "scaling_num_events=" << opts::scaling_num_events.get() << std::endl;
+            LOG(info) << "scaling_max_rounds=" << opts::scaling_max_rounds.get() << std::endl;
+            LOG(info) << "scaling_min_progress=" << opts::scaling_min_progress.get() << std::endl;
+            LOG(info) << "scaling_select_threshold=" << opts::scaling_select_threshold.get() << std::endl;
+            LOG(info) << "train_drift=" << opts::train_drift.get() << std::endl;
+        }
+    }
+    LOG(info) << "basecall=" << opts::basecall.get() << std::endl;
+    try {
+        return real_main();
+    } catch (const std::exception& e) {
+        LOG(error) << e.what() << std::endl;
+        return EXIT_FAILURE;
+    }
+}

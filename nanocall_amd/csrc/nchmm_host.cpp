@@ -38,6 +38,7 @@ const char* nchmm_strerror(int code)
     case NCHMM_E_TOPOLOGY: return "transitions are not the stay/step/skip-1 graph of compute_transitions_fast";
     case NCHMM_E_NOMEM: return "out of memory";
     case NCHMM_E_NUMERIC: return "read decoded to -INF/NaN in every state";
+    case -7: return "I/O error (HDF5 / FAST5; see nchmm_fast5_last_error)";
     default: return "unknown error";
     }
 }

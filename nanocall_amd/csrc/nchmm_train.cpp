@@ -318,7 +318,9 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
             if (m[s] < 0) continue;
             if (m[s] >= (int)n_models) return NCHMM_E_INVALID;
             const uint64_t b = strand_off[2 * r + s], e = strand_off[2 * r + s + 1];
-            if (e - b < o->min_ed_events) continue;
+            // single-strand candidates skip short strands (nanocall.cpp:788); a 2D pair decodes both of its strands
+            // whatever their length (:715-732) -- only an empty one is left out (the reference would read ev[0])
+            if (kind == 2 ? e == b : e - b < o->min_ed_events) continue;
             off.push_back(off.back() + (e - b));
             const size_t v = cands.size();
             cands.push_back(Cand{k, s, v});

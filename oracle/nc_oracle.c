@@ -806,3 +806,153 @@ float nco_train_one_round_soa(size_t n_seqs, const uint64_t* off, const unsigned
     free(seqs); free(len); free(m0); free(m1);
     return fit;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * Fast5_Summary  (src/nanocall/Fast5_Summary.hpp)  -- see the header for the parity status
+ * ---------------------------------------------------------------------------------------- */
+
+/* alg::mean_stdv_of<float> (hpptools alg.hpp, ABSENT) as used at Fast5_Summary.hpp:225-230,256-258 and
+ * nanocall.cpp:633-635.  Same restatement as model_update_statistics above. */
+void nco_mean_stdv(const float* v, size_t n, float* mean, float* stdv)
+{
+    float s = 0, s2 = 0;
+    for (size_t i = 0; i < n; ++i) {
+        s += v[i];
+        s2 += v[i] * v[i];
+    }
+    float fn = (float)n;
+    *mean = n > 0 ? s / fn : 0;
+    float var = n > 1 ? (s2 - s * *mean) / (fn - 1) : 0;
+    *stdv = var > 0 ? sqrtf(var) : 0;
+}
+
+static int cmp_float(const void* a, const void* b)
+{
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* detect_abasic_level, Fast5_Summary.hpp:528-543 */
+static float f5_detect_abasic_level(const nco_f5_opts* o, const nco_ed_event* ed, unsigned n)
+{
+    float* s = (float*)malloc(sizeof(float) * (n ? n : 1));
+    for (unsigned i = 0; i < n; ++i) s[i] = (float)ed[i].mean;                 /* :539 */
+    qsort(s, n, sizeof(float), cmp_float);                                     /* :541 */
+    size_t idx = (size_t)((double)n * (1.0 - o->abasic_level_top_percent / 100.0));   /* :542 */
+    float r = (float)((double)s[idx] + o->abasic_level_top_offset);            /* float + double -> double -> Float_Type */
+    free(s);
+    return r;
+}
+
+typedef struct { unsigned first, second; } f5_island;
+
+/* detect_strands, Fast5_Summary.hpp:653-731 with find_islands_5_consec :545-571 */
+static void f5_detect_strands(const nco_f5_opts* o, const nco_ed_event* ed, unsigned n, float abasic_level, unsigned sb[4])
+{
+    f5_island* isl = (f5_island*)malloc(sizeof(f5_island) * (n / 5 + 2));
+    unsigned n_isl = 0;
+    unsigned i = 0;
+    while (i < n) {                                                           /* :552-569 */
+        if (ed[i].mean >= abasic_level) {
+            unsigned j = i + 1;
+            while (j < n && ed[j].mean >= abasic_level) ++j;
+            if (j - i >= 5) { isl[n_isl].first = i; isl[n_isl].second = j; ++n_isl; }
+            i = j + 1;
+        } else {
+            ++i;
+        }
+    }
+    /* merge islands within max(hp_start, hp_end) of each other, restarting after every merge (:665-676) */
+    const unsigned gap = o->trim_margins[2] > o->trim_margins[3] ? o->trim_margins[2] : o->trim_margins[3];
+    for (unsigned k = 1; k < n_isl; ++k) {
+        if (isl[k - 1].second + gap >= isl[k].first) {
+            isl[k - 1].second = isl[k].second;
+            memmove(&isl[k], &isl[k + 1], sizeof(f5_island) * (n_isl - k - 1));
+            --n_isl;
+            k = 0;
+        }
+    }
+    if (n_isl == 0) { free(isl); return; }                                    /* template only, :685-690 */
+    /* island closest to the middle (alg::min_of = first minimum), :694-698 */
+    unsigned best = 0, best_d = 0;
+    for (unsigned k = 0; k < n_isl; ++k) {
+        long a = labs((long)isl[k].first - (long)n / 2), b = labs((long)isl[k].second - (long)n / 2);
+        unsigned d = (unsigned)(a < b ? a : b);
+        if (k == 0 || d < best_d) { best = k; best_d = d; }
+    }
+    if (best_d > n / 6) { free(isl); return; }                                /* not in the middle third: template only, :700-713 */
+    sb[0] = o->trim_margins[0];                                               /* :718-729 */
+    if (isl[0].first < o->trim_margins[0] + o->trim_margins[2]) sb[0] = sb[0] > isl[0].second ? sb[0] : isl[0].second;
+    sb[1] = isl[best].first - o->trim_margins[2];
+    sb[2] = isl[best].first + o->trim_margins[3];
+    sb[3] = n - o->trim_margins[1];
+    if (isl[n_isl - 1].second > n - (o->trim_margins[3] + o->trim_margins[1]))
+        sb[3] = sb[3] < isl[n_isl - 1].first ? sb[3] : isl[n_isl - 1].first;
+    free(isl);
+}
+
+/* filter_ed_event, Fast5_Summary.hpp:734-745 */
+static int f5_filter(const nco_ed_event* e, float abasic_level)
+{
+    if (e->mean >= abasic_level) return 0;
+    if (e->stdv > 4.0) return 0;
+    return 1;
+}
+
+size_t nco_f5_load_events(const nco_f5_summary* s, const nco_ed_event* ed, float sampling_rate, unsigned st, float* mean,
+                          float* stdv, float* start, float* length)
+{
+    size_t n = 0;
+    if (s->num_ed_events == 0) return 0;
+    const unsigned ref = s->strand_bounds[s->scale_strands_together ? 0 : 2 * st];          /* :359 */
+    for (unsigned j = s->strand_bounds[2 * st]; j < s->strand_bounds[2 * st + 1]; ++j) {   /* :351-364 */
+        if (!f5_filter(&ed[j], s->abasic_level)) continue;
+        nco_event e;
+        nco_event_init(&e, (float)ed[j].mean, (float)ed[j].stdv,
+                       (float)(ed[j].start - ed[ref].start) / sampling_rate,                /* long long -> float, float divide */
+                       (float)ed[j].length / sampling_rate);
+        mean[n] = e.mean; stdv[n] = e.stdv; start[n] = e.start; length[n] = e.length;
+        ++n;
+    }
+    return n;
+}
+
+void nco_f5_summarize(const nco_f5_opts* o, const nco_ed_event* ed, size_t n_ed_file, float sampling_rate, int sst,
+                      nco_f5_summary* out)
+{
+    memset(out, 0, sizeof(*out));
+    if (sampling_rate < 1000.0 || sampling_rate > 10000.0) return;                           /* :168-172 */
+    unsigned n = n_ed_file > o->max_ed_events ? o->max_ed_events : (unsigned)n_ed_file;      /* load_ed_events :505-525 */
+    if (n < o->trim_margins[0] + o->trim_margins[1] + o->min_ed_events) return;             /* :185-191 */
+    out->abasic_level = f5_detect_abasic_level(o, ed, n);                                   /* :193 */
+    if (out->abasic_level <= 1.0) return;                                                    /* :194-200 */
+    unsigned sb[4] = {o->trim_margins[0], n - o->trim_margins[1], 0, 0};                     /* :202 */
+    if (!o->template_only) f5_detect_strands(o, ed, n, out->abasic_level, sb);
+    memcpy(out->strand_bounds, sb, sizeof(sb));
+    if (sb[1] <= sb[0]) return;                                                              /* :204-209 (bounds stay as detected) */
+    out->num_ed_events = n;
+    out->scale_strands_together = sst && sb[1] - sb[0] >= o->min_ed_events && sb[3] - sb[2] >= o->min_ed_events;   /* :210-212 */
+    /* time lengths, :214-219 */
+    for (unsigned st = 0; st < 2; ++st) {
+        const unsigned cap = sb[2 * st + 1] > sb[2 * st] ? sb[2 * st + 1] - sb[2 * st] : 0;
+        if (cap == 0) continue;
+        float* buf = (float*)malloc(sizeof(float) * 4 * cap);
+        size_t m = nco_f5_load_events(out, ed, sampling_rate, st, buf, buf + cap, buf + 2 * cap, buf + 3 * cap);
+        if (m >= o->min_ed_events) out->time_length[st] = buf[2 * cap + m - 1] + buf[3 * cap + m - 1];
+        free(buf);
+    }
+}
+
+void nco_f5_initial_scaling(int together, const float r0[2], const float r1[2], const float m0[2], const float m1[2], float out[2])
+{
+    if (together) {                                                            /* Fast5_Summary.hpp:237-241 */
+        float scale = (r0[1] / m0[1] + r1[1] / m1[1]) / 2;
+        float shift = (r0[0] - scale * m0[0] + r1[0] - scale * m1[0]) / 2;
+        out[0] = scale; out[1] = shift;
+    } else {                                                                   /* :265-267 */
+        float scale = r0[1] / m0[1];
+        float shift = r0[0] - scale * m0[0];
+        out[0] = scale; out[1] = shift;
+    }
+}

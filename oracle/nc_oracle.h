@@ -154,6 +154,43 @@ float nco_train_one_round_soa(size_t n_seqs, const uint64_t* off, const unsigned
                               float new_pm[6], float new_st[4], int* done,
                               int train_scaling, int train_transitions);
 
+/* ---- Fast5_Summary (src/nanocall/Fast5_Summary.hpp): strand segmentation, event filter, initial scaling ----
+ * PARITY UNPINNED: fast5::EventDetection_Event_Entry comes from the un-vendored fast5 submodule ([recalled]:
+ * {double mean; double stdv; long long start; long long length;}) and alg::mean_stdv_of from hpptools
+ * (restated as nco_mean_stdv: float accumulation, sample (n-1) stdv -- the same restatement the oracle's
+ * Pore_Model statistics use). */
+typedef struct { double mean, stdv; long long start, length; } nco_ed_event;
+
+typedef struct {
+    unsigned min_ed_events;               /* Fast5_Summary.hpp:74-78   (10) */
+    unsigned max_ed_events;               /* :80-84                     (100000) */
+    double abasic_level_top_percent;      /* :93-97                     (1.0) */
+    double abasic_level_top_offset;       /* :100-104                   (r9: 0.0, r73: 5.0; nanocall.cpp:943-964) */
+    unsigned template_only;               /* :121-125 */
+    unsigned trim_margins[4];             /* :128-132  sq_start, sq_end, hp_start, hp_end (50 each) */
+} nco_f5_opts;
+
+typedef struct {
+    unsigned num_ed_events;               /* 0 = read skipped */
+    float abasic_level;
+    unsigned strand_bounds[4];
+    int scale_strands_together;
+    float time_length[2];
+} nco_f5_summary;
+
+void nco_mean_stdv(const float* v, size_t n, float* mean, float* stdv);
+/* summarize (:138-319) from the EventDetection table; n_ed_file = events in the file */
+void nco_f5_summarize(const nco_f5_opts* o, const nco_ed_event* ed, size_t n_ed_file, float sampling_rate, int sst,
+                      nco_f5_summary* out);
+/* load_events (:321-370) for strand st: filtered events -> mean/stdv/start/length (stdv after update_logs); returns count.
+ * Arrays must hold strand_bounds[2st+1] - strand_bounds[2st] entries. */
+size_t nco_f5_load_events(const nco_f5_summary* s, const nco_ed_event* ed, float sampling_rate, unsigned st, float* mean,
+                          float* stdv, float* start, float* length);
+/* initial model scaling (:223-278): together != 0 -> pair (r0, r1 = strand mean/stdv; m0, m1 = model mean/stdv),
+ * else single strand (r0, m0 only).  out = {scale, shift}. */
+void nco_f5_initial_scaling(int together, const float r0[2], const float r1[2], const float m0[2], const float m1[2],
+                            float out[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,11 @@ def lib():
         L.nco_train_one_round_soa.restype = C.c_float
         L.nco_train_one_round_soa.argtypes = [C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int,
                                               vp, vp, vp, vp, vp, C.c_int, C.c_int]
+        L.nco_mean_stdv.argtypes = [vp, C.c_size_t, vp, vp]
+        L.nco_f5_summarize.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_int, vp]
+        L.nco_f5_load_events.restype = C.c_size_t
+        L.nco_f5_load_events.argtypes = [vp, vp, C.c_float, C.c_uint, vp, vp, vp, vp]
+        L.nco_f5_initial_scaling.argtypes = [C.c_int, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -128,6 +133,15 @@ class Model:
     @property
     def ptr(self):
         return _p(self.buf)
+
+    @property
+    def mean(self):
+        """Pore_Model::mean() (Pore_Model.hpp:307-313)"""
+        return np.float32(self.buf[S * 10])
+
+    @property
+    def stdv(self):
+        return np.float32(self.buf[S * 10 + 1])
 
     def states(self):
         """S x 10 in Pore_Model_State field order."""
@@ -255,3 +269,60 @@ def train_one_round(off, strand, mean, stdv, start, model0_Sx4, model1_Sx4, crt_
                                         int(train_drift), _p(cp), _p(cs), _p(npm), _p(nst), C.byref(done),
                                         int(train_scaling), int(train_transitions))
     return dict(fit=np.float32(fit), pm=npm, st=nst, done=bool(done.value))
+
+
+# ------------------------------------------------------------------------------------------------
+# Fast5_Summary: segmentation, filter, initial scaling (parity unpinned, see nc_oracle.h)
+# ------------------------------------------------------------------------------------------------
+ED_DTYPE = np.dtype([("mean", "<f8"), ("stdv", "<f8"), ("start", "<i8"), ("length", "<i8")])
+
+
+class F5Opts(C.Structure):
+    _fields_ = [("min_ed_events", C.c_uint), ("max_ed_events", C.c_uint), ("abasic_level_top_percent", C.c_double),
+                ("abasic_level_top_offset", C.c_double), ("template_only", C.c_uint), ("trim_margins", C.c_uint * 4)]
+
+
+class F5Summary(C.Structure):
+    _fields_ = [("num_ed_events", C.c_uint), ("abasic_level", C.c_float), ("strand_bounds", C.c_uint * 4),
+                ("scale_strands_together", C.c_int), ("time_length", C.c_float * 2)]
+
+
+def f5_opts(pore="r73", template_only=False, min_ed_events=10, max_ed_events=100000, trim=(50, 50, 50, 50)):
+    """The option singletons main() sets (nanocall.cpp:925-964)."""
+    o = F5Opts()
+    o.min_ed_events, o.max_ed_events = min_ed_events, max_ed_events
+    o.abasic_level_top_percent = 1.0
+    o.abasic_level_top_offset = {"r9": 0.0, "r73": 5.0}[pore]
+    o.template_only = int(template_only)
+    o.trim_margins[:] = list(trim)
+    return o
+
+
+def mean_stdv(v):
+    v = np.ascontiguousarray(v, np.float32)
+    m, s = C.c_float(0), C.c_float(0)
+    lib().nco_mean_stdv(_p(v), v.shape[0], C.byref(m), C.byref(s))
+    return np.float32(m.value), np.float32(s.value)
+
+
+def f5_summarize(opts, ed, sampling_rate, sst):
+    ed = np.ascontiguousarray(ed, ED_DTYPE)
+    out = F5Summary()
+    lib().nco_f5_summarize(C.byref(opts), _p(ed), ed.shape[0], C.c_float(sampling_rate), int(sst), C.byref(out))
+    return out
+
+
+def f5_load_events(summary, ed, sampling_rate, st):
+    """-> (mean, stdv, start, length) float32 arrays of the filtered events of strand st."""
+    ed = np.ascontiguousarray(ed, ED_DTYPE)
+    cap = max(0, int(summary.strand_bounds[2 * st + 1]) - int(summary.strand_bounds[2 * st]))
+    bufs = [np.empty(cap, np.float32) for _ in range(4)]
+    n = lib().nco_f5_load_events(C.byref(summary), _p(ed), C.c_float(sampling_rate), st, *[_p(b) for b in bufs]) if cap else 0
+    return tuple(b[:n].copy() for b in bufs)
+
+
+def f5_initial_scaling(together, r0, r1, m0, m1):
+    a = [np.ascontiguousarray(x if x is not None else (0, 1), np.float32) for x in (r0, r1, m0, m1)]
+    out = np.empty(2, np.float32)
+    lib().nco_f5_initial_scaling(int(together), *[_p(x) for x in a], _p(out))
+    return out

@@ -1,0 +1,223 @@
+"""The `nanocall` command line (nanocall_amd/bin/nanocall: FAST5 / event tables -> segmentation -> EM -> Viterbi ->
+FASTA on the GPU) against the reference driver transcribed on the CPU oracle (tests/oracle_pipeline.py).
+
+Two kinds of comparison:
+  * no EM in the way (--no-train): the FASTA must be byte-identical to the oracle pipeline's, record for record;
+  * with EM: the trained parameters are floats that agree with the oracle's within the EM tolerances of
+    test_fwbw_gpu.py (not bit for bit), so the decode is checked TEACHER-FORCED -- the oracle decodes with exactly
+    the parameters the CLI reports (--dump-params, hex floats) and that FASTA must be byte-identical -- while the
+    control flow (model chosen, rounds) and the parameters themselves are compared with the free-running oracle.
+BASELINE config 1 (single FAST5 read, template strand, builtin R7.3 model, 1 EM round) is test_config1_*.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_pipeline as op
+from test_fast5_ingest import parse_events
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "nanocall_amd", "bin", "nanocall")
+G = os.path.join(ROOT, "tests", "golden", "fast5")
+
+
+def run_cli(args, env=None, expect_rc=0):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([CLI] + args, capture_output=True, text=True, env=e, timeout=1200)
+    assert p.returncode == expect_rc, f"rc={p.returncode}\n{p.stderr[-3000:]}"
+    return p
+
+
+def fixture_inputs(names, ext=".fast5"):
+    """[(path the CLI is given, table for the oracle pipeline)] -- the table is parsed from the .events twin."""
+    out = []
+    for n in names:
+        rate, rid, ed = parse_events(os.path.join(G, n + ".events"))
+        if n == "r9_2d_d" and ext == ".fast5":         # stored as variance in the FAST5
+            ed["stdv"] = np.sqrt(ed["stdv"] * ed["stdv"])
+        if n == "r73_1d_b" and ext == ".fast5":        # written without a read_id attribute
+            rid = ""
+        out.append((os.path.join(G, n + ext), dict(sampling_rate=rate, read_id=rid, events=ed)))
+    return out
+
+
+def split_fasta(text):
+    recs, name = {}, None
+    for line in text.splitlines():
+        if line.startswith(">"):
+            name = line[1:]
+            recs[name] = ""
+        else:
+            recs[name] += line
+    return recs
+
+
+def check_teacher_forced(o, inputs, fasta, dump):
+    forced = {k: (v["model"], v["pm"], v["st"]) for k, v in dump.items()}
+    exp, _, recs = op.run(o, inputs, forced=forced)
+    assert fasta == exp, "FASTA differs from the oracle decode with the CLI's own parameters"
+    for name, seq, info in recs:
+        rid, _, st = name.rsplit(":", 2)
+        got = dump[(rid, int(st))]["logp"]
+        assert np.float32(got).tobytes() == np.float32(info["logp"]).tobytes(), (name, got, info["logp"])
+    return recs
+
+
+def check_free_running(o, inputs, dump, fasta):
+    """Control flow and parameters against the oracle's own EM."""
+    exp_fasta, reads, recs = op.run(o, inputs)
+    assert len(recs) == len(dump)
+    for name, seq, info in recs:
+        rid, _, st = name.rsplit(":", 2)
+        d = dump[(rid, int(st))]
+        assert d["model"] == info["model"], (name, d["model"], info["model"])
+        pm, got = info["pm"], d["pm"]
+        assert abs(got[0] - pm[0]) <= 2e-4 * abs(pm[0]) and abs(got[4] - pm[4]) <= 2e-4 * abs(pm[4]), (name, got, pm)
+        assert abs(got[1] - pm[1]) <= 2e-4 * 60 and abs(got[2] - pm[2]) <= 2e-4 * 60 / 5.0, (name, got, pm)
+        assert abs(got[3] - pm[3]) <= 1.5e-3 * abs(pm[3]) and abs(got[5] - pm[5]) <= 1.5e-3 * abs(pm[5]), (name, got, pm)
+        assert np.allclose(d["st"], info["st"], rtol=5e-4, atol=0), (name, d["st"], info["st"])
+        assert abs(d["logp"] - info["logp"]) <= 1e-4 * abs(info["logp"]), (name, d["logp"], info["logp"])
+    for r in reads:
+        for key, rounds in r.rounds.items():
+            for st in (0, 1):
+                d = dump.get((r.read_id, st))
+                if d is not None and key[st] == d["model"] and (not r.together or all(key[s] == dump[(r.read_id, s)]["model"] for s in (0, 1))):
+                    assert d["rounds"] == rounds, (r.read_id, key, d["rounds"], rounds)
+                    assert abs(d["fit"] - r.fit[key]) <= 1e-4 * abs(r.fit[key])
+    # the free-running FASTA is normally identical too; report how close it is rather than require it
+    a, b = split_fasta(fasta), split_fasta(exp_fasta)
+    assert a.keys() == b.keys()
+    return sum(a[k] == b[k] for k in a), len(a)
+
+
+def test_no_train_fasta_is_byte_identical_r73_2d_and_1d(tmp_path):
+    """No EM: initial scaling (Fast5_Summary.hpp:223-278) straight into Viterbi with every candidate model."""
+    names = ["r73_2d_a", "r73_1d_b", "r73_short_c", "r73_2d_e"]
+    inputs = fixture_inputs(names)
+    out = tmp_path / "out.fa"
+    p = run_cli(["--pore", "r73", "--no-train", "-o", str(out)] + [i[0] for i in inputs])
+    o = op.Opts(pore="r73", train=False)
+    exp, reads, recs = op.run(o, inputs)
+    assert [r.together for r in reads] == [False] * 4          # nanocall.cpp:1025-1038: no training -> no 2D scaling
+    assert len(recs) == 5                                       # 2 + 1 + 0 + 2 strands
+    assert out.read_text() == exp
+    assert "rid-1-2d:r73_2d_a:0" in exp and "r73_1d_b:r73_1d_b:0" in exp
+    # --1d: the hairpin is ignored, the whole read is one template strand
+    p = run_cli(["--pore", "r73", "--no-train", "--1d"] + [i[0] for i in inputs])
+    exp, _, recs = op.run(op.Opts(pore="r73", train=False, one_d=True), inputs)
+    assert len(recs) == 3 and p.stdout == exp
+
+
+def test_no_train_r9_preset_and_fasta_line_width(tmp_path):
+    inputs = fixture_inputs(["r9_2d_d", "r9_1d_f"])
+    p = run_cli(["--no-train", "--fasta-line-width", "60"] + [i[0] for i in inputs])      # --pore defaults to r9
+    exp, reads, recs = op.run(op.Opts(pore="r9", train=False, fasta_line_width=60), inputs)
+    assert len(recs) == 3 and p.stdout == exp
+    assert max(len(l) for l in p.stdout.splitlines() if not l.startswith(">")) == 60
+
+
+def test_config1_single_fast5_read_template_strand_one_em_round(tmp_path):
+    """BASELINE config 1: one FAST5 read, template strand, builtin R7.3 model, 1 EM round, -t 1."""
+    inputs = fixture_inputs(["r73_1d_b"])
+    dump = tmp_path / "params.tsv"
+    args = ["--pore", "r73", "--1d", "--scaling-max-rounds", "1", "-t", "1", "--dump-params", str(dump)]
+    p = run_cli(args + [inputs[0][0]])
+    o = op.Opts(pore="r73", one_d=True, scaling_max_rounds=1)
+    d = op.read_dump(str(dump))
+    assert list(d) == [("r73_1d_b", 0)] and d[("r73_1d_b", 0)]["rounds"] == 1
+    check_teacher_forced(o, inputs, p.stdout, d)
+    same, n = check_free_running(o, inputs, d, p.stdout)
+    assert n == 1
+    assert p.stdout.startswith(">r73_1d_b:r73_1d_b:0\n")
+
+
+@pytest.mark.parametrize("pore,names,extra", [
+    ("r73", ["r73_2d_a", "r73_1d_b", "r73_short_c"], []),                       # 2D scaling, drift trained (r73 preset)
+    ("r9", ["r9_2d_d", "r9_1d_f"], []),                                          # r9 preset: no drift training
+    ("r73", ["r73_2d_e", "r73_2d_a"], ["--single-strand-scaling"]),              # per-strand jobs, model selection per strand
+])
+def test_trained_decode_teacher_forced_and_em_within_tolerance(tmp_path, pore, names, extra):
+    inputs = fixture_inputs(names)
+    dump, out, stats = tmp_path / "params.tsv", tmp_path / "out.fa", tmp_path / "stats.tsv"
+    args = ["--pore", pore, "--scaling-num-events", "120", "--scaling-max-rounds", "2", "--dump-params", str(dump), "-o", str(out),
+            "--stats", str(stats), "-t", "4"] + extra
+    run_cli(args + [i[0] for i in inputs])
+    o = op.Opts(pore=pore, scaling_num_events=120, scaling_max_rounds=2, single_strand_scaling=bool(extra))
+    d = op.read_dump(str(dump))
+    fasta = out.read_text()
+    check_teacher_forced(o, inputs, fasta, d)
+    same, n = check_free_running(o, inputs, d, fasta)
+    print(f"free-running FASTA records identical to the oracle's: {same}/{n}")
+    # --stats: one row per input (skipped reads too), reference column layout (Fast5_Summary.hpp:460-502)
+    rows = stats.read_text().splitlines()
+    assert rows[0].split("\t")[:4] == ["file_name", "read_name", "num_ed_events", "abasic_level"] and len(rows[0].split("\t")) == 8 + 2 * 9
+    assert len(rows) == 1 + len(names)
+    for row, n_ in zip(rows[1:], names):
+        f = row.split("\t")
+        assert f[0] == n_ and len(f) == 26
+        for st in (0, 1):
+            key = (f[1], st)
+            if key in d:
+                assert f[8 + 9 * st] == d[key]["model"]
+                assert f[9 + 9 * st] == f"{d[key]['pm'][0]:.5f}" and f[15 + 9 * st] == f"{d[key]['st'][0]:.5f}"
+            else:
+                assert f[8 + 9 * st] == "."
+
+
+def test_fast5_and_event_table_inputs_fofn_and_directory_agree(tmp_path):
+    names = ["r73_2d_a", "r73_2d_e"]
+    a = run_cli(["--pore", "r73", "--no-train"] + [os.path.join(G, n + ".fast5") for n in names]).stdout
+    b = run_cli(["--pore", "r73", "--no-train"] + [os.path.join(G, n + ".events") for n in names]).stdout
+    # same events -> same sequences; the record names differ only by the base file name (".events" is not stripped)
+    assert [s for s in split_fasta(a).values()] == [s for s in split_fasta(b).values()]
+    fofn = tmp_path / "reads.fofn"
+    fofn.write_text("".join(os.path.join(G, n + ".fast5") + "\n" for n in names) + "/nonexistent/file.fast5\n")
+    assert run_cli(["--pore", "r73", "--no-train", str(fofn)]).stdout == a
+    d = tmp_path / "dir"
+    d.mkdir()
+    for n in names:
+        os.symlink(os.path.join(G, n + ".fast5"), d / (n + ".fast5"))
+    (d / "notes.txt").write_text("not a read\n")
+    got = split_fasta(run_cli(["--pore", "r73", "--no-train", str(d)]).stdout)
+    assert got == split_fasta(a)                                 # readdir order is unspecified: compare per record
+
+
+def test_two_contexts_shard_the_reads_and_gather_counters(tmp_path):
+    """The multi-GPU host path on one GPU: two contexts / host threads on device 0 (NANOCALL_DEVICE_IDS=0,0), reads
+    sharded by event count, output in input order -- byte-identical to the single-context run."""
+    names = ["r73_2d_a", "r73_1d_b", "r73_short_c", "r73_2d_e", "r73_2d_a", "r73_1d_b"]
+    files = [os.path.join(G, n + ".fast5") for n in names]
+    base = ["--pore", "r73", "--scaling-num-events", "120", "--scaling-max-rounds", "2", "--log", "info"]
+    one = run_cli(base + files)
+    two = run_cli(base + files, env={"NANOCALL_DEVICE_IDS": "0,0"})
+    assert one.stdout == two.stdout and one.stdout.count(">") == 8
+    assert "devices=2" in two.stderr and "gathered_by=host_sum" in two.stderr
+    c1 = [l for l in one.stderr.splitlines() if "counters reads=" in l][0]
+    c2 = [l for l in two.stderr.splitlines() if "counters reads=" in l][0]
+    pick = lambda l, k: l.split(k + "=")[1].split()[0]
+    for k in ("reads", "bases", "strands_decoded", "events_decoded", "fb_windows"):
+        assert pick(c1, k) == pick(c2, k), k
+    # tiny chunks: several batches, same output
+    three = run_cli(base + ["--chunk-events", "1500"] + files, env={"NANOCALL_DEVICE_IDS": "0,0"})
+    assert three.stdout == one.stdout
+    # the RCCL path itself (ncclCommInitAll over the pool's devices + one all-reduce) on the single device
+    four = run_cli(base + files, env={"NCHMM_POOL_FORCE_RCCL": "1"})
+    assert four.stdout == one.stdout
+    c4 = [l for l in four.stderr.splitlines() if "counters reads=" in l][0]
+    assert "gathered_by=rccl_allreduce" in c4 and pick(c4, "events_decoded") == pick(c1, "events_decoded")
+
+
+def test_option_errors_and_help():
+    assert "Required argument missing" in run_cli([], expect_rc=1).stderr
+    assert "unknown pore type" in run_cli(["--pore", "r10", os.path.join(G, "r73_1d_b.fast5")], expect_rc=1).stderr
+    assert "not both" in run_cli(["--train", "--no-train", os.path.join(G, "r73_1d_b.fast5")], expect_rc=1).stderr
+    assert "Couldn't find match" in run_cli(["--frobnicate", "x"], expect_rc=1).stderr
+    h = run_cli(["--help"]).stdout
+    for opt in ("--pore", "--1d", "--scaling-max-rounds", "--pr-skip", "--pr-stay", "--fasta-line-width", "--stats", "--no-train-transitions"):
+        assert opt in h
+    assert "cannot open" in run_cli(["--pore", "r73", "/nonexistent/x.fast5"], expect_rc=1).stderr

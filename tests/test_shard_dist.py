@@ -58,3 +58,17 @@ def test_two_rank_gloo_counter_gather():
         assert mx == 2.0
         seen += mine
     assert sorted(seen) == list(range(40))
+
+
+def test_c_abi_lpt_partition_equals_the_python_one():
+    """nchmm_lpt_partition (what the C++ host / CLI shards with) against nanocall_amd.shard.lpt_partition."""
+    from nanocall_amd import api
+    rng = np.random.default_rng(5)
+    cases = [rng.integers(10, 50000, size=1000), np.full(100000, 5000), np.full(7, 3), np.array([], np.int64),
+             np.array([5, 5, 9, 9, 1]), rng.integers(1, 4, size=64)]
+    for lens in cases:
+        for ws in (1, 2, 3, 8):
+            of = api.lpt_partition(lens, ws)
+            parts = shard.lpt_partition(lens, ws)
+            for k in range(ws):
+                assert np.array_equal(np.nonzero(of == k)[0], parts[k]), (len(lens), ws, k)

@@ -263,19 +263,9 @@ def test_exactness_branches_are_exercised(r73t):
     an ordinary read where at least the tie rule does (866 exact ties in a 3k-event read)."""
     ctx = _profiled_ctx()
     try:
-        # (1) every state identical: every 3-way combine is a tie
-        t = r73t.copy()
-        t[:, :] = t[0, :]
-        n = 50
-        cm, sd, ls = na.events_prepare(np.full(n, t[0, 0], np.float32), np.full(n, t[0, 2], np.float32), None, 0.0)
-        off = np.array([0, n], np.uint64)
-        states, logp, _ = _run(ctx, t, IDENT, 0.3, 0.1, off, cm, sd, ls)
-        tk = ctx.profile_ticks()
-        assert tk[7] > 0, "the exact tie rule never ran on all-equal alphas"
-        ostates, ologp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
-        assert np.array_equal(states, ostates)
-        assert_bits_equal(logp, ologp, "path probability")
-        # (2) an ordinary 5000-event read: alphas of order -1e4 have an ulp of ~1e-3, exact ties happen
+        # (identical states tie inside the groups, which the ascending strict-> scans settle; the three CLASS winners
+        # differ by their weights there, so that input does not reach the combine's tie rule)
+        # an ordinary 5000-event read: alphas of order -1e4 have an ulp of ~1e-3, exact ties between classes happen
         off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [5000], first_read=0)
         states, logp, _ = _run(ctx, r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
         tk = ctx.profile_ticks()
