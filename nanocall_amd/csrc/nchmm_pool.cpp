@@ -3,10 +3,12 @@
 #include "nanocall_hip.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -34,6 +36,9 @@ struct Rccl {
     bool ok = false;
     Rccl()
     {
+        // RCCL writes its version banner / warnings to stdout unless told otherwise; a host program may be streaming
+        // FASTA there (nanocall without -o), so send them to stderr -- unless the user chose a file
+        setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
         for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
@@ -54,6 +59,14 @@ Rccl& rccl()
     return r;
 }
 
+// RCCL 2.27 prints a version banner on stdout from ncclCommInitAll whatever NCCL_DEBUG says.  A host program may be
+// streaming FASTA on stdout (nanocall without -o): while the communicators are created, fd 1 points at stderr.
+struct Stdout_To_Stderr {
+    int saved;
+    Stdout_To_Stderr() { std::fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+    ~Stdout_To_Stderr() { std::fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+};
+
 // sum of eight uint64 per device over the devices, through RCCL; false on any failure (the caller falls back)
 bool rccl_sum(const std::vector<int>& dev, std::vector<uint64_t>& per_dev /* 8 per device, in/out: every slot gets the sum */)
 {
@@ -61,7 +74,10 @@ bool rccl_sum(const std::vector<int>& dev, std::vector<uint64_t>& per_dev /* 8 p
     if (!R.ok) return false;
     const int n = (int)dev.size();
     std::vector<ncclComm_t> comm((size_t)n);
-    if (R.CommInitAll(comm.data(), n, dev.data()) != ncclSuccess) return false;
+    {
+        Stdout_To_Stderr guard;
+        if (R.CommInitAll(comm.data(), n, dev.data()) != ncclSuccess) return false;
+    }
     std::vector<uint64_t*> buf((size_t)n, nullptr);
     std::vector<hipStream_t> st((size_t)n, nullptr);
     bool ok = true;
