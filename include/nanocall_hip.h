@@ -249,6 +249,23 @@ int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t 
                       const uint32_t* d_order, uint16_t* d_out_state, float* d_out_path_logp,
                       int32_t* d_out_status);
 
+/* Viterbi from RAW events, with the host prep of basecall_strand on the device:
+ * candidate v decodes raw events [src[v], src[v] + len[v]) of the uploaded (mean, stdv, start) arrays -- several
+ * candidates may share a range (one strand, several models / parameter sets, nanocall.cpp:715-732,809-818) -- after
+ *   Event::update_logs            stdv == 0 -> 0.01, log_stdv = log(stdv)                (Event.hpp:39-43)
+ *   apply_drift_correction        corrected_mean = mean - drift[v] * start               (Event.hpp:77-84, nanocall.cpp:685-686)
+ * done by a gather kernel; log() there is a port of glibc 2.35 logf that is bit-identical to the host libm over all
+ * binary32 inputs (nchmm_logf; tests/test_logf_gpu.py), so the decoded path is the same as with host prep.
+ * The raw arrays go up once (12 B per event however many candidates).  out_state is packed by candidate:
+ * candidate v's states start at sum_{u < v} len[u].  model_slot / trans_slot / out_status as nchmm_viterbi. */
+int nchmm_viterbi_raw(nchmm_ctx* ctx, size_t n_raw_events, const float* mean, const float* stdv, const float* start,
+                      size_t n_cand, const uint64_t* src, const uint32_t* len, const float* drift, const int32_t* model_slot,
+                      const int32_t* trans_slot, uint16_t* out_state, float* out_path_logp, int32_t* out_status);
+
+/* logf on the device, bit-identical to glibc 2.35 logf as x86-64 CPUs with FMA run it: out[i] = log(in[i]), host
+ * buffers, any n (chunked).  Exists so that the claim above can be checked exhaustively. */
+int nchmm_logf(nchmm_ctx* ctx, size_t n, const float* in, float* out);
+
 /* ------------------------------------------------------------------------------------------
  * Forward-backward + EM sufficient statistics -- replaces Forward_Backward::fill
  * (Forward_Backward.hpp:46-135) as called from Parameter_Trainer::fill_train_data

@@ -326,6 +326,32 @@ class Context:
             check(rc, "nchmm_viterbi")
         return states, logp, status
 
+    def viterbi_raw(self, mean, stdv, start, src, length, drift, model_slot=None, trans_slot=None, raise_on_numeric=True):
+        """nchmm_viterbi_raw: candidates over raw events, host prep on the device.
+        Returns (states u16[sum(length)] packed by candidate, path_logp f32[n_cand], status i32[n_cand])."""
+        mean, stdv, start = _f32(mean), _f32(stdv), _f32(start)
+        src = np.ascontiguousarray(src, np.uint64)
+        ln = np.ascontiguousarray(length, np.uint32)
+        dr = _f32(drift)
+        n = src.shape[0]
+        ms = None if model_slot is None else np.ascontiguousarray(model_slot, np.int32)
+        ts = None if trans_slot is None else np.ascontiguousarray(trans_slot, np.int32)
+        states = np.empty(int(ln.sum()), np.uint16)
+        logp = np.empty(n, np.float32)
+        status = np.zeros(n, np.int32)
+        rc = lib().nchmm_viterbi_raw(self._h, mean.shape[0], _p(mean), _p(stdv), _p(start), n, _p(src), _p(ln), _p(dr), _p(ms), _p(ts),
+                                     _p(states), _p(logp), _p(status))
+        if rc != 0 and not (rc == -6 and not raise_on_numeric):
+            check(rc, "nchmm_viterbi_raw")
+        return states, logp, status
+
+    def logf(self, x):
+        """Device logf (bit-identical port of glibc's) on a host array."""
+        x = _f32(x)
+        out = np.empty_like(x)
+        check(lib().nchmm_logf(self._h, x.shape[0], _p(x), _p(out)), "nchmm_logf")
+        return out
+
     def viterbi_dev(self, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_out_state,
                     d_out_logp, d_out_status=None, d_model_slot=None, d_trans_slot=None, d_order=None):
         """Device-resident batch Viterbi on torch CUDA tensors; asynchronous on the context's stream."""

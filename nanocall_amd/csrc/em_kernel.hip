@@ -10,9 +10,13 @@
 //                     to the host, which solves the 3x3 system (nchmm_train_pm_solve).
 #include "nchmm_device.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace nchmm {
+
+constexpr unsigned kGatherChunk = 4096;   // events per block along a window / strand (blockIdx.y)
 
 __global__ __launch_bounds__(256) void em_gather_kernel(EmGatherArgs P)
 {
@@ -20,13 +24,25 @@ __global__ __launch_bounds__(256) void em_gather_kernel(EmGatherArgs P)
     const uint64_t src = P.win_src[w], dst = P.off[w];
     const unsigned n = (unsigned)(P.off[w + 1] - dst);
     const float drift = P.win_drift[w];
-    for (unsigned i = threadIdx.x; i < n; i += 256) {
+    const unsigned lo = blockIdx.y * kGatherChunk, hi = lo + kGatherChunk < n ? lo + kGatherChunk : n;
+    for (unsigned i = lo + threadIdx.x; i < hi; i += 256) {
         float c = P.mean[src + i];
         c -= drift * P.start[src + i];          // apply_drift_correction
         P.cmean[dst + i] = c;
-        P.out_stdv[dst + i] = P.stdv[src + i];
-        P.out_lstdv[dst + i] = P.lstdv[src + i];
+        float sd = P.stdv[src + i];
+        if (P.lstdv) {
+            P.out_lstdv[dst + i] = P.lstdv[src + i];
+        } else {
+            if (sd == 0.0f) sd = 0.01f;         // Event::update_logs, Event.hpp:39-42
+            P.out_lstdv[dst + i] = glibc_logf(sd);
+        }
+        P.out_stdv[dst + i] = sd;
     }
+}
+
+__global__ __launch_bounds__(256) void logf_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = glibc_logf(in[i]);
 }
 
 __global__ __launch_bounds__(256) void em_reduce_kernel(EmReduceArgs P)
@@ -71,9 +87,15 @@ __global__ __launch_bounds__(256) void em_reduce_kernel(EmReduceArgs P)
     if (threadIdx.x < 13) P.out[13 * (size_t)job + threadIdx.x] = (sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x]) + (sAcc[2][threadIdx.x] + sAcc[3][threadIdx.x]);
 }
 
-void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream)
+void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream, unsigned max_events)
 {
-    if (n_win) hipLaunchKernelGGL(em_gather_kernel, dim3(n_win), dim3(256), 0, stream, a);
+    const unsigned chunks = max_events > kGatherChunk ? (max_events + kGatherChunk - 1) / kGatherChunk : 1;
+    if (n_win) hipLaunchKernelGGL(em_gather_kernel, dim3(n_win, chunks), dim3(256), 0, stream, a);
+}
+
+void launch_logf(const float* in, float* out, size_t n, hipStream_t stream)
+{
+    if (n) hipLaunchKernelGGL(logf_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, stream, in, out, n);
 }
 
 void launch_em_reduce(const EmReduceArgs& a, unsigned n_jobs, hipStream_t stream)

@@ -725,6 +725,93 @@ int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float
     return worst;
 }
 
+int nchmm_logf(nchmm_ctx* c, size_t n, const float* in, float* out)
+{
+    if (!c || (n && (!in || !out))) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t chunk = (size_t)1 << 24;
+    int rc = ensure(c, &c->d_stage, &c->stage_bytes, 2 * sizeof(float) * std::min(n ? n : 1, chunk));
+    if (rc != NCHMM_OK) return rc;
+    float* d_in = (float*)c->d_stage;
+    float* d_out = d_in + std::min(n ? n : 1, chunk);
+    for (size_t b = 0; b < n; b += chunk) {
+        const size_t m = std::min(chunk, n - b);
+        HIP_TRY(c, hipMemcpyAsync(d_in, in + b, m * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        launch_logf(d_in, d_out, m, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(out + b, d_out, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return NCHMM_OK;
+}
+
+int nchmm_viterbi_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, const float* start, size_t n_cand,
+                      const uint64_t* src, const uint32_t* len, const float* drift, const int32_t* model_slot,
+                      const int32_t* trans_slot, uint16_t* out_state, float* out_logp, int32_t* out_status)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_cand == 0) return NCHMM_OK;
+    if (!src || !len || !drift || !out_logp || (n_raw && (!mean || !stdv || !start))) return NCHMM_E_INVALID;
+    std::vector<uint64_t> off(n_cand + 1, 0);
+    size_t max_events = 0;
+    for (size_t v = 0; v < n_cand; ++v) {
+        if (src[v] + len[v] > n_raw) return NCHMM_E_INVALID;
+        off[v + 1] = off[v] + len[v];
+        max_events = std::max<size_t>(max_events, len[v]);
+        const int ms = model_slot ? model_slot[v] : 0, ts = trans_slot ? trans_slot[v] : 0;
+        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts]) return NCHMM_E_INVALID;
+    }
+    const size_t total = (size_t)off[n_cand];
+    if (total && !out_state) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint32_t> order(n_cand);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // [raw mean | stdv | start | src | drift | off | cm | sd | ls | mslot | tslot | order | state | logp | status]
+    size_t o_rm = 0, o_rs = o_rm + al(4 * n_raw), o_rt = o_rs + al(4 * n_raw), o_src = o_rt + al(4 * n_raw), o_dr = o_src + al(8 * n_cand);
+    size_t o_off = o_dr + al(4 * n_cand), o_cm = o_off + al(8 * (n_cand + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total);
+    size_t o_ms = o_ls + al(4 * total), o_ts = o_ms + al(4 * n_cand), o_or = o_ts + al(4 * n_cand), o_st = o_or + al(4 * n_cand);
+    size_t o_lp = o_st + al(2 * total), o_ss = o_lp + al(4 * n_cand), need = o_ss + al(4 * n_cand);
+    int rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
+    if (rc != NCHMM_OK) return rc;
+    char* d = (char*)c->d_stage;
+    hipStream_t s = c->stream;
+    if (n_raw) {
+        HIP_TRY(c, hipMemcpyAsync(d + o_rm, mean, 4 * n_raw, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_rs, stdv, 4 * n_raw, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_rt, start, 4 * n_raw, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(d + o_src, src, 8 * n_cand, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d + o_dr, drift, 4 * n_cand, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d + o_off, off.data(), 8 * (n_cand + 1), hipMemcpyHostToDevice, s));
+    if (model_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ms, model_slot, 4 * n_cand, hipMemcpyHostToDevice, s));
+    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_cand, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d + o_or, order.data(), 4 * n_cand, hipMemcpyHostToDevice, s));
+    EmGatherArgs g;
+    g.mean = (const float*)(d + o_rm); g.stdv = (const float*)(d + o_rs); g.start = (const float*)(d + o_rt); g.lstdv = nullptr;
+    g.win_src = (const uint64_t*)(d + o_src); g.off = (const uint64_t*)(d + o_off); g.win_drift = (const float*)(d + o_dr);
+    g.cmean = (float*)(d + o_cm); g.out_stdv = (float*)(d + o_sd); g.out_lstdv = (float*)(d + o_ls);
+    launch_em_gather(g, (unsigned)n_cand, s, (unsigned)max_events);
+    HIP_TRY(c, hipGetLastError());
+    rc = nchmm_viterbi_dev(c, n_cand, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
+                           (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
+                           trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or), (uint16_t*)(d + o_st),
+                           (float*)(d + o_lp), (int32_t*)(d + o_ss));
+    if (rc != NCHMM_OK) return rc;
+    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(out_logp, d + o_lp, 4 * n_cand, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> status(n_cand);
+    HIP_TRY(c, hipMemcpyAsync(status.data(), d + o_ss, 4 * n_cand, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    int worst = NCHMM_OK;
+    for (size_t v = 0; v < n_cand; ++v) {
+        if (out_status) out_status[v] = status[v];
+        if (status[v] != 0) worst = NCHMM_E_NUMERIC;
+    }
+    return worst;
+}
+
 int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_events, const uint64_t* d_off,
                    const float* d_cmean, const float* d_stdv, const float* d_lstdv, const int32_t* d_scaled_slot,
                    const float* d_pm_params, const int32_t* d_trans_slot, const float* d_st_params,

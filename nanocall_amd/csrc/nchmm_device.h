@@ -93,8 +93,52 @@ void launch_scale_models(const float* d_states, const int32_t* d_table_idx, cons
                          int32_t* d_model_fast, int first_slot, size_t n, float log_2pi, hipStream_t stream);
 void launch_expand_transitions(const float* d_wm, const uint8_t* d_masks, float* d_trans, float* d_trans_fb, int first_slot,
                                size_t n, hipStream_t stream);
+// glibc 2.35 logf (sysdeps/ieee754/flt-32/e_logf.c, table + cubic in double) as x86-64 machines with FMA execute it
+// (the ifunc-selected __logf_fma: every  a * b + c  below is one fused operation there -- read off the disassembly of
+// libm.so.6, and off the published source for the constants).  Device fp64 FMA is IEEE, so the double result and its
+// rounding to float are the host's, bit for bit: tests/test_logf_gpu.py checks all 2^31 non-negative inputs (and the
+// negative / NaN classes) against the host libm.  This is what lets Event::update_logs' log(stdv) (Event.hpp:43) move to
+// the device without touching the bit-exact contract of the Viterbi path.
+__device__ __forceinline__ float glibc_logf(float x)
+{
+    // T[i] = {1/c_i, log(c_i)}, c_i near the centre of the i-th of 16 sub-intervals of [0x1.66p-1, 0x1.66p0)
+    const double invc[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
+                             0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
+                             0x1.0953f419900a7p+0, 0x1p+0,               0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                             0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+    const double logc[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
+                             -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,   -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4,
+                             -0x1.252f438e10c1ep-5, 0x0p+0,                0x1.aa5aa5df25984p-5,  0x1.c5e53aa362eb4p-4,
+                             0x1.526e57720db08p-3,  0x1.bc2860d22477p-3,   0x1.1058bc8a07ee1p-2,  0x1.4043057b6ee09p-2};
+    const double Ln2 = 0x1.62e42fefa39efp-1;
+    const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+    unsigned ix = __builtin_bit_cast(unsigned, x);
+    if (ix == 0x3f800000u) return 0.0f;                                   // log(1) = +0
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {                  // x < 0x1p-126, or inf, or nan
+        if (ix * 2u == 0u) return -__builtin_inff();                      // log(+-0) = -inf
+        if (ix == 0x7f800000u) return x;                                  // log(inf) = inf
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");   // x < 0 or NaN
+        ix = __builtin_bit_cast(unsigned, x * 0x1p23f);                   // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const unsigned tmp = ix - 0x3f330000u;
+    const unsigned i = (tmp >> 19) & 15u;
+    const int k = (int)tmp >> 23;                                         // arithmetic shift
+    const unsigned iz = ix - (tmp & 0xff800000u);
+    const double z = (double)__builtin_bit_cast(float, iz);
+    const double r = __builtin_fma(z, invc[i], -1.0);
+    const double y0 = __builtin_fma((double)k, Ln2, logc[i]);
+    const double r2 = r * r;
+    double y = __builtin_fma(A1, r, A2);
+    y = __builtin_fma(A0, r2, y);
+    y = __builtin_fma(y, r2, y0 + r);
+    return (float)y;
+}
+
 struct EmGatherArgs {
-    const float* mean; const float* stdv; const float* start; const float* lstdv;   // resident raw events
+    const float* mean; const float* stdv; const float* start;
+    const float* lstdv;   // resident raw events; lstdv == nullptr: log(stdv) is computed here (glibc_logf), and
+                          // stdv == 0 becomes 0.01 first (Event::update_logs, Event.hpp:39-43)
     const uint64_t* win_src;   // [n_win] first raw event of each window
     const uint64_t* off;       // [n_win + 1] packed offsets
     const float* win_drift;    // [n_win]
@@ -108,7 +152,8 @@ struct EmReduceArgs {
     int train_drift;
     double* out;                     // [n_jobs][13]
 };
-void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream);
+void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream, unsigned max_events = 0);
+void launch_logf(const float* in, float* out, size_t n, hipStream_t stream);
 void launch_em_reduce(const EmReduceArgs& a, unsigned n_jobs, hipStream_t stream);
 void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream, bool scaled);
 void launch_fwbw_scaled(const FwbwArgs& a, int grid, hipStream_t stream);

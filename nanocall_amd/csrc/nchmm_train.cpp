@@ -332,36 +332,29 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
             slot_t.push_back((int32_t)v);
         }
     }
-    // every candidate's events, drift-corrected with ITS parameters; the candidates fill their slices in parallel
-    // (Event::update_logs happened at load time in the reference: log_stdv = log(stdv), float libm)
+    // every candidate's events are drift-corrected with ITS parameters and get their log_stdv ON THE DEVICE
+    // (nchmm_viterbi_raw: one upload of the raw events, a gather kernel per batch); only the candidate table is built here
     const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     const size_t tot = (size_t)off.back();
-    // host staging lives with the calling thread and only grows: a fresh 290 MB per call costs more in page faults
-    // and unmapping than the gather itself (no zero fill either)
-    struct Staging { std::unique_ptr<float[]> cm, sd, ls; std::unique_ptr<uint16_t[]> states; size_t cap = 0; };
+    std::vector<uint64_t> c_src(cands.size());
+    std::vector<uint32_t> c_len(cands.size());
+    std::vector<float> c_drift(cands.size());
+    for (size_t v = 0; v < cands.size(); ++v) {
+        const size_t k = cands[v].job;
+        const int r = job_read[k];
+        c_src[v] = strand_off[2 * r + cands[v].strand];
+        c_len[v] = (uint32_t)(off[v + 1] - off[v]);
+        c_drift[v] = job_pm[6 * k + 2];   // corrected_events.apply_drift_correction(pm_params.drift), nanocall.cpp:685-686
+    }
+    // host buffer for the decoded states of all candidates: lives with the calling thread and only grows
+    struct Staging { std::unique_ptr<uint16_t[]> states; size_t cap = 0; };
     static thread_local Staging stg;
     if (stg.cap < tot + 1) {
         stg.cap = tot + 1 + tot / 8;
-        stg.cm.reset(); stg.sd.reset(); stg.ls.reset(); stg.states.reset();
-        stg.cm.reset(new float[stg.cap]); stg.sd.reset(new float[stg.cap]); stg.ls.reset(new float[stg.cap]);
+        stg.states.reset();
         stg.states.reset(new uint16_t[stg.cap]);
     }
-    float* const cm = stg.cm.get(); float* const sd = stg.sd.get(); float* const ls = stg.ls.get();
-    parallel_for(cands.size(), [&](size_t lo, size_t hi) {
-        for (size_t v = lo; v < hi; ++v) {
-            const size_t k = cands[v].job;
-            const int r = job_read[k];
-            const uint64_t b = strand_off[2 * r + cands[v].strand], e = strand_off[2 * r + cands[v].strand + 1];
-            const float drift = job_pm[6 * k + 2];
-            uint64_t d = off[v];
-            for (uint64_t i = b; i < e; ++i, ++d) {
-                float c = mean[i];
-                c -= drift * start[i];   // corrected_events.apply_drift_correction(pm_params.drift), nanocall.cpp:685-686
-                cm[d] = c; sd[d] = stdv[i]; ls[d] = std::log(stdv[i]);
-            }
-        }
-    });
     for (size_t i = 0; i < 2 * n_reads; ++i) { out_best_job[i] = -1; out_best_logp[i] = std::numeric_limits<float>::quiet_NaN(); }
     if (cands.empty()) return NCHMM_OK;
     int rc;
@@ -371,7 +364,8 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
     std::vector<float> logp(cands.size());
     std::vector<int32_t> status(cands.size());
     const auto t_1 = std::chrono::steady_clock::now();
-    rc = nchmm_viterbi(ctx, cands.size(), off.data(), cm, sd, ls, slot_m.data(), slot_t.data(), states, logp.data(), status.data());
+    rc = nchmm_viterbi_raw(ctx, (size_t)strand_off[2 * n_reads], mean, stdv, start, cands.size(), c_src.data(), c_len.data(), c_drift.data(),
+                           slot_m.data(), slot_t.data(), states, logp.data(), status.data());
     if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) return rc;
     const auto t_2 = std::chrono::steady_clock::now();
     // choose per read: 2D jobs by the float sum of both strands (:725-739), 1D jobs per strand (:807-825);
@@ -415,7 +409,7 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
     });
     if (dbg_time) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "[nchmm_basecall_reads] %zu candidates, %zu events: gather+tables %.2f ms, viterbi %.2f ms, choose+copy %.2f ms\n",
+        std::fprintf(stderr, "[nchmm_basecall_reads] %zu candidates, %zu events: tables %.2f ms, upload+gather+viterbi %.2f ms, choose+copy %.2f ms\n",
                      cands.size(), tot, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, std::chrono::steady_clock::now()));
     }
     return rc;

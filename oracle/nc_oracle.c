@@ -956,3 +956,21 @@ void nco_f5_initial_scaling(int together, const float r0[2], const float r1[2], 
         out[0] = scale; out[1] = shift;
     }
 }
+
+
+size_t nco_logf_mismatches(const float* x, const float* y, size_t n, long long* first_bad)
+{
+    size_t bad = 0;
+    long long first = -1;
+    for (size_t i = 0; i < n; ++i) {
+        const float h = logf(x[i]);
+        uint32_t a, b;
+        memcpy(&a, &h, 4); memcpy(&b, &y[i], 4);
+        if (a == b) continue;
+        if (h != h && y[i] != y[i]) continue;   /* both NaN */
+        if (first < 0) first = (long long)i;
+        ++bad;
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}

@@ -154,6 +154,11 @@ float nco_train_one_round_soa(size_t n_seqs, const uint64_t* off, const unsigned
                               float new_pm[6], float new_st[4], int* done,
                               int train_scaling, int train_transitions);
 
+/* The host libm's logf over an array (what Event::update_logs' std::log(float) calls, Event.hpp:43): the reference value
+ * for the device port, compared bit for bit.  Returns the number of i with bits(logf(x[i])) != bits(y[i]) (NaNs compare
+ * equal to each other), and the first such index through *first_bad (or -1). */
+size_t nco_logf_mismatches(const float* x, const float* y, size_t n, long long* first_bad);
+
 /* ---- Fast5_Summary (src/nanocall/Fast5_Summary.hpp): strand segmentation, event filter, initial scaling ----
  * PARITY UNPINNED: fast5::EventDetection_Event_Entry comes from the un-vendored fast5 submodule ([recalled]:
  * {double mean; double stdv; long long start; long long length;}) and alg::mean_stdv_of from hpptools

@@ -71,6 +71,8 @@ def lib():
         L.nco_train_one_round_soa.restype = C.c_float
         L.nco_train_one_round_soa.argtypes = [C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int,
                                               vp, vp, vp, vp, vp, C.c_int, C.c_int]
+        L.nco_logf_mismatches.restype = C.c_size_t
+        L.nco_logf_mismatches.argtypes = [vp, vp, C.c_size_t, vp]
         L.nco_mean_stdv.argtypes = [vp, C.c_size_t, vp, vp]
         L.nco_f5_summarize.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_int, vp]
         L.nco_f5_load_events.restype = C.c_size_t
@@ -326,3 +328,12 @@ def f5_initial_scaling(together, r0, r1, m0, m1):
     out = np.empty(2, np.float32)
     lib().nco_f5_initial_scaling(int(together), *[_p(x) for x in a], _p(out))
     return out
+
+
+def logf_mismatches(x, y):
+    """Number of elements where the host libm's logf(x) differs bitwise from y (both float32), and the first index."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    first = C.c_longlong(-1)
+    n = lib().nco_logf_mismatches(_p(x), _p(y), x.shape[0], C.byref(first))
+    return int(n), int(first.value)

@@ -80,3 +80,24 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     import nanocall_amd as na
     assert int(ver) == 2 and int(rc) == 0 and int(n) == len(na.st_train_kmers())
     assert "no CPU fallback" in r.stdout
+
+
+def test_reference_call_sites_compile_against_the_mirror_headers(tmp_path):
+    """The reference's own call sites of the HMM core (2D round loop nanocall.cpp:360-426, basecall_strand :645-690),
+    kept as the reference writes them in tests/boundary/reference_call_sites.cpp, compile (C++11, the reference's
+    standard, src/CMakeLists.txt:144) and link against include/nanocall_amd/nanocall_amd.hpp + the library; so does
+    the Fast5_Summary mirror.  (Their behaviour is checked on the GPU in tests/test_cpp_layer_gpu.py.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    libdir = os.path.join(ROOT, "nanocall_amd")
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-O0", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "boundary", "reference_call_sites.cpp"), "-L", libdir, "-lnanocall_hip",
+                        "-Wl,-rpath," + libdir, "-pthread", "-o", str(tmp_path / "rcs")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++",
+                        os.path.join(ROOT, "include", "nanocall_amd", "fast5_summary.hpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(tmp_path / "rcs")], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

@@ -100,3 +100,61 @@ def test_run_fwbw_prints_the_middle_event_posteriors(tmp_path, r73t):
     assert mat.shape == (61 * 4096, 4)
     assert np.allclose(mat[:, 2].reshape(61, 4096), al, rtol=1e-4, atol=1e-3)
     assert np.allclose(mat[:, 3].reshape(61, 4096), be, rtol=1e-4, atol=1e-3)
+
+
+def test_reference_call_sites_train_loop_and_basecall_strand(tmp_path):
+    """tests/boundary/reference_call_sites.cpp: the 2D round loop (nanocall.cpp:360-426) and basecall_strand (:645-690)
+    as the reference writes them, compiled against nanocall_amd.hpp.  This drives the C++
+    Parameter_Trainer::train_one_round / Pore_Model::scale / Viterbi::fill mirrors: control flow and fits against the
+    oracle's train_one_round loop (EM tolerances), the decode teacher-forced (the oracle with the program's own final
+    parameters) bit for bit."""
+    import oracle_pipeline as op
+    exe = tmp_path / "reference_call_sites"
+    libdir = os.path.join(ROOT, "nanocall_amd")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "boundary", "reference_call_sites.cpp"), "-L", libdir, "-lnanocall_hip",
+                        "-Wl,-rpath," + libdir, "-pthread", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    names = ["r73.t.006.ont.model", "r73.c.p2.006.ont.model"]
+    tabs = [na.builtin_model(n) for n in names]
+    from nanocall_amd import synth
+    evs = [synth.generate(tabs[0], 1, 420, first_read=900), synth.generate(tabs[1], 1, 380, first_read=901)]
+    paths = []
+    for st, e in enumerate(evs):
+        p = tmp_path / f"ev{st}.tsv"
+        with open(p, "w") as f:
+            for m, s, t, ln in zip(e["mean"][0], e["stdv"][0], e["start"][0], e["length"][0]):
+                f.write(f"{m:.9g}\t{s:.9g}\t{t:.9g}\t{ln:.9g}\n")
+        paths.append(str(p))
+    for train_drift in (1, 0):
+        r = subprocess.run([str(exe)] + paths + names + ["120", "2", str(train_drift)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.splitlines()
+        rounds = [l.split() for l in lines if l.startswith("round ")]
+        result = [l.split() for l in lines if l.startswith("result ")][0]
+        hx = lambda xs: np.float32([float.fromhex(x) for x in xs])
+        # the oracle's loop on the same windows
+        o = op.Opts(pore="r73", scaling_num_events=120, scaling_max_rounds=2, train_drift=train_drift)
+        rd = op.Read()
+        rd.events = [(e["mean"][0], na.events_prepare(e["mean"][0], e["stdv"][0], None, 0.0)[1], e["start"][0], e["length"][0]) for e in evs]
+        win, wst = op._windows(o, rd, [0, 1])
+        key = (names[0], names[1])
+        pm, st, fit, rnd = op.train_job(o, dict(zip(names, tabs)), win, wst, key, [1, 0, 0, 1, 1, 1], [0.1, 0.3, 0.1, 0.3])
+        assert int(result[12]) == rnd and len(rounds) in (rnd, rnd + 1)
+        got_pm, got_st, got_fit = hx(result[1:7]), hx(result[7:11]), np.float32(float.fromhex(result[11]))
+        assert abs(got_fit - fit) <= 1e-4 * abs(fit)
+        assert abs(got_pm[0] - pm[0]) <= 2e-4 * abs(pm[0]) and abs(got_pm[4] - pm[4]) <= 2e-4 * abs(pm[4])
+        assert abs(got_pm[1] - pm[1]) <= 2e-4 * 60 and abs(got_pm[2] - pm[2]) <= 2e-4 * 60 / 5.0
+        assert abs(got_pm[3] - pm[3]) <= 1.5e-3 * abs(pm[3]) and abs(got_pm[5] - pm[5]) <= 1.5e-3 * abs(pm[5])
+        assert np.allclose(got_st, st, rtol=5e-4, atol=0)
+        if not train_drift:
+            assert got_pm[2] == 0.0
+        # basecall_strand, teacher-forced
+        for s in (0, 1):
+            f = [l.split() for l in lines if l.startswith(f"strand {s} ")][0]
+            om = oracle.Model(tabs[s], got_pm)
+            ot = oracle.Transitions(float(got_st[2 * s + 1]), float(got_st[2 * s]))
+            cm, sd, ls = oracle.events_prepare(rd.events[s][0], rd.events[s][1], rd.events[s][2], float(got_pm[2]))
+            states, mv, lp = oracle.viterbi(om, ot, cm, sd, ls)
+            assert np.float32(float.fromhex(f[2])).tobytes() == np.float32(lp).tobytes()
+            assert f[3] == oracle.base_seq(states, mv)

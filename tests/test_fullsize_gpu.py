@@ -59,3 +59,48 @@ def test_config5_r9_50k_event_read_against_oracle(gpu_ctx, r9t):
     assert_bits_equal(logp, ologp, "path probability")
     mv, seq = na.base_seq(states[:50000])
     assert 45000 < len(seq) < 60000
+
+
+def test_config4_shard_12500_reads_sub_batched(r73t):
+    """The per-GPU shard of BASELINE config 4 (100 000 reads x 5 000 events over 8 GPUs = 12 500 reads, 62.5 M events):
+    its 256 GB of back-pointers exceed the workspace budget, so one call is several forward + traceback launches over
+    contiguous read ranges.  Properties: every read decodes, every decoded transition is an arc of the HMM, the
+    reported log-probabilities equal the score recomputed along the decoded path (bit for bit, sampled across the
+    sub-batches), and reads decode to the same bits alone as inside the shard (batch independence)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from nanocall_amd import shard
+    n_reads, n_events = 12500, 5000
+    mine = shard.lpt_partition(np.full(100000, n_events), 8)[3]            # rank 3's reads: 37 500 .. 49 999
+    assert len(mine) == n_reads and mine[0] == 37500
+    off, mean, stdv, start = bench.generate_shard(r73t, mine, n_events, threads=min(16, os.cpu_count() or 1))
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    del mean, stdv, start
+    ctx = na.Context(0)
+    try:
+        ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        launches0 = int(ctx.counters()[3])
+        states, logp, status = ctx.viterbi(off, cm, sd, ls)
+        n_sub = (int(ctx.counters()[3]) - launches0) // 2
+        assert n_sub >= 2, "the shard was expected not to fit one workspace"
+        assert (status == 0).all() and np.isfinite(logp).all()
+        S = states.reshape(n_reads, n_events)
+        for lo in range(0, n_reads, 2500):                                   # arcs, 2500 reads at a time
+            blk = S[lo:lo + 2500].astype(np.int32)
+            prev, cur = blk[:, :-1], blk[:, 1:]
+            assert ((prev == cur) | ((prev & 1023) == (cur >> 2)) | ((prev & 255) == (cur >> 4))).all()
+        for r in (0, 6249, 6250, 12499):                                     # rescoring across the sub-batch boundary region
+            a, b = r * n_events, (r + 1) * n_events
+            score, ok = rescore_path(r73t, IDENT, 0.3, 0.1, cm[a:b], sd[a:b], ls[a:b], states[a:b])
+            assert ok and np.float32(score).tobytes() == logp[r].tobytes(), (r, score, logp[r])
+        for lo in (0, n_reads - 300):                                        # batch independence
+            a, b = lo * n_events, (lo + 300) * n_events
+            s2, lp2, _ = ctx.viterbi(off[: 301], cm[a:b], sd[a:b], ls[a:b])
+            assert np.array_equal(s2, states[a:b]) and np.array_equal(lp2.view(np.uint32), logp[lo:lo + 300].view(np.uint32))
+        # the first read of the shard against the oracle itself
+        os_, ol = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, np.array([0, n_events], np.uint64), cm[:n_events], sd[:n_events], ls[:n_events])
+        assert np.array_equal(states[:n_events], os_) and ol[0].tobytes() == logp[0].tobytes()
+    finally:
+        ctx.close()
