@@ -37,6 +37,7 @@ struct nchmm_ctx {
     uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace (4 KiB per event of a batch)
     size_t ws_bytes = 0;
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
+    size_t fb_budget = 0;           // same for the forward-backward alpha rows (16 KiB per event)
     unsigned* d_last_state = nullptr; // per read: arg-max state of the last column
     size_t last_state_bytes = 0;
     float* d_fb_ws = nullptr;       // FB alpha workspace
@@ -627,7 +628,7 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
         size_t free_b = 0, total_b = 0;
         HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
         const char* e = std::getenv("NCHMM_WS_BUDGET_MB");
-        c->ws_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : (free_b / 10) * 7;
+        c->ws_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : (free_b / 10) * 6;
         if (c->ws_budget < ((size_t)64 << 20)) c->ws_budget = (size_t)64 << 20;
     }
     const size_t need_all = std::max<size_t>(total_events, 1) * (size_t)kStates;
@@ -865,9 +866,74 @@ int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_e
     return NCHMM_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Largest number of events a forward-backward launch may cover: its alpha rows are 16 KiB per event (plus, for the
+// host-pointer form with matrices, two staged n x S outputs).  NCHMM_FB_BUDGET_MB overrides a quarter of the device memory.
+size_t fb_budget_events(nchmm_ctx* c, size_t bytes_per_event)
+{
+    if (c->fb_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+        const char* e = std::getenv("NCHMM_FB_BUDGET_MB");
+        c->fb_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : total_b / 4;
+        if (c->fb_budget < ((size_t)16 << 20)) c->fb_budget = (size_t)16 << 20;
+    }
+    return std::max<size_t>(c->fb_budget / bytes_per_event, 1);
+}
+
+int fwbw_host_range(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cmean, const float* stdv, const float* lstdv,
+                    const int32_t* scaled_slot, const float* pm_params, const int32_t* trans_slot, const float* st_params,
+                    float* out_lpd, float* out_pm, float* out_st, float* out_alpha, float* out_beta);
+
+}  // namespace
+
+extern "C" {
+
+// Windows are independent: a batch whose alpha rows exceed the budget is cut into consecutive window ranges that run one
+// after the other through the same workspace (a single window larger than the budget still runs, alone).
 int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cmean, const float* stdv, const float* lstdv,
                const int32_t* scaled_slot, const float* pm_params, const int32_t* trans_slot, const float* st_params,
                float* out_lpd, float* out_pm, float* out_st, float* out_alpha, float* out_beta)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_win == 0) return NCHMM_OK;
+    size_t max_events = 0, total = 0;
+    int rc = check_offsets(n_win, off, &max_events, &total);
+    if (rc != NCHMM_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t per_event = (size_t)kStates * sizeof(float) * (1 + (out_alpha ? 1 : 0) + (out_beta ? 1 : 0));
+    const size_t cap = fb_budget_events(c, per_event);
+    if (total <= cap)
+        return fwbw_host_range(c, n_win, off, cmean, stdv, lstdv, scaled_slot, pm_params, trans_slot, st_params, out_lpd, out_pm, out_st,
+                               out_alpha, out_beta);
+    std::vector<uint64_t> sub;
+    for (size_t w0 = 0; w0 < n_win;) {
+        size_t w1 = w0 + 1;
+        while (w1 < n_win && off[w1 + 1] - off[w0] <= cap) ++w1;
+        sub.assign(w1 - w0 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) sub[w - w0] = off[w] - off[w0];
+        const size_t e0 = (size_t)off[w0];
+        rc = fwbw_host_range(c, w1 - w0, sub.data(), cmean ? cmean + e0 : nullptr, stdv ? stdv + e0 : nullptr, lstdv ? lstdv + e0 : nullptr,
+                             scaled_slot ? scaled_slot + w0 : nullptr, pm_params ? pm_params + 6 * w0 : nullptr,
+                             trans_slot ? trans_slot + w0 : nullptr, st_params ? st_params + 2 * w0 : nullptr, out_lpd + w0,
+                             out_pm ? out_pm + 6 * e0 : nullptr, out_st ? out_st + 3 * w0 : nullptr,
+                             out_alpha ? out_alpha + e0 * (size_t)kStates : nullptr, out_beta ? out_beta + e0 * (size_t)kStates : nullptr);
+        if (rc != NCHMM_OK) return rc;
+        w0 = w1;
+    }
+    return NCHMM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int fwbw_host_range(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cmean, const float* stdv, const float* lstdv,
+                    const int32_t* scaled_slot, const float* pm_params, const int32_t* trans_slot, const float* st_params,
+                    float* out_lpd, float* out_pm, float* out_st, float* out_alpha, float* out_beta)
 {
     if (!c) return NCHMM_E_INVALID;
     if (n_win == 0) return NCHMM_OK;
@@ -918,6 +984,14 @@ int nchmm_fwbw(nchmm_ctx* c, size_t n_win, const uint64_t* off, const float* cme
     return NCHMM_OK;
 }
 
+int em_round_range(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift,
+                   const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
+                   size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_lpd, float* out_st, double* out_acc);
+
+}  // namespace
+
+extern "C" {
+
 int nchmm_em_load_events(nchmm_ctx* c, size_t n_events, const float* mean, const float* stdv, const float* start,
                          const float* log_stdv)
 {
@@ -935,6 +1009,8 @@ int nchmm_em_load_events(nchmm_ctx* c, size_t n_events, const float* mean, const
     return NCHMM_OK;
 }
 
+// A round whose alpha rows exceed the forward-backward budget is cut at job boundaries (a job's windows stay together:
+// its outer sums are reduced on the device) and the ranges run one after the other.
 int nchmm_em_round(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift,
                    const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
                    size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_lpd, float* out_st, double* out_acc)
@@ -944,6 +1020,40 @@ int nchmm_em_round(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const ui
     if (!win_src || !win_len || !win_drift || !out_lpd || (n_jobs && (!job_first_win || !out_acc)) || n_win > 0xFFFFFFF0ull)
         return NCHMM_E_INVALID;
     if (n_jobs && (job_first_win[0] != 0 || job_first_win[n_jobs] != n_win)) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t total = 0;
+    for (size_t w = 0; w < n_win; ++w) total += win_len[w];
+    const size_t cap = fb_budget_events(c, (size_t)kStates * sizeof(float));
+    if (total <= cap || n_jobs <= 1)
+        return em_round_range(c, n_win, win_src, win_len, win_drift, win_pm, scaled_slot, trans_slot, st_params, n_jobs, job_first_win,
+                              train_drift, out_lpd, out_st, out_acc);
+    std::vector<uint64_t> ev_before(n_win + 1, 0);
+    for (size_t w = 0; w < n_win; ++w) ev_before[w + 1] = ev_before[w] + win_len[w];
+    std::vector<uint32_t> jf;
+    for (size_t j0 = 0; j0 < n_jobs;) {
+        size_t j1 = j0 + 1;
+        while (j1 < n_jobs && ev_before[job_first_win[j1 + 1]] - ev_before[job_first_win[j0]] <= cap) ++j1;
+        const size_t w0 = job_first_win[j0], w1 = job_first_win[j1];
+        jf.assign(j1 - j0 + 1, 0);
+        for (size_t j = j0; j <= j1; ++j) jf[j - j0] = job_first_win[j] - (uint32_t)w0;
+        const int rc = em_round_range(c, w1 - w0, win_src + w0, win_len + w0, win_drift + w0, win_pm ? win_pm + 6 * w0 : nullptr,
+                                      scaled_slot ? scaled_slot + w0 : nullptr, trans_slot ? trans_slot + w0 : nullptr,
+                                      st_params ? st_params + 2 * w0 : nullptr, j1 - j0, jf.data(), train_drift, out_lpd + w0,
+                                      out_st ? out_st + 3 * w0 : nullptr, out_acc + 13 * j0);
+        if (rc != NCHMM_OK) return rc;
+        j0 = j1;
+    }
+    return NCHMM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int em_round_range(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift,
+                   const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
+                   size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_lpd, float* out_st, double* out_acc)
+{
     std::vector<uint64_t> off(n_win + 1, 0);
     size_t max_events = 0;
     for (size_t w = 0; w < n_win; ++w) {
@@ -1000,6 +1110,10 @@ int nchmm_em_round(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const ui
     HIP_TRY(c, hipStreamSynchronize(s));
     return NCHMM_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int nchmm_counters(const nchmm_ctx* c, uint64_t out[8])
 {

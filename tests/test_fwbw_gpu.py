@@ -407,3 +407,64 @@ def test_em_round_edge_shapes(gpu_ctx, r73t):
     # no jobs: only log-likelihoods / transition sums come back
     only = gpu_ctx.em_round(src[:3], ln[:3], np.full(3, pm[2]), pm, np.full(3, 50), np.full(3, 50), stp[:3], [0])
     assert only["acc"].shape == (0, 13) and np.array_equal(only["log_pr_data"], ref["log_pr_data"][:3])
+
+
+def test_forward_backward_budget_cuts_batches_into_ranges(r73t):
+    """nchmm_fwbw / nchmm_em_round with an alpha-row budget far below the batch (NCHMM_FB_BUDGET_MB=16: 1024 events per
+    launch): the batch runs as consecutive window (job) ranges through one workspace and returns exactly what the
+    unsplit call returns -- windows are independent."""
+    import os
+    t0, t1 = na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")
+    n_reads, n_ev = 6, 500
+    e0 = synth.generate(t0, n_reads, n_ev, first_read=177)
+    e1 = synth.generate(t1, n_reads, n_ev, first_read=10**6 + 177)
+    mean = np.stack([e0["mean"], e1["mean"]], 1).reshape(-1)
+    stdv = np.stack([e0["stdv"], e1["stdv"]], 1).reshape(-1)
+    start = np.stack([e0["start"], e1["start"]], 1).reshape(-1)
+    _, stdv, lsd = na.events_prepare(mean, stdv, None, 0.0)
+    pm = np.float32([1.01, 0.3, 0.002, 1.02, 0.98, 1.1])
+    win_src, win_len, s_slot, jf = [], [], [], [0]
+    for r in range(n_reads):
+        for s in range(2):
+            base = (2 * r + s) * n_ev
+            for b, ln in ((base, 100), (base + n_ev - 130, 130 if r % 2 else 100)):
+                win_src.append(b); win_len.append(ln); s_slot.append(s)
+        jf.append(len(win_src))
+    n_win = len(win_src)
+    stp = np.tile(np.float32([0.1, 0.3]), (n_win, 1))
+
+    def run(budget):
+        if budget:
+            os.environ["NCHMM_FB_BUDGET_MB"] = budget
+        try:
+            ctx = na.Context(0)
+        finally:
+            os.environ.pop("NCHMM_FB_BUDGET_MB", None)
+        try:
+            for s, tab in enumerate((t0, t1)):
+                ctx.put_model(s, na.scaled_model_table(tab, pm))
+            ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+            ctx.em_load_events(mean, stdv, start, lsd)
+            l0 = int(ctx.counters()[3])
+            em = ctx.em_round(win_src, win_len, np.full(n_win, pm[2]), np.tile(pm, (n_win, 1)), s_slot, np.zeros(n_win, np.int32), stp, jf)
+            n_launch_em = int(ctx.counters()[3]) - l0
+            off = np.concatenate([[0], np.cumsum(win_len)]).astype(np.uint64)
+            idx = np.concatenate([np.arange(b, b + ln) for b, ln in zip(win_src, win_len)])
+            cm = np.concatenate([na.events_prepare(mean[b:b + ln], stdv[b:b + ln], start[b:b + ln], float(pm[2]))[0] for b, ln in zip(win_src, win_len)])
+            l0 = int(ctx.counters()[3])
+            fb = ctx.fwbw(off, cm, stdv[idx], lsd[idx], scaled_slot=s_slot, pm_params=np.tile(pm, (n_win, 1)), st_params=stp)
+            n_launch_fb = int(ctx.counters()[3]) - l0
+            fbm = ctx.fwbw(off[:5], cm[: int(off[4])], stdv[idx][: int(off[4])], lsd[idx][: int(off[4])], scaled_slot=s_slot[:4], want_matrices=True)
+            return em, fb, fbm, n_launch_em, n_launch_fb
+        finally:
+            ctx.close()
+
+    em1, fb1, fbm1, a1, b1 = run(None)
+    em2, fb2, fbm2, a2, b2 = run("16")
+    assert a1 == 1 and b1 == 1 and a2 >= 3 and b2 >= 3            # 2660 events against 1024 per launch
+    for k in ("log_pr_data", "st_sums", "acc"):
+        assert np.array_equal(em1[k], em2[k]), k
+    for k in ("log_pr_data", "st_sums", "pm_sums"):
+        assert np.array_equal(fb1[k], fb2[k]), k
+    for k in ("log_pr_data", "alpha", "beta"):                     # log-space pair with matrices: 3 x 16 KiB per event
+        assert np.array_equal(fbm1[k], fbm2[k]), k
