@@ -108,9 +108,57 @@ def truth_round0(d):
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "em_2d_drift1_truth64.json")
+GOLDEN_ALL = os.path.join(ROOT, "tests", "golden", "em_2d_truth64_all_rounds.json")
+
+
+def truth_all_rounds():
+    """Every round of both EM fixtures (drift trained / not trained), teacher-forced from the fixture's previous-round
+    parameters exactly as tests/test_fwbw_gpu.py::test_em_rounds_against_golden runs them: forward-backward in float64 on
+    the SCALED model with the round's transitions and drift-corrected events, inner sums in float64 over the UNSCALED
+    model (Parameter_Trainer.hpp:273-296), finished by nchmm_train_pm_finish.  -> {drift: [ {fit, params[6]} per round ]}"""
+    out = {}
+    tabs = [na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")]
+    unscaled = [na.model_load(t).astype(np.float64) for t in tabs]      # S x 10: level_mean, level_stdv, sd_mean, sd_stdv, sd_lambda, ...
+    for drift in (1, 0):
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"em_2d_drift{drift}.npz"))
+        mean, stdv, start, strand, off = z["mean"], z["stdv"], z["start"], z["strand"].astype(np.int64), z["off"]
+        pm = np.array([1, 0, 0, 1, 1, 1], np.float32)
+        stp = np.array([[0.1, 0.3], [0.1, 0.3]], np.float32)
+        rounds = []
+        for rnd, exp in enumerate(z["rounds"]):
+            t6 = [na.scaled_model_table(t, pm) for t in tabs]
+            tr = [na.transitions_fast(float(stp[st, 1]), float(stp[st, 0])) for st in range(2)]
+            cm, sd, ls = na.events_prepare(mean, stdv, start, float(pm[2]))
+            sums = np.zeros((cm.shape[0], 6))
+            fit64 = 0.0
+            for w in range(len(strand)):
+                a, b = int(off[w]), int(off[w + 1])
+                st = strand[w]
+                lpd, al, be = fwbw64(t6[st], *tr[st], cm[a:b], sd[a:b])
+                fit64 += lpd
+                p = np.exp(al + be - lpd)
+                u = unscaled[st]
+                u0 = 1.0 / (u[:, 1] ** 2)
+                sums[a:b, 0] = p @ u0
+                sums[a:b, 1] = p @ (u0 * u[:, 0])
+                sums[a:b, 2] = p @ (u0 * u[:, 0] ** 2)
+                sums[a:b, 3] = p @ u[:, 4]
+                sums[a:b, 4] = p @ (u[:, 4] / u[:, 2])
+                sums[a:b, 5] = p @ (u[:, 4] / u[:, 2] ** 2)
+            truth, done = na.train_pm_finish(sums.astype(np.float32), mean, sd, start, pm, train_drift=bool(drift))
+            rounds.append({"fit": fit64, "params": [float(v) for v in truth], "done": bool(done),
+                           "oracle_params": [float(v) for v in exp[1:7]], "oracle_fit": float(exp[0])})
+            pm, stp = exp[1:7].astype(np.float32), exp[7:11].astype(np.float32).reshape(2, 2)
+        out[str(drift)] = rounds
+    return out
 
 
 def main():
+    if "--golden-all" in sys.argv:
+        with open(GOLDEN_ALL, "w") as f:
+            json.dump({"made_by": "tools/fb_truth.py --golden-all", "rounds": truth_all_rounds()}, f, indent=1)
+        print("wrote", GOLDEN_ALL)
+        return
     d = setup()
     z, pm, strand, off, mean, start = d["z"], d["pm"], d["strand"], d["off"], d["mean"], d["start"]
     cm, sd, ls, t6 = d["cm"], d["sd"], d["ls"], d["t6"]
