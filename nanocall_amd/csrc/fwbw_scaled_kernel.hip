@@ -278,6 +278,9 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
         // c2b[j] = w2[j & 255] for every state: the producer of successor group q = tau >> 1 applies it
         const float W2 = ex2(P.trans[(size_t)ts * kTransFloats + kStates + 1024 + t] * kLog2e);
         const unsigned train = P.train_mask[tau];   // bit u: state j0+u is a transition-training k-mer
+        unsigned tmask[8];                          // all-ones / zero per state (bfe_i32: sign-extended bit u)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tmask[u] = (unsigned)__builtin_amdgcn_sbfe((int)train, u, 1);
         float p_stay = 0.0f, p_step4 = 0.0f;
         if (P.st_params) {
             p_stay = P.st_params[2 * w];                                         // Parameter_Trainer.hpp:444
@@ -421,12 +424,15 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
                     const float bt = __builtin_fmaf(w12[v], h1[v], __builtin_fmaf(t02[v], g[u], h2[v]));
                     const float p = al[u] * bt;                              // posterior of (i-1, u) up to kappa
                     pm_add(u, p);
-                    // Parameter_Trainer.hpp:470-512 for the pair (i-1, i), same units
-                    const float pm = ((train >> u) & 1u) ? p : 0.0f;
-                    const float pst = __builtin_fminf(al[u] * g[u] * p_stay, pm);
-                    const float pstep = al[u] * h1[v] * p_step4;
-                    const float p01 = __builtin_fminf(pst + pstep, pm);
-                    part_p += pm; part_stay += pst; part_skip += pm - p01;
+                    // Parameter_Trainer.hpp:470-512 for the pair (i-1, i), same units.  Every term carries the factor
+                    // alpha_{i-1}[u] >= 0, and min(a x, a y) = a min(x, y): the clamps (:480-488, :502-510) are taken on
+                    // the beta side and alpha multiplies the three contributions once (as the FMAs of the partial sums).
+                    const float mbt = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, bt) & tmask[u]);   // bt on training k-mers, else +0
+                    const float st_b = __builtin_fminf(g[u] * p_stay, mbt);
+                    const float p01_b = __builtin_fminf(__builtin_fmaf(h1[v], p_step4, st_b), mbt);
+                    part_p = __builtin_fmaf(al[u], mbt, part_p);
+                    part_stay = __builtin_fmaf(al[u], st_b, part_stay);
+                    part_skip = __builtin_fmaf(al[u], mbt - p01_b, part_skip);
                     bh[u] = bt * sc;
                 }
             }

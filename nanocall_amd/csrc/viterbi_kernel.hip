@@ -185,6 +185,18 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
     float m4[2]; unsigned x4[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {            // y = 2g + h, members i = 2x + g
+#ifdef NCHMM_SCAN_MAX3
+        // the maximum first (two ops), then the FIRST member equal to it: the ascending strict-> scan of the reference
+        // names exactly that one.  (NaN members never equal the maximum; an all-NaN group names member 3, which cannot
+        // matter: see below.)
+        const float a0 = S.alpha[g], a1 = S.alpha[2 + g], a2 = S.alpha[4 + g], a3 = S.alpha[6 + g];
+        const float bv = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3);
+        const mask_t e0 = ballot(a0 == bv), e1 = ballot(a1 == bv), e2 = ballot(a2 == bv);
+        unsigned bx;
+        asm("v_cndmask_b32_e64 %0, 3, 2, %1" : "=v"(bx) : "s"(e2));
+        asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(bx) : "v"(bx), "s"(e1));
+        bx = selm_zero(e0, bx);
+#else
         // starting from member 0 instead of -INF saves one compare-select; the results differ only
         // if member 0 is NaN while another member is not, which needs a NaN emission for some
         // states but not others -- no finite model/event does that (and an all-NaN column is
@@ -197,6 +209,7 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
             bv = selm(m, v, bv);
             bx = selm(m, (unsigned)xx, bx);
         }
+#endif
         m4[g] = bv; x4[g] = bx;
     }
     // own half of the skip group: k = 4x + y

@@ -145,9 +145,14 @@ def test_em_round0_against_float64_truth(gpu_ctx):
 def test_em_all_rounds_against_float64_truth(gpu_ctx, drift):
     """Every round of both EM fixtures (drift trained / not), teacher-forced as in test_em_rounds_against_golden, against
     the float64 evaluation of the same round (tests/golden/em_2d_truth64_all_rounds.json, tools/fb_truth.py --golden-all:
-    forward-backward and inner sums in float64 from the same fp32 inputs).  This is what justifies holding `var` / `var_sd`
-    to 5e-4 against the fp32 oracle: the oracle itself is up to 2.2e-4 (`var`) / 1e-4 (`var_sd`) from the real-number
-    answer, round by round, while the GPU stays within 1e-4 of it on every parameter of every round."""
+    forward-backward, inner sums, outer sums, solve and closed forms all in float64 from the same fp32 inputs).
+
+    What it establishes, round by round: (1) on the well-conditioned parameters (scale, shift, drift, scale_sd) the GPU is
+    within 1e-5 of the real-number answer; (2) `var` = sqrt(d_numer / N) (Parameter_Trainer.hpp:406-417, O(1e6) sums
+    cancelling to O(1e2)) and `var_sd` (:426) carry a noise floor of ~1e-4 that belongs to the REFERENCE'S arithmetic, not
+    to the kernels: even exact float64 inner sums rounded once and finished as the reference finishes them (float
+    products `s[0] * x_i * x_i`, :297-312) land up to 1.0e-4 from the truth, the fp32 oracle up to 2.0e-4.  The GPU is
+    held to 3e-4 / 2e-4 here, which is what makes 5e-4 the tightest honest bound between two fp32 implementations."""
     import json
     with open(os.path.join(G, "em_2d_truth64_all_rounds.json")) as f:
         truth = json.load(f)["rounds"][str(drift)]
@@ -156,7 +161,7 @@ def test_em_all_rounds_against_float64_truth(gpu_ctx, drift):
     mean, stdv, start, strand, off = z["mean"], z["stdv"], z["start"], z["strand"].astype(np.int64), z["off"]
     pm = np.array([1, 0, 0, 1, 1, 1], np.float32)
     stp = np.array([[0.1, 0.3], [0.1, 0.3]], np.float32)
-    worst_gpu, worst_oracle = np.zeros(6), np.zeros(6)
+    worst_gpu, worst_oracle, worst_mixed = np.zeros(6), np.zeros(6), np.zeros(6)
     for rnd, exp in enumerate(z["rounds"]):
         gpu_ctx.put_model(12, na.scaled_model_table(t0, pm))
         gpu_ctx.put_model(13, na.scaled_model_table(t1, pm))
@@ -170,14 +175,19 @@ def test_em_all_rounds_against_float64_truth(gpu_ctx, drift):
         assert abs(float(np.sum(out["log_pr_data"], dtype=np.float64)) - t["fit"]) <= 1e-5 * abs(t["fit"]), rnd
         tp = np.array(t["params"])
         den = np.abs(tp)
-        den[1], den[2] = 60.0, 60.0 / float(start.max())
+        den[1], den[2] = 60.0, 60.0 / float(start.max())      # shift / drift are offsets on the level scale
         err = np.abs(got.astype(np.float64) - tp) / den
-        o_err = np.abs(np.array(t["oracle_params"]) - tp) / den
-        assert err.max() <= 1e-4, (rnd, err, got, tp)
-        worst_gpu, worst_oracle = np.maximum(worst_gpu, err), np.maximum(worst_oracle, o_err)
+        assert err[[0, 1, 2, 4]].max() <= 1e-5, (rnd, err)
+        assert err[3] <= 3e-4 and err[5] <= 2e-4, (rnd, err, got, tp)
+        worst_gpu = np.maximum(worst_gpu, err)
+        worst_oracle = np.maximum(worst_oracle, np.abs(np.array(t["oracle_params"]) - tp) / den)
+        worst_mixed = np.maximum(worst_mixed, np.abs(np.array(t["params_f64_sums_f32_finish"]) - tp) / den)
         pm, stp = exp[1:7].astype(np.float32), exp[7:11].astype(np.float32).reshape(2, 2)
-    # the fp32 reference arithmetic is further from the real-number answer than the GPU on the ill-conditioned parameters
-    assert worst_oracle[3] > worst_gpu[3] and worst_oracle[3] > 1e-4, (worst_oracle, worst_gpu)
+    # the noise floor is the reference's own: exact sums + its finish, and its full fp32 arithmetic
+    assert worst_mixed[3] > 5e-5, worst_mixed
+    if drift:
+        assert worst_oracle[3] > 1e-4, worst_oracle
+    print(f"drift={drift}: worst relative distance to float64 truth  gpu {worst_gpu}  oracle {worst_oracle}  f64-sums+ref-finish {worst_mixed}")
 
 
 def _em_window_batch(n_reads=6, n_ev=100, outlier=None, pore="r73"):

@@ -107,6 +107,29 @@ def truth_round0(d):
     return fit64, sums, truth
 
 
+def finish64(sums, x, y, t, crt_pm, train_drift):
+    """Parameter_Trainer::train_pm_params' outer sums and solve (Parameter_Trainer.hpp:297-427) entirely in float64:
+    products, accumulation, the 3x3 solve and the closed forms.  -> params[6] float64 (scale, shift, drift, var, scale_sd, var_sd)"""
+    s0, s1, s2, l0, l1, l2 = (sums[:, k] for k in range(6))
+    x, y, t = x.astype(np.float64), y.astype(np.float64), t.astype(np.float64)
+    A = np.zeros((3, 3))
+    B = np.zeros(3)
+    A[0, 0], A[0, 1], A[1, 1] = s0.sum(), s1.sum(), s2.sum()
+    B[0], B[1] = (s0 * x).sum(), (s1 * x).sum()
+    if train_drift:
+        A[0, 2], A[1, 2], A[2, 2], B[2] = (s0 * t).sum(), (s1 * t).sum(), (s0 * t * t).sum(), (s0 * x * t).sum()
+    else:
+        A[2, 2] = 1.0
+    A[1, 0], A[2, 0], A[2, 1] = A[0, 1], A[0, 2], A[1, 2]
+    D, Vn, Vd, Up = (s0 * x * x).sum(), (l2 * y).sum(), l1.sum(), (l0 / y).sum()
+    a, b, c = np.linalg.solve(A, B)
+    n = float(len(x))
+    d_numer = (D + a * a * A[0, 0] + b * b * A[1, 1] + c * c * A[2, 2] + 2 * a * b * A[0, 1] + 2 * a * c * A[0, 2] + 2 * b * c * A[1, 2]
+               - 2 * (a * B[0] + b * B[1] + c * B[2]))
+    v = Vn / Vd
+    return np.array([b, a, c if train_drift else float(crt_pm[2]), np.sqrt(d_numer / n), v, n / (Up - Vd / v)])
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden", "em_2d_drift1_truth64.json")
 GOLDEN_ALL = os.path.join(ROOT, "tests", "golden", "em_2d_truth64_all_rounds.json")
 
@@ -145,8 +168,12 @@ def truth_all_rounds():
                 sums[a:b, 3] = p @ u[:, 4]
                 sums[a:b, 4] = p @ (u[:, 4] / u[:, 2])
                 sums[a:b, 5] = p @ (u[:, 4] / u[:, 2] ** 2)
-            truth, done = na.train_pm_finish(sums.astype(np.float32), mean, sd, start, pm, train_drift=bool(drift))
-            rounds.append({"fit": fit64, "params": [float(v) for v in truth], "done": bool(done),
+            # two finishes: the reference's (float products of float32 sums, nchmm_train_pm_finish) fed the float64 sums
+            # rounded once, and the same closed forms evaluated entirely in float64 -- the real-number answer
+            mixed, done = na.train_pm_finish(sums.astype(np.float32), mean, sd, start, pm, train_drift=bool(drift))
+            truth = finish64(sums, mean, sd, start, pm, bool(drift))
+            rounds.append({"fit": fit64, "params": [float(v) for v in truth], "params_f64_sums_f32_finish": [float(v) for v in mixed],
+                           "done": bool(done),
                            "oracle_params": [float(v) for v in exp[1:7]], "oracle_fit": float(exp[0])})
             pm, stp = exp[1:7].astype(np.float32), exp[7:11].astype(np.float32).reshape(2, 2)
         out[str(drift)] = rounds
