@@ -362,8 +362,12 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             const unsigned buf = (unsigned)i & 1u;
             const float x = nx_x, y = nx_y, ry = __builtin_amdgcn_rcpf(y);
             rowp -= kStates;
+#ifdef NCHMM_EXP_NOLOAD      // experiment only (wrong results): how much of the sweep is waiting for the alpha rows?
+            nx_lo = make_float4(1e-3f, 2e-3f, 1e-3f, 3e-3f); nx_hi = nx_lo;
+#else
             nx_lo = *reinterpret_cast<const float4*>(rowp + jl);
             nx_hi = *reinterpret_cast<const float4*>(rowp + jl + 4);
+#endif
             nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_ia = iexp[i - 1];
             // g = emission(event i) * beta_i; H1/H2 sums over consecutive successor groups (Forward_Backward.hpp:107-125)
             float g[8];
@@ -390,7 +394,9 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(ps[4], ps[5], pend_kappa, 0.0f);
                 sZ[buf][tl >> 6] = z;
             }
+#ifndef NCHMM_EXP_NOBARRIER   // experiment only (wrong results): what does the per-event barrier cost?
             __syncthreads();
+#endif
             publish((unsigned)i, tl);    // the barrier made every wave's sums of event i visible
             const float4 z0 = *reinterpret_cast<const float4*>(&sZ[buf][0]);
             const float4 z1 = *reinterpret_cast<const float4*>(&sZ[buf][4]);

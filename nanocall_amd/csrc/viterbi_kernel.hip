@@ -260,7 +260,9 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
     sV1[(h << 8) | t] = ValSlot{s1[0], sl1[0]};
     sV1[((2u + h) << 8) | t] = ValSlot{s1[1], sl1[1]};
     if (h == 0) sV2[t] = ValSlot{s2, sl2};
+#ifndef NCHMM_EXP_NOBARRIER   // experiment only (wrong results): what does the per-event barrier cost?
     __syncthreads();
+#endif
 
     // ---------------- 3-way combine per state ----------------
     const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
@@ -316,7 +318,11 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
         }
     }
     const unsigned w_lo = bpw[0], w_hi = bpw[1];
+#ifdef NCHMM_EXP_NOSTORE      // experiment only (no traceback possible): what do the back-pointer stores cost?
+    if (w_lo == 0x12345678u) *reinterpret_cast<uint2*>(bp_row + tau * 8u) = make_uint2(w_lo, w_hi);
+#else
     *reinterpret_cast<uint2*>(bp_row + tau * 8u) = make_uint2(w_lo, w_hi);
+#endif
 }
 
 __device__ __forceinline__ bool event_in_fast_range(float x, float y)
