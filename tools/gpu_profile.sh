@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fwbw"
+BENCH="python3 $ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-fwbw"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o vit -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq1 -o vit -- $BENCH > $OUT/pmc_sq1.log 2>&1
