@@ -215,6 +215,8 @@ def launch_ranks(args):
     (torch.cuda.device_count() only counts), and the child is spawned, never exec'ed over this process."""
     import torch
     have = torch.cuda.device_count()
+    if os.environ.get("NCHMM_BENCH_SHARE_GPU0") == "1" and have >= 1:
+        have = args.gpus          # test hook: all ranks share GPU 0 (see main())
     if have < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
                          f"{args.gpus}-GPU number from fewer devices\n")
@@ -259,13 +261,24 @@ def main():
     import nanocall_amd as na
     from nanocall_amd import shard
 
-    if torch.cuda.device_count() <= local_rank:
-        sys.stderr.write(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)\n")
+    # TEST HOOK (tests/test_bench_gpu.py): NCHMM_BENCH_SHARE_GPU0=1 puts every rank on GPU 0 with gloo for the two small
+    # exchanges, so that the N > 1 code path (LPT shard per rank, per-rank generation, counter all-reduce, max over ranks,
+    # JSON assembly) runs on a 1-GPU box.  RCCL cannot form a communicator from two ranks on one device; the line says so.
+    share_gpu0 = os.environ.get("NCHMM_BENCH_SHARE_GPU0") == "1"
+    if share_gpu0:
+        local_rank_dev = 0
+    else:
+        local_rank_dev = local_rank
+    if torch.cuda.device_count() <= local_rank_dev:
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU {local_rank_dev} ({torch.cuda.device_count()} visible)\n")
         sys.exit(2)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank_dev)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if share_gpu0:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     table = na.builtin_model(args.model)
     n_events = args.events
@@ -282,7 +295,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
     total = n_reads * n_events
 
-    ctx = na.Context(local_rank)
+    ctx = na.Context(local_rank_dev)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # launches are ordered with torch's work on this stream
     ctx.put_model(0, na.scaled_model_table(table))
     ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
@@ -315,10 +328,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dev if world > 1 else None)
+    red_dev = dev if (world > 1 and not share_gpu0) else None      # gloo reduces host tensors
+    dt = shard.max_over_ranks(dt, red_dev)
     local_counters = ctx.counters()
     launches_per_step = (int(local_counters[3]) - launches0) // (2 * max(1, args.steps))
-    counters = shard.gather_counters(local_counters, dev if world > 1 else None)
+    counters = shard.gather_counters(local_counters, red_dev)
 
     if os.environ.get("NCHMM_PROFILE") == "1" and rank == 0:
         profile_report(ctx)
@@ -348,6 +362,7 @@ def main():
                                    f"over {world} GPU(s)), template-only Viterbi, builtin {args.model} 6-mer model, identity scaling, "
                                    f"transitions p_skip=.3 p_stay=.1",
                        "reads_per_gpu": reads_per_gpu, "events_per_read": n_events, "parallelism": f"read-sharded x{world} (LPT, no data-path collective)",
+                       "collective": ("gloo, all ranks on GPU 0 (test hook)" if share_gpu0 else ("rccl all-reduce of 8 counters + max of the step time" if world > 1 else "none")),
                        "grid_slots": ctx.grid_slots(), "forward_launches_per_step": launches_per_step,
                        "host_generation_s": round(t_gen, 1)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
