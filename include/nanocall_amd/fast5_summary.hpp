@@ -9,6 +9,7 @@
 #ifndef NANOCALL_AMD_FAST5_SUMMARY_HPP
 #define NANOCALL_AMD_FAST5_SUMMARY_HPP
 
+#include <atomic>
 #include <fstream>
 #include <set>
 
@@ -60,7 +61,9 @@ inline Ed_Table read_events_table(const std::string& fn)
 
 inline Ed_Table read_ed_table(const std::string& fn, const std::string& ed_group)
 {
-    if (is_events_table(fn)) return read_events_table(fn);
+    // (a *.fast5 name is tried as HDF5 straight away: every extra open of a file costs as much as reading its table)
+    const bool named_fast5 = fn.size() >= 6 && fn.compare(fn.size() - 6, 6, ".fast5") == 0;
+    if (!(named_fast5 && nchmm_fast5_available()) && is_events_table(fn)) return read_events_table(fn);
     nchmm_fast5_read r;
     const int rc = nchmm_fast5_load(fn.c_str(), ed_group.c_str(), &r);
     if (rc != NCHMM_OK) throw Error(rc, nchmm_fast5_last_error());   // the reference's hdf5_tools::Exception
@@ -116,6 +119,12 @@ public:
     static unsigned& hairpin_island_window_load() { static unsigned v = 5; return v; }    //  which detect_strands does not call, :661)
     static unsigned& template_only() { static unsigned v = 0; return v; }
     static std::array<unsigned, 4>& trim_margins() { static std::array<unsigned, 4> v = {{50u, 50u, 50u, 50u}}; return v; }
+    // The reference drops the EventDetection table after summarize() and reads the file again in load_events()
+    // (Fast5_Summary.hpp:317-318,329-347) to bound memory.  Opening and reading a FAST5 costs ~0.7 ms and HDF5 serialises
+    // its calls, so a driver that is about to process the reads may let summarize() keep up to this many bytes of tables
+    // (0 = the reference's behaviour); load_events() then uses the kept table and releases it.
+    static size_t& ed_cache_budget() { static size_t v = 0; return v; }
+    static std::atomic<size_t>& ed_cache_bytes() { static std::atomic<size_t> v{0}; return v; }
 
     Fast5_Summary() = default;
     Fast5_Summary(const std::string fn, const Pore_Model_Dict_Type& models, bool sst) { summarize(fn, models, sst); }
@@ -130,8 +139,9 @@ public:
         return o;
     }
 
-    // Fast5_Summary.hpp:138-319
-    void summarize(const std::string& fn, const Pore_Model_Dict_Type& models, bool sst)
+    // Fast5_Summary.hpp:138-319.  `preloaded`: the file's EventDetection table when the caller has read it already (a driver
+    // that reads the files on one thread -- HDF5 serialises anyway -- and summarises on many); it is consumed.
+    void summarize(const std::string& fn, const Pore_Model_Dict_Type& models, bool sst, Ed_Table* preloaded = nullptr)
     {
         valid = true;
         file_name = fn;
@@ -145,7 +155,7 @@ public:
         num_ed_events = 0;
         abasic_level = 0;
         try {
-            Ed_Table t = read_ed_table(file_name, eventdetection_group());
+            Ed_Table t = preloaded ? std::move(*preloaded) : read_ed_table(file_name, eventdetection_group());
             do {
                 if (!t.have_sampling_rate) { log_info(file_name + ": missing sampling rate"); break; }
                 sampling_rate = static_cast<Float_Type>(t.sampling_rate);
@@ -207,6 +217,14 @@ public:
             num_ed_events = 0;
         }
         drop_events();
+        if (ed_events_ptr && num_ed_events > 0) {
+            const size_t bytes = ed_events_ptr->size() * sizeof(nchmm_ed_event);
+            if (ed_cache_bytes().fetch_add(bytes) + bytes <= ed_cache_budget()) {
+                _ed_cached = true;                       // load_events() takes it from here
+                return;
+            }
+            ed_cache_bytes().fetch_sub(bytes);
+        }
         ed_events_ptr.reset();
     }
 
@@ -216,6 +234,8 @@ public:
         drop_events();
         if (num_ed_events == 0) return;
         const bool must_load = !ed_events_ptr;
+        const bool release_cached = _ed_cached;
+        _ed_cached = false;
         if (must_load) {
             Ed_Table t = read_ed_table(file_name, eventdetection_group());
             t.events.resize(std::min<size_t>(t.events.size(), num_ed_events));
@@ -240,7 +260,10 @@ public:
                 e.update_logs();
             }
         }
-        if (must_load) ed_events_ptr.reset();
+        if (must_load || release_cached) {
+            if (release_cached) ed_cache_bytes().fetch_sub(ed_events_ptr->size() * sizeof(nchmm_ed_event));
+            ed_events_ptr.reset();
+        }
     }
     void drop_events()
     {
@@ -292,6 +315,7 @@ public:
 
     static bool& verbose() { static bool v = false; return v; }
 private:
+    bool _ed_cached = false;
     static void log_info(const std::string& msg)
     {
         if (verbose()) std::clog << "info: " << msg << std::endl;

@@ -170,6 +170,7 @@ ValueArg<unsigned> num_threads("t", "threads", "Number of parallel threads.", fa
 // MI355X additions
 ValueArg<int> gpus("", "gpus", "Number of GPUs to shard the reads over. (default: all visible)", false, 0, "int");
 ValueArg<unsigned long> chunk_events("", "chunk-events", "Events decoded per batch and GPU.", false, 32000000ul, "int");
+ValueArg<unsigned long> ed_cache_mb("", "ed-cache-mb", "Memory (MiB) in which event tables read by the summary pass are kept for the basecalling pass instead of re-reading the files.", false, 4096ul, "int");
 ValueArg<std::string> dump_params_fn("", "dump-params", "Write the exact (hex float) parameters and path log-probability of every basecalled strand.", false, "", "file");
 std::vector<std::string> input_fn;   // UnlabeledMultiArg "inputs"
 
@@ -215,6 +216,30 @@ bool parse(int argc, char* argv[], int* rc)
     return true;
 }
 }  // namespace opts
+
+// wall-clock per stage of the run, reported with the counters (the reference logs user CPU seconds of its two loops,
+// nanocall.cpp:580-581,867-868)
+struct Stage_Clock {
+    std::map<std::string, double> secs;
+    std::vector<std::string> order;
+    struct Scope {
+        Stage_Clock& c; std::string name; std::chrono::steady_clock::time_point t0;
+        Scope(Stage_Clock& cl, const std::string& n) : c(cl), name(n), t0(std::chrono::steady_clock::now()) {}
+        ~Scope()
+        {
+            if (!c.secs.count(name)) c.order.push_back(name);
+            c.secs[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    };
+    std::string str() const
+    {
+        std::ostringstream os;
+        for (const auto& n : order) os << " " << n << "=" << secs.at(n);
+        return os.str();
+    }
+};
+static Stage_Clock stage_clock;
+#define STAGE(name) Stage_Clock::Scope stage_scope_##__LINE__(stage_clock, name)
 
 // ---------------------------------------------------------------------------------------------------------------
 // file-system helpers (fs_support.hpp:15-45)
@@ -353,9 +378,35 @@ template <typename F> static void host_parallel(size_t n, unsigned nt, F&& f)
 
 static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, std::deque<Fast5_Summary_Type>& reads)
 {
+    // The reference summarises file after file on one thread (nanocall.cpp:263-273).  Here one thread reads the event
+    // tables (HDF5 serialises its calls; from many threads the same reads take 3-4x longer) a block of files ahead, and
+    // `-t` threads turn the previous block into summaries (abasic level, strand detection, initial scalings).
     const std::vector<std::string> fv(files.begin(), files.end());
     reads.resize(fv.size());
-    host_parallel(fv.size(), opts::num_threads, [&](size_t i) { reads[i].summarize(fv[i], models, opts::double_strand_scaling); });
+    const size_t block = 256;
+    std::vector<Ed_Table> cur, nxt;
+    std::vector<char> cur_ok, nxt_ok;
+    auto read_block = [&](size_t b0, std::vector<Ed_Table>& tab, std::vector<char>& ok) {
+        const size_t b1 = std::min(fv.size(), b0 + block);
+        tab.assign(b1 - b0, Ed_Table());
+        ok.assign(b1 - b0, 0);
+        for (size_t i = b0; i < b1; ++i) {
+            try { tab[i - b0] = read_ed_table(fv[i], Fast5_Summary_Type::eventdetection_group()); ok[i - b0] = 1; }
+            catch (const Error&) { ok[i - b0] = 0; }   // summarize() re-reads it and reports the error as the reference does
+        }
+    };
+    if (!fv.empty()) read_block(0, cur, cur_ok);
+    for (size_t b0 = 0; b0 < fv.size(); b0 += block) {
+        const size_t b1 = std::min(fv.size(), b0 + block);
+        std::thread reader;
+        if (b1 < fv.size()) reader = std::thread([&, b1] { read_block(b1, nxt, nxt_ok); });
+        host_parallel(b1 - b0, opts::num_threads, [&](size_t k) {
+            reads[b0 + k].summarize(fv[b0 + k], models, opts::double_strand_scaling, cur_ok[k] ? &cur[k] : nullptr);
+        });
+        if (reader.joinable()) reader.join();
+        cur.swap(nxt);
+        cur_ok.swap(nxt_ok);
+    }
     for (const auto& s : reads) LOG(info) << "summary: " << s << std::endl;
 }
 
@@ -415,7 +466,11 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
         }
         if (idx.empty()) continue;
         const size_t nr = idx.size();
-        host_parallel(nr, opts::num_threads, [&](size_t i) { reads[idx[i]].load_events(); });
+        {
+            STAGE("load_events_s");
+            host_parallel(nr, opts::num_threads, [&](size_t i) { reads[idx[i]].load_events(); });
+        }
+        auto* stage_soa = new Stage_Clock::Scope(stage_clock, "soa_and_jobs_s");
         std::vector<uint64_t> strand_off(2 * nr + 1, 0);
         std::vector<uint8_t> together(nr);
         for (size_t i = 0; i < nr; ++i) {
@@ -467,8 +522,10 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
             std::copy(p6, p6 + 6, &job_pm[6 * k]);
             for (int s = 0; s < 2; ++s) { job_st[4 * k + 2 * s] = stp[s].p_stay; job_st[4 * k + 2 * s + 1] = stp[s].p_skip; }
         }
+        delete stage_soa;
         // ---- training ----
         if (opts::train && n_jobs) {
+            STAGE("training_total_s");
             const auto t0 = std::chrono::steady_clock::now();
             check(nchmm_pool_train_reads(pool, &o, n_models, M.states.data(), nr, strand_off.data(), mean.data(), stdv.data(), start.data(), n_jobs,
                                          job_read.data(), job_m0.data(), job_m1.data(), job_pm.data(), job_st.data(), job_fit.data(),
@@ -506,6 +563,7 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
         }
         // ---- basecalling ----
         if (opts::basecall && n_jobs) {
+            STAGE("basecalling_total_s");
             std::vector<uint16_t> states(total + 1);
             std::vector<int32_t> best_job(2 * nr, -1);
             std::vector<float> best_logp(2 * nr, NAN);
@@ -588,10 +646,10 @@ static int real_main()
     State_Transitions_Type default_transitions;
     std::deque<Fast5_Summary_Type> reads;
     std::list<std::string> files;
-    init_models(models);
+    { STAGE("init_models_s"); init_models(models); }
     init_transitions(default_transitions);
-    init_files(files);
-    init_reads(models, files, reads);
+    { STAGE("init_files_s"); init_files(files); }
+    { STAGE("init_reads_s"); init_reads(models, files, reads); }
     // devices: one context + host thread per GPU
     int n_dev = 0;
     if (nchmm_device_count(&n_dev) != NCHMM_OK || n_dev < 1) {
@@ -600,6 +658,12 @@ static int real_main()
     }
     int use = opts::gpus.get() > 0 ? opts::gpus.get() : n_dev;
     if (use > n_dev) { LOG(error) << "--gpus " << use << " requested but only " << n_dev << " visible" << std::endl; return EXIT_FAILURE; }
+    // Workspaces: back-pointers 4 KiB and alpha rows 16 KiB per event in flight.  The library would take 60 % / 25 % of the
+    // device for them (best for a resident benchmark loop); a command-line run pays for mapping that memory once, ~20 ms per
+    // GiB on a cold device, so it caps them where the launches are still long enough (measured: 32 GiB of back-pointers =
+    // 3 x 512 reads of 5000 events per launch costs 2 % of the decode rate).
+    setenv("NCHMM_WS_BUDGET_MB", "32768", 0);
+    setenv("NCHMM_FB_BUDGET_MB", "16384", 0);
     nchmm_pool* pool = nullptr;
     std::vector<int> ids;
     if (const char* e = std::getenv("NANOCALL_DEVICE_IDS")) {   // e.g. "0,0": several contexts on one GPU (test hook)
@@ -608,7 +672,7 @@ static int real_main()
         while (std::getline(is, tok, ',')) ids.push_back(std::atoi(tok.c_str()));
         use = (int)ids.size();
     }
-    check(nchmm_pool_create(&pool, use, ids.empty() ? nullptr : ids.data()), "nchmm_pool_create");
+    { STAGE("device_init_s"); check(nchmm_pool_create(&pool, use, ids.empty() ? nullptr : ids.data()), "nchmm_pool_create"); }
     LOG(info) << "devices=" << use << " (of " << n_dev << " visible)" << std::endl;
 
     std::ofstream ofs;
@@ -619,7 +683,7 @@ static int real_main()
         os_p = &ofs;
     }
     uint64_t counters[4] = {0, 0, 0, 0};   // reads, bases, training us, basecalling us
-    if (opts::train || opts::basecall) process_reads(pool, models, reads, os_p, counters);
+    if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters); }
     os_p->flush();
     uint64_t dev[8];
     int used_rccl = 0;
@@ -627,6 +691,7 @@ static int real_main()
     LOG(info) << "counters reads=" << counters[0] << " bases=" << counters[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
               << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " gathered_by=" << (used_rccl ? "rccl_allreduce" : "host_sum")
               << " training_secs=" << counters[2] / 1e6 << " basecalling_secs=" << counters[3] / 1e6 << std::endl;
+    LOG(info) << "stage_wall_secs" << stage_clock.str() << std::endl;
     nchmm_pool_destroy(pool);
     if (!opts::stats_fn.get().empty()) {   // nanocall.cpp:893-903
         std::ofstream sfs(opts::stats_fn.get());
@@ -663,6 +728,7 @@ int main(int argc, char* argv[])
     Fast5_Summary_Type::eventdetection_group() = opts::ed_group;
     Fast5_Summary_Type::template_only() = opts::template_only;
     Fast5_Summary_Type::trim_margins() = {{opts::trim_ed_sq_start, opts::trim_ed_sq_end, opts::trim_ed_hp_start, opts::trim_ed_hp_end}};
+    Fast5_Summary_Type::ed_cache_budget() = (size_t)opts::ed_cache_mb.get() << 20;
     LOG(info) << "eventdetection_group=" << (Fast5_Summary_Type::eventdetection_group().empty() ? std::string("smallest") : Fast5_Summary_Type::eventdetection_group()) << std::endl;
     // pore-related options, nanocall.cpp:936-970
     if (!opts::train_drift.get().empty() && opts::train_drift.get() != "0" && opts::train_drift.get() != "1") {

@@ -75,6 +75,16 @@ Hdf5& h5()
 
 int fail(const std::string& msg) { g_err = msg; return NCHMM_E_IO; }
 
+// One file at a time.  The thread-safe HDF5 build serialises every API call on its own global lock anyway; with a few
+// dozen host threads contending for it call by call, 2000 files took 1.6 s instead of 0.43 s from one thread
+// (profiles/r02_bench_cli.json).  Taking one mutex per FILE keeps the callers' other work (segmentation, scaling) parallel
+// and the HDF5 part at its single-thread speed.
+std::mutex& file_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+
 struct Names { std::vector<std::string> v; };
 herr_t collect(hid_t, const char* name, const H5L_info_t*, void* data)
 {
@@ -162,6 +172,7 @@ int nchmm_fast5_is_valid_file(const char* path)
 {
     if (!path || !h5().ok) return 0;
     Hdf5& L = h5();
+    std::lock_guard<std::mutex> one_file(file_mutex());
     if (L.H5Fis_hdf5(path) <= 0) return 0;
     const hid_t f = L.H5Fopen(path, kAccRdOnly, H5P_DEFAULT);
     if (f < 0) return 0;
@@ -183,6 +194,7 @@ int nchmm_fast5_load(const char* path, const char* ed_group, nchmm_fast5_read* o
     std::memset(out, 0, sizeof(*out));
     if (!h5().ok) return fail(h5().why);
     Hdf5& L = h5();
+    std::lock_guard<std::mutex> one_file(file_mutex());
     const hid_t f = L.H5Fopen(path, kAccRdOnly, H5P_DEFAULT);
     if (f < 0) return fail(std::string(path) + ": cannot open as HDF5");
     int rc = NCHMM_OK;

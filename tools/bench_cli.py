@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the `nanocall` binary (FAST5 in, FASTA out) on this machine's GPU(s): N synthetic 2D reads as
+FAST5 files (a few dozen distinct reads written through tools/make_fast5, copied under new names), one CLI run, wall time
+split into the stages the CLI reports.  Prints one JSON line.
+
+  READS=2000 EVENTS=3000 THREADS=32 python tools/bench_cli.py [extra nanocall options]
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import oracle_pipeline as op   # noqa: E402  (only its synthetic read generator: test infrastructure, not the measured path)
+
+n_reads = int(os.environ.get("READS", 2000))
+n_events = int(os.environ.get("EVENTS", 3000))
+threads = int(os.environ.get("THREADS", min(32, os.cpu_count() or 1)))
+distinct = min(n_reads, 24)
+cli = os.path.join(ROOT, "nanocall_amd", "bin", "nanocall")
+tool = os.path.join(ROOT, "tools", "make_fast5")
+if not os.path.exists(tool):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "make_fast5"], check=True, capture_output=True)
+tmp = tempfile.mkdtemp(prefix="nanocall_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+try:
+    t0 = time.perf_counter()
+    half = n_events // 2
+    for k in range(distinct):
+        ed = op.synth_ed_table("r73", half, half, seed=100 + k, hairpin=8, complement_model="r73.c.p1.006.ont.model" if k % 2 else "r73.c.p2.006.ont.model",
+                               scale=1.0 + 0.01 * (k % 5), shift=float(k % 7) - 3.0, drift=0.002 * (k % 3))
+        ev = os.path.join(tmp, f"seed{k}.events")
+        op.write_events_table(ev, ed, 4000.0, f"read-{k}")
+        subprocess.run([tool, ev, os.path.join(tmp, f"seed{k}.fast5")], check=True)
+        os.remove(ev)
+    d = os.path.join(tmp, "reads")
+    os.mkdir(d)
+    for r in range(n_reads):
+        shutil.copy(os.path.join(tmp, f"seed{r % distinct}.fast5"), os.path.join(d, f"r{r:06d}.fast5"))
+    t_gen = time.perf_counter() - t0
+    out = os.path.join(tmp, "out.fa")
+    cmd = [cli, "--pore", "r73", "-t", str(threads), "-o", out] + sys.argv[1:] + [d]
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    if os.environ.get("NCHMM_DEBUG"):
+        sys.stderr.write("".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("[nchmm")))
+    line = [l for l in p.stderr.splitlines() if "counters reads=" in l][-1]
+    kv = dict(tok.split("=") for tok in line.split() if "=" in tok)
+    stages = [l for l in p.stderr.splitlines() if "stage_wall_secs" in l][-1].split("stage_wall_secs")[1].split()
+    stages = {t.split("=")[0]: round(float(t.split("=")[1]), 3) for t in stages}
+    n_rec = sum(1 for l in open(out) if l.startswith(">"))
+    ev_in = int(kv["reads"]) * n_events
+    print(json.dumps({"reads": int(kv["reads"]), "events_per_read": n_events, "fasta_records": n_rec, "bases": int(kv["bases"]),
+                      "wall_s": round(wall, 3), "training_s": float(kv["training_secs"]), "basecalling_s": float(kv["basecalling_secs"]),
+                      "other_s_(summaries, event loading, FASTA)": round(wall - float(kv["training_secs"]) - float(kv["basecalling_secs"]), 3),
+                      "reads_per_s": round(int(kv["reads"]) / wall, 1), "input_Mevents_per_s_end_to_end": round(ev_in / wall / 1e6, 2),
+                      "events_decoded": int(kv["events_decoded"]), "decoded_Mevents_per_s_in_basecalling": round(int(kv["events_decoded"]) / float(kv["basecalling_secs"]) / 1e6, 1),
+                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages,
+                      "cmd": " ".join(cmd[:1] + cmd[1:-1])}))
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
