@@ -221,3 +221,66 @@ def test_option_errors_and_help():
     for opt in ("--pore", "--1d", "--scaling-max-rounds", "--pr-skip", "--pr-stay", "--fasta-line-width", "--stats", "--no-train-transitions"):
         assert opt in h
     assert "cannot open" in run_cli(["--pore", "r73", "/nonexistent/x.fast5"], expect_rc=1).stderr
+
+
+def _kmer(j):
+    return "".join("ACGT"[(j >> (2 * (5 - i))) & 3] for i in range(6))
+
+
+def test_custom_model_files_equal_the_builtin_models(tmp_path):
+    """-m strand:file (Pore_Model operator>>, Pore_Model.hpp:251-287; init_models nanocall.cpp:99-153): the three r73 tables
+    written as text (rows shuffled, header + comment lines) decode to the same sequences as --pore r73."""
+    import nanocall_amd as na
+    rng = np.random.default_rng(3)
+    args = []
+    for fname, name, strand in (("a_c_p1.model", "r73.c.p1", 1), ("b_c_p2.model", "r73.c.p2", 1), ("c_t.model", "r73.t", 0)):   # same order as the builtin names
+        t = na.builtin_model(name)
+        with open(tmp_path / fname, "w") as f:
+            f.write("#model_file written by the test\nkmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+            for j in rng.permutation(4096):
+                f.write(_kmer(int(j)) + "\t" + "\t".join(f"{v:.9g}" for v in t[j]) + "\n")
+        args += ["-m", f"{strand}:{tmp_path / fname}"]
+    files = [os.path.join(G, n + ".fast5") for n in ("r73_2d_a", "r73_1d_b")]
+    base = ["--scaling-num-events", "120", "--scaling-max-rounds", "2"]
+    a = run_cli(["--pore", "r73"] + base + files).stdout
+    b = run_cli(["--pore", "r73"] + base + args + files).stdout
+    assert a == b and a.count(">") == 3
+    # the same through --model-fofn; and a strand given models on one side only is refused (nanocall.cpp:130-135)
+    fofn = tmp_path / "models.fofn"
+    fofn.write_text("".join(f"{s}:{tmp_path / f}\n" for f, s in (("a_c_p1.model", 1), ("b_c_p2.model", 1), ("c_t.model", 0))))
+    assert run_cli(["--pore", "r73", "--model-fofn", str(fofn)] + base + files).stdout == a
+    assert "models were specified only for strand" in run_cli(["-m", f"0:{tmp_path / 'c_t.model'}"] + files, expect_rc=1).stderr
+
+
+def test_non_default_transition_and_segmentation_options_no_train():
+    inputs = fixture_inputs(["r73_2d_a", "r73_2d_e"])
+    args = ["--pore", "r73", "--no-train", "--pr-stay", "0.12", "--pr-skip", "0.25", "--min-ed-events", "20", "--trim-ed-sq-start", "30",
+            "--trim-ed-sq-end", "70", "--trim-ed-hp-start", "40", "--trim-ed-hp-end", "60", "--max-ed-events", "1300"]
+    p = run_cli(args + [i[0] for i in inputs])
+    o = op.Opts(pore="r73", train=False, pr_stay=0.12, pr_skip=0.25, min_ed_events=20, trim=(30, 70, 40, 60), max_ed_events=1300)
+    exp, reads, recs = op.run(o, inputs)
+    assert p.stdout == exp and len(recs) >= 3
+    assert [r.num_ed_events for r in reads] == [1300, 1300]          # both tables are longer than the cap
+
+
+@pytest.mark.parametrize("extra,kw", [
+    (["--no-train-transitions"], dict(train_transitions=False)),
+    (["--no-train-scaling", "--single-strand-scaling"], dict(train_scaling=False, single_strand_scaling=True)),
+    (["--train-drift", "0"], dict(train_drift=False)),
+])
+def test_partial_training_modes_teacher_forced(tmp_path, extra, kw):
+    inputs = fixture_inputs(["r73_2d_a", "r73_1d_b"])
+    dump = tmp_path / "params.tsv"
+    base = ["--pore", "r73", "--scaling-num-events", "120", "--scaling-max-rounds", "2", "--dump-params", str(dump)]
+    p = run_cli(base + extra + [i[0] for i in inputs])
+    o = op.Opts(pore="r73", scaling_num_events=120, scaling_max_rounds=2, **kw)
+    d = op.read_dump(str(dump))
+    check_teacher_forced(o, inputs, p.stdout, d)
+    for v in d.values():
+        if "--no-train-transitions" in extra:
+            assert v["st"].tolist() == [np.float32(0.1), np.float32(0.3)]        # transitions stay at --pr-stay / --pr-skip
+        if "--no-train-scaling" in extra:
+            assert v["pm"][2] == 0 and v["pm"][3] == 1 and v["pm"][4] == 1 and v["pm"][5] == 1   # only the initial scale / shift
+        if "--train-drift" in extra:
+            assert v["pm"][2] == 0
+    same, n = check_free_running(o, inputs, d, p.stdout)
