@@ -1,6 +1,12 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fwbw 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('base', d['value'], d['roofline']['kernel_ms'])"
-make -C nanocall_amd/csrc clean > /dev/null; make -C nanocall_amd/csrc -j16 HIPFLAGS='--offload-arch=gfx950 $(CXXFLAGS) -fno-slp-vectorize -DNCHMM_PK_EMISSION' > gpurun_out/r02i_build.log 2>&1
-python -m pytest tests/test_viterbi_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q 2>&1 | tail -2
-python bench.py --steps 10 --warmup 3 --no-fwbw 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pk', d['value'], d['roofline']['kernel_ms'], d['cpu_baseline']['parity_checked_reads'])"
+NCHMM_FB_LAYOUT=8 python tools/bench_fwbw.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('layout8', d['value'], d['kernel_ms'], d['log_pr_data_mean'])"
+python tools/bench_fwbw.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('layout4', d['value'], d['kernel_ms'], d['log_pr_data_mean'])"
+cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r02j_stats -o fb -- python3 $GRAFT_REPO_ROOT/tools/bench_fwbw.py > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
+python - <<'PY'
+import csv,glob
+for f in glob.glob('gpurun_out/r02j_stats/**/*kernel_stats.csv', recursive=True):
+    for row in csv.DictReader(open(f)):
+        if 'scaled' in row['Name']: print(row['Name'][:50], row['AverageNs'], row['MinNs'])
+PY
+timeout 600 python -m pytest tests/test_fwbw_gpu.py -m gpu -x -q 2>&1 | tail -3
