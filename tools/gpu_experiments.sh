@@ -1,0 +1,56 @@
+#!/bin/bash
+# tools/gpu_experiments.sh <which> -- the round-2 measurement recipes, run on the GPU box from the repo root
+# (gpurun -- 'bash tools/gpu_experiments.sh stalls').  Results go to gpurun_out/; what was kept is under profiles/.
+#
+#   stalls    where do the two hot kernels wait?  Rebuilds the library with the experiment switches of the kernels
+#             (-DNCHMM_EXP_NOLOAD: alpha-row loads of the backward sweep replaced by constants; -DNCHMM_EXP_NOBARRIER: the
+#             per-event barrier removed; -DNCHMM_EXP_NOSTORE: back-pointer stores compiled out; results are garbage by
+#             construction) and times bench.py / tools/bench_fwbw.py for each.            -> DESIGN.md sections 4.1 / 4.3
+#   budgets   config-4 shard throughput against the back-pointer workspace budget (tail of a launch vs launch count)
+#   rates     tools/ubench/valu_rate.hip: ns per wave-instruction per SIMD by instruction class and occupancy
+#   hbm       torch fill / sum / copy rates of the device (calibration of "achievable" for the roofline fractions)
+#   cli       tools/bench_cli.py: FAST5 files -> nanocall -> FASTA, wall time by stage
+set -u
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+variant() {  # tag, extra hipcc flags
+  make -C nanocall_amd/csrc clean > /dev/null
+  make -C nanocall_amd/csrc -j16 HIPFLAGS="--offload-arch=gfx950 \$(CXXFLAGS) -fno-slp-vectorize $2" > gpurun_out/exp_build_$1.log 2>&1
+  python tools/bench_fwbw.py > gpurun_out/exp_fb_$1.json 2>/dev/null
+  timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fwbw > gpurun_out/exp_vit_$1.json 2>/dev/null
+  python - "$1" <<'PY'
+import json, sys
+t = sys.argv[1]
+def last(f, pick):
+    try:
+        return pick(json.loads(open(f).read().strip().splitlines()[-1]))
+    except Exception as e:
+        return ("ERR", str(e)[:60])
+print(t, "FB (M event-rounds/s, kernel ms)", last(f"gpurun_out/exp_fb_{t}.json", lambda d: (d["value"], d["kernel_ms"])),
+      " Viterbi (Mevents/s, kernel ms)", last(f"gpurun_out/exp_vit_{t}.json", lambda d: (d["value"], d["roofline"]["kernel_ms"])))
+PY
+}
+case "${1:-}" in
+stalls)
+  variant base ""
+  variant noload "-DNCHMM_EXP_NOLOAD"
+  variant nobarrier "-DNCHMM_EXP_NOBARRIER"
+  variant nostore "-DNCHMM_EXP_NOSTORE"
+  make -C nanocall_amd/csrc clean > /dev/null; make -C nanocall_amd/csrc -j16 > /dev/null 2>&1 ;;
+budgets)
+  for mb in 0 65536 32768 16384 8192; do
+    if [ $mb = 0 ]; then unset NCHMM_WS_BUDGET_MB; else export NCHMM_WS_BUDGET_MB=$mb; fi
+    python bench.py --reads 12500 --steps 3 --warmup 1 --no-cpu-baseline --no-fwbw 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('budget_mb=$mb', 'Mevents/s', d['value'], 'ms/step', d['ms_per_step'], 'launches', d['config']['forward_launches_per_step'])"
+  done ;;
+rates)
+  (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate) | tee gpurun_out/valu_rate.txt ;;
+hbm)
+  python tools/ubench/hbm_rate.py | tee gpurun_out/hbm_rate.txt ;;
+cli)
+  READS=${READS:-8000} EVENTS=${EVENTS:-5000} THREADS=${THREADS:-32} python tools/bench_cli.py | tee gpurun_out/bench_cli.json ;;
+*)
+  echo "usage: bash tools/gpu_experiments.sh stalls|budgets|rates|hbm|cli" ; exit 2 ;;
+esac
