@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <deque>
 #include <fstream>
@@ -220,6 +221,7 @@ bool parse(int argc, char* argv[], int* rc)
 // wall-clock per stage of the run, reported with the counters (the reference logs user CPU seconds of its two loops,
 // nanocall.cpp:580-581,867-868)
 struct Stage_Clock {
+    std::mutex m;
     std::map<std::string, double> secs;
     std::vector<std::string> order;
     struct Scope {
@@ -227,6 +229,7 @@ struct Stage_Clock {
         Scope(Stage_Clock& cl, const std::string& n) : c(cl), name(n), t0(std::chrono::steady_clock::now()) {}
         ~Scope()
         {
+            std::lock_guard<std::mutex> g(c.m);
             if (!c.secs.count(name)) c.order.push_back(name);
             c.secs[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
@@ -376,13 +379,26 @@ template <typename F> static void host_parallel(size_t n, unsigned nt, F&& f)
     for (auto& t : th) t.join();
 }
 
-static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, std::deque<Fast5_Summary_Type>& reads)
+// how far the summary pass has got: reads [0, ready) are summarised (the decode loop runs behind it)
+struct Read_Progress {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t ready = 0;
+    bool done = false;
+    void publish(size_t n, bool finished)
+    {
+        { std::lock_guard<std::mutex> g(m); ready = n; done = finished; }
+        cv.notify_all();
+    }
+};
+
+static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, std::deque<Fast5_Summary_Type>& reads,
+                       Read_Progress& progress)
 {
     // The reference summarises file after file on one thread (nanocall.cpp:263-273).  Here one thread reads the event
     // tables (HDF5 serialises its calls; from many threads the same reads take 3-4x longer) a block of files ahead, and
     // `-t` threads turn the previous block into summaries (abasic level, strand detection, initial scalings).
-    const std::vector<std::string> fv(files.begin(), files.end());
-    reads.resize(fv.size());
+    const std::vector<std::string> fv(files.begin(), files.end());   // (`reads` was sized by the caller: its elements do not move)
     const size_t block = 256;
     std::vector<Ed_Table> cur, nxt;
     std::vector<char> cur_ok, nxt_ok;
@@ -406,8 +422,10 @@ static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::
         if (reader.joinable()) reader.join();
         cur.swap(nxt);
         cur_ok.swap(nxt_ok);
+        for (size_t i = b0; i < b1; ++i) LOG(info) << "summary: " << reads[i] << std::endl;
+        progress.publish(b1, b1 == fv.size());
     }
-    for (const auto& s : reads) LOG(info) << "summary: " << s << std::endl;
+    progress.publish(fv.size(), true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -428,7 +446,7 @@ struct Model_Table {
 };
 
 static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, std::deque<Fast5_Summary_Type>& reads, std::ostream* os_p,
-                          uint64_t counters[4])
+                          uint64_t counters[4], Read_Progress& progress)
 {
     std::ofstream dump;
     if (!opts::dump_params_fn.get().empty()) {
@@ -452,18 +470,34 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
     o.train_drift = opts::train_drift.get() == "1"; o.default_p_stay = opts::pr_stay; o.default_p_skip = opts::pr_skip;
 
     const uint64_t chunk_cap = std::max<uint64_t>(1, opts::chunk_events.get()) * (uint64_t)nchmm_pool_size(pool);
+    // The summary pass (one FAST5 reader thread + the summarising threads) runs AHEAD of this loop: a chunk is decoded as soon
+    // as enough summarised reads are waiting (or the pass has finished), so the GPU stages hide behind the file reading.
+    const uint64_t chunk_min = std::min<uint64_t>(chunk_cap, (uint64_t)16000000 * (uint64_t)nchmm_pool_size(pool));   // (smaller chunks leave the GPU launches short: 3x the GPU time at 4 M)
     size_t next = 0;
     while (next < reads.size()) {
-        // ---- the chunk: consecutive reads up to the event budget (at least one) ----
+        // ---- the chunk: consecutive summarised reads up to the event budget (at least one) ----
         std::vector<size_t> idx;
         uint64_t budget = 0;
-        while (next < reads.size()) {
-            const Fast5_Summary_Type& r = reads[next];
-            const uint64_t ev = r.num_ed_events ? (r.strand_bounds[1] - r.strand_bounds[0]) + (r.strand_bounds[3] > r.strand_bounds[2] ? r.strand_bounds[3] - r.strand_bounds[2] : 0) : 0;
-            if (!idx.empty() && budget + ev > chunk_cap) break;
-            if (r.num_ed_events) { idx.push_back(next); budget += ev; }   // (reads without events are skipped, nanocall.cpp:294,623)
-            ++next;
+        size_t scan = next;
+        for (;;) {
+            size_t lim;
+            bool all;
+            {
+                std::unique_lock<std::mutex> lk(progress.m);
+                progress.cv.wait(lk, [&] { return progress.ready > scan || progress.done; });
+                lim = progress.ready; all = progress.done;
+            }
+            bool full = false;
+            while (scan < lim) {
+                const Fast5_Summary_Type& r = reads[scan];
+                const uint64_t ev = r.num_ed_events ? (r.strand_bounds[1] - r.strand_bounds[0]) + (r.strand_bounds[3] > r.strand_bounds[2] ? r.strand_bounds[3] - r.strand_bounds[2] : 0) : 0;
+                if (!idx.empty() && budget + ev > chunk_cap) { full = true; break; }
+                if (r.num_ed_events) { idx.push_back(scan); budget += ev; }   // (reads without events are skipped, nanocall.cpp:294,623)
+                ++scan;
+            }
+            if (full || budget >= chunk_min || (all && scan >= reads.size())) break;   // else: wait for more summaries
         }
+        next = scan;
         if (idx.empty()) continue;
         const size_t nr = idx.size();
         {
@@ -649,7 +683,6 @@ static int real_main()
     { STAGE("init_models_s"); init_models(models); }
     init_transitions(default_transitions);
     { STAGE("init_files_s"); init_files(files); }
-    { STAGE("init_reads_s"); init_reads(models, files, reads); }
     // devices: one context + host thread per GPU
     int n_dev = 0;
     if (nchmm_device_count(&n_dev) != NCHMM_OK || n_dev < 1) {
@@ -683,7 +716,17 @@ static int real_main()
         os_p = &ofs;
     }
     uint64_t counters[4] = {0, 0, 0, 0};   // reads, bases, training us, basecalling us
-    if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters); }
+    // the summary pass (init_reads) runs on its own threads; the decode loop follows it block by block
+    reads.resize(files.size());
+    Read_Progress progress;
+    std::thread summary_pass([&] { STAGE("init_reads_s"); init_reads(models, files, reads, progress); });
+    try {
+        if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters, progress); }
+    } catch (...) {
+        summary_pass.join();
+        throw;
+    }
+    summary_pass.join();
     os_p->flush();
     uint64_t dev[8];
     int used_rccl = 0;
