@@ -328,6 +328,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the hot kernels are VALU-issue bound, so their duration follows the shader clock -- and the boxes of one pool do not
+    # all sustain the same clock (the same binary: 15.8 ms and 23.2 ms per launch on two boxes).  Probe it while still hot.
+    sclk_mhz = ctx.shader_clock_mhz()
     red_dev = dev if (world > 1 and not share_gpu0) else None      # gloo reduces host tensors
     dt = shard.max_over_ranks(dt, red_dev)
     local_counters = ctx.counters()
@@ -366,6 +369,8 @@ def main():
                        "grid_slots": ctx.grid_slots(), "forward_launches_per_step": launches_per_step,
                        "host_generation_s": round(t_gen, 1)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
+            "device": {"shader_clock_mhz_under_load": round(sclk_mhz, 0), "peak_shader_clock_mhz": round(SCLK_GHZ * 1e3, 0),
+                       "note": "rank 0, ~3 ms full-chip VALU probe right after the timed region (nchmm_shader_clock_mhz)"},
         }
         if events_per_launch:
             achieved = BYTES_PER_EVENT * events_per_launch / (k_ms * 1e-3) / 1e9

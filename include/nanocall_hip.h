@@ -388,6 +388,12 @@ int nchmm_counters(const nchmm_ctx* ctx, uint64_t out[8]);
  * until those kernels have finished. */
 int nchmm_last_kernel_ms(nchmm_ctx* ctx, float out[4]);
 
+/* The shader clock (MHz) the device sustains under a full-chip VALU load, measured now by a ~3 ms probe kernel on the
+ * context's stream: shader-clock ticks over constant-rate wall-clock ticks.  The hot kernels are VALU-issue bound, so
+ * their duration scales with 1 / this clock; bench.py reports it next to the throughput (boxes of one pool differ).
+ * No reference counterpart (measurement aid). */
+int nchmm_shader_clock_mhz(nchmm_ctx* ctx, double* out_mhz);
+
 /* Phase counters of the Viterbi kernel, accumulated over launches while the environment variable
  * NCHMM_PROFILE=1 was set at nchmm_create time: out[0] = forward-sweep ticks summed over blocks,
  * [1] = unused, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks), [4] = traceback

@@ -72,6 +72,7 @@ SIGNATURES = {
     "nchmm_em_round": (C.c_int, [vp, C.c_size_t] + [vp] * 7 + [C.c_size_t, vp, C.c_int, vp, vp, vp]),
     "nchmm_counters": (C.c_int, [vp, vp]),
     "nchmm_last_kernel_ms": (C.c_int, [vp, vp]),
+    "nchmm_shader_clock_mhz": (C.c_int, [vp, vp]),
     "nchmm_profile_ticks": (C.c_int, [vp, vp, C.c_int]),
     "nchmm_profile_blocks": (C.c_int, [vp, vp]),
     "nchmm_grid_slots": (C.c_int, [vp, vp]),

@@ -467,6 +467,12 @@ class Context:
         check(lib().nchmm_last_kernel_ms(self._h, _p(out)), "nchmm_last_kernel_ms")
         return tuple(float(x) for x in out)
 
+    def shader_clock_mhz(self):
+        """nchmm_shader_clock_mhz: the shader clock the device sustains under a full-chip VALU load, measured now."""
+        out = C.c_double(0.0)
+        check(lib().nchmm_shader_clock_mhz(self._h, C.byref(out)), "nchmm_shader_clock_mhz")
+        return float(out.value)
+
     def profile_ticks(self, reset=True):
         out = np.zeros(8, np.uint64)
         check(lib().nchmm_profile_ticks(self._h, _p(out), int(reset)), "nchmm_profile_ticks")

@@ -4,6 +4,7 @@
 #include "nchmm_device.h"
 #include "nchmm_internal.hpp"
 #include "nchmm_kmer.hpp"
+#include "nchmm_probe.h"
 
 #include <algorithm>
 #include <cmath>
@@ -711,6 +712,8 @@ int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(d + o_off, off, 8 * (n_reads + 1), hipMemcpyHostToDevice, s));
     if (total) {
+        // pageable memory is fine here: the runtime pins it in place and the copies run at PCIe rate (55 GB/s measured,
+        // tools/ubench/pcie_rate.py) -- 1.1 ms of a 17 ms call; staging through our own pinned buffer measured slower
         HIP_TRY(c, hipMemcpyAsync(d + o_cm, cmean, 4 * total, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(d + o_sd, stdv, 4 * total, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(d + o_ls, lstdv, 4 * total, hipMemcpyHostToDevice, s));
@@ -724,10 +727,10 @@ int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float
                            trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or),
                            (uint16_t*)(d + o_st), (float*)(d + o_lp), (int32_t*)(d + o_ss));
     if (rc != NCHMM_OK) return rc;
-    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(out_logp, d + o_lp, 4 * n_reads, hipMemcpyDeviceToHost, s));
     std::vector<int32_t> status(n_reads);
     HIP_TRY(c, hipMemcpyAsync(status.data(), d + o_ss, 4 * n_reads, hipMemcpyDeviceToHost, s));
+    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     int worst = NCHMM_OK;
     for (size_t r = 0; r < n_reads; ++r) {
@@ -811,10 +814,10 @@ int nchmm_viterbi_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float
                            trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or), (uint16_t*)(d + o_st),
                            (float*)(d + o_lp), (int32_t*)(d + o_ss));
     if (rc != NCHMM_OK) return rc;
-    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(out_logp, d + o_lp, 4 * n_cand, hipMemcpyDeviceToHost, s));
     std::vector<int32_t> status(n_cand);
     HIP_TRY(c, hipMemcpyAsync(status.data(), d + o_ss, 4 * n_cand, hipMemcpyDeviceToHost, s));
+    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     int worst = NCHMM_OK;
     for (size_t v = 0; v < n_cand; ++v) {
@@ -1155,6 +1158,30 @@ int nchmm_last_kernel_ms(nchmm_ctx* c, float out[4])
         HIP_TRY(c, hipEventSynchronize(c->ev_fb1));
         HIP_TRY(c, hipEventElapsedTime(&out[2], c->ev_fb0, c->ev_fb1));
     }
+    return NCHMM_OK;
+}
+
+int nchmm_shader_clock_mhz(nchmm_ctx* c, double* out_mhz)
+{
+    if (!c || !out_mhz) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int wall_khz = 0;
+    HIP_TRY(c, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device));
+    if (wall_khz <= 0) wall_khz = 100000;
+    unsigned long long* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, 3 * sizeof(unsigned long long)));
+    unsigned long long h[3] = {0, 0, 0};
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(h), c->stream);
+    if (e == hipSuccess) {
+        launch_clock_probe(d, 4 * c->n_cu, 40000, c->stream);       // 4 waves per SIMD for about 3 ms
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIP_TRY(c, e);
+    if (h[1] == 0) return NCHMM_E_HIP;
+    *out_mhz = (double)h[0] / (double)h[1] * (double)wall_khz * 1e-3;
     return NCHMM_OK;
 }
 

@@ -30,3 +30,4 @@ def test_two_ranks_share_gpu0_and_report_whole_job_throughput():
     # whole-job value = all ranks' events / max-over-ranks time
     assert abs(d["value"] - 2 * 600 * 800 * 2 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) <= 0.01 * d["value"]
     assert "cpu_baseline" not in d and "fwbw" not in d   # N = 1 only
+    assert 400 <= d["device"]["shader_clock_mhz_under_load"] <= 2600

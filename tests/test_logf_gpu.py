@@ -83,3 +83,9 @@ def test_viterbi_raw_equals_host_prepared_viterbi(gpu_ctx, r73t):
         else:
             assert np.isnan(logp[v])
         v += 1
+
+
+def test_shader_clock_probe_reports_a_plausible_clock(gpu_ctx):
+    # nchmm_shader_clock_mhz: gfx950's valid sclk range is 500-2400 MHz (rocm-smi --showsclkrange on the boxes)
+    mhz = gpu_ctx.shader_clock_mhz()
+    assert 400.0 <= mhz <= 2600.0, mhz

@@ -9,6 +9,7 @@
 #   budgets   config-4 shard throughput against the back-pointer workspace budget (tail of a launch vs launch count)
 #   rates     tools/ubench/valu_rate.hip: ns per wave-instruction per SIMD by instruction class and occupancy
 #   hbm       torch fill / sum / copy rates of the device (calibration of "achievable" for the roofline fractions)
+#   hostpath  nchmm_viterbi / nchmm_viterbi_raw from pageable host memory (wall vs kernels), and the box's PCIe / host-copy rates
 #   cli       tools/bench_cli.py: FAST5 files -> nanocall -> FASTA, wall time by stage
 set -u
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
@@ -49,8 +50,11 @@ rates)
   (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate) | tee gpurun_out/valu_rate.txt ;;
 hbm)
   python tools/ubench/hbm_rate.py | tee gpurun_out/hbm_rate.txt ;;
+hostpath)
+  python tools/bench_hostpath.py | tee gpurun_out/bench_hostpath.json
+  python tools/ubench/pcie_rate.py | tee gpurun_out/pcie_rate.txt ;;
 cli)
   READS=${READS:-8000} EVENTS=${EVENTS:-5000} THREADS=${THREADS:-32} python tools/bench_cli.py | tee gpurun_out/bench_cli.json ;;
 *)
-  echo "usage: bash tools/gpu_experiments.sh stalls|budgets|rates|hbm|cli" ; exit 2 ;;
+  echo "usage: bash tools/gpu_experiments.sh stalls|budgets|rates|hbm|hostpath|cli" ; exit 2 ;;
 esac
