@@ -121,6 +121,36 @@ __device__ __forceinline__ void wave_sum7_lane63(float& a, float& b, float& c, f
 #undef NCHMM_DPP7
 }
 
+// Seven wave sums in 21 instructions instead of 42 (gfx950's lane-swap instructions).  v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, so one swap + one add folds TWO values from 64 to 32 lanes
+// (each then lives in one half); v_permlane16_swap does the same between 16-lane rows.  After the two folds the seven
+// values sit one per row in two registers and four DPP steps sum each row.  Layout on return, row r = lanes 16 r .. 16 r + 15,
+// every lane of a row holding the row's total:   q0 = rows { a, b, c, d },   q1 = rows { e, f, g, 0 }.
+// (Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc 7.2 miscompiles the builtins' second result -- the add of
+// the two halves comes out as `v_add_f32 v1, v1, v1`; tools/ubench/permlane_swap.hip shows it on the device.  The
+// s_nop covers the two wait states between a VALU write and a lane-swap read, which the compiler cannot see in here.)
+__device__ __forceinline__ void wave_sum7_rows(float a, float b, float c, float d, float e, float f, float g, float& q0, float& q1)
+{
+    float z = 0.0f;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"      // a = [ a.lo | c.lo ], c = [ a.hi | c.hi ]
+                 "v_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\t"
+                 "v_permlane32_swap_b32 %6, %7"
+                 : "+v"(a), "+v"(c), "+v"(b), "+v"(d), "+v"(e), "+v"(g), "+v"(f), "+v"(z));
+    float ac = a + c, bd = b + d, eg = e + g, f0 = f + z;             // halves { a | c }, { b | d }, { e | g }, { f | 0 }
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"      // ac = rows { ac.0, bd.0, ac.2, bd.2 }, bd = rows { ac.1, bd.1, ac.3, bd.3 }
+                 "v_permlane16_swap_b32 %2, %3"
+                 : "+v"(ac), "+v"(bd), "+v"(eg), "+v"(f0));
+    float u = ac + bd, v = eg + f0;                                    // rows { a, b, c, d } and { e, f, g, 0 }
+    u = dpp_add<0xB1, 0xF>(u); v = dpp_add<0xB1, 0xF>(v);
+    u = dpp_add<0x4E, 0xF>(u); v = dpp_add<0x4E, 0xF>(v);
+    u = dpp_add<0x141, 0xF>(u); v = dpp_add<0x141, 0xF>(v);
+    u = dpp_add<0x140, 0xF>(u); v = dpp_add<0x140, 0xF>(v);
+    q0 = u; q1 = v;
+}
+
 // LDS tables are pair-major: the two floats of thread tau's cell pair `pair` of a table sit at
 // sTab[f][(pair * 512 + tau) * 2 ..]: consecutive lanes read consecutive 8-byte words (conflict-free
 // ds_read_b64) and every access of a thread is ONE base register plus an immediate offset.

@@ -35,17 +35,20 @@ using namespace fb;
 namespace {
 
 constexpr float kMinTotal = 0x1p-100f;
+constexpr unsigned kG1Pitch = 544, kG2Pitch = 144;   // plane pitches of the backward sweep's group-sum arrays (words)
 constexpr int kMaxKappaExp = 100;     // |Ia + Ib - Ia_final| beyond this: forward and backward mass barely overlap
 
 // binary exponent e of a positive normal float z (2^e <= z < 2^(e+1)) and the exact scale 2^-e
 __device__ __forceinline__ int exponent_of(float z) { return (int)((__builtin_bit_cast(unsigned, z) >> 23) & 255u) - 127; }
 __device__ __forceinline__ float pow2i(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // -126 <= e <= 127
 
-// (x - mu)^2 r2 + (y - eta)^2 lq / y  -- the state-dependent part of -log2 emission
-__device__ __forceinline__ float xs(float x, float y, float ry, float mu, float r2, float eta, float lq)
+// (x - mu)^2 r2 + (y - eta)^2 lq / y  -- the state-dependent part of -log2 emission.  The division by y is folded into
+// the difference: (y - eta) / sqrt(y) = y rsq(y) - eta rsq(y) is one FMA on the two per-event values ysry = y rsq(y) and
+// sry = rsq(y) (v_rsq_f32, one per thread and event), which takes a multiply per cell out of both sweeps: 6 VALU ops.
+__device__ __forceinline__ float xs(float x, float ysry, float sry, float mu, float r2, float eta, float lq)
 {
-    const float dx = x - mu, dy = y - eta;
-    return __builtin_fmaf(dx * dx, r2, dy * dy * lq * ry);
+    const float dx = x - mu, dyp = __builtin_fmaf(-eta, sry, ysry);
+    return __builtin_fmaf(dx * dx, r2, dyp * dyp * lq);
 }
 
 __device__ __forceinline__ float block_max(float v, float* sRed, unsigned wave, unsigned lane)
@@ -67,6 +70,20 @@ __device__ __forceinline__ void flag_window(const FwbwArgs& P, unsigned w)
     atomicAdd(P.fb_total, 1ull);
 }
 
+
+// Two blocks share a CU, two waves of each on every SIMD.  Each block alternates a VALU-bound phase with a wait (the
+// LDS exchange behind its per-event barrier, the alpha-row load), and with equal priorities the issue arbiter keeps the
+// two in step: both compute at half speed, then both wait.  Measured on the backward sweep: one block per CU 1.70 us per
+// event, two blocks 2.91 us per event EACH -- the second block bought 17 %.  A fixed priority order takes them out of
+// step: the first block runs as if alone and the second fills its waits (the queue gives the faster block more windows).
+__device__ __forceinline__ void stagger_block_priority()
+{
+#ifndef NCHMM_FB_NO_PRIO
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave slot [3:0]
+    if (((hw & 15u) >> 1) & 1u) __builtin_amdgcn_s_setprio(0);       // the block in wave slots 2,3 of each SIMD
+    else __builtin_amdgcn_s_setprio(3);
+#endif
+}
 }  // namespace
 
 // ================================================ forward ================================================
@@ -75,13 +92,14 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
     __shared__ __attribute__((aligned(16))) float sG1[2][1024];
     __shared__ __attribute__((aligned(16))) float sG2[2][256];
     __shared__ __attribute__((aligned(16))) float sZ[2][kThreads / 64];
-    __shared__ __attribute__((aligned(16))) float4 sEv[kFbChunk];     // x, y, 1/y, log2e * 3 log(y) / 2
+    __shared__ __attribute__((aligned(16))) float4 sEv[kFbChunk];     // x, y rsq(y), rsq(y), log2e * 3 log(y) / 2
     __shared__ float sRed[16];
     __shared__ unsigned sWork;
 
     const unsigned tau = threadIdx.x;
     const unsigned t = tau >> 1, h = tau & 1u;
     const unsigned wave = tau >> 6, lane = tau & 63u;
+    stagger_block_priority();
 
     for (;;) {
         // The barrier comes BEFORE thread 0's fetch: it ends the previous window, and it keeps that window's closing
@@ -137,7 +155,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
             const unsigned ie = base + tau;
             if (tau < kFbChunk && ie < n) {
                 const float y = ey[ie];
-                sEv[tau] = make_float4(ex[ie], y, 1.0f / y, (1.5f * kLog2e) * el[ie]);
+                const float sry = __builtin_amdgcn_rsqf(y);
+                sEv[tau] = make_float4(ex[ie], y * sry, sry, (1.5f * kLog2e) * el[ie]);
             }
             __syncthreads();
             const unsigned hi = (n - base < kFbChunk) ? n - base : kFbChunk;
@@ -215,8 +234,13 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
 __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwArgs P)
 {
     __shared__ __attribute__((aligned(16))) float sTab[3][kStates];   // T0b | W1b | k0 - K0max
-    __shared__ __attribute__((aligned(16))) float sG1[2][1024];
-    __shared__ __attribute__((aligned(16))) float sG2[2][256];
+    // Successor-group sums, laid out for their READERS: thread tau needs the eight consecutive groups 8 tau .. 8 tau + 7
+    // (mod 1024 / 256).  As one array that is a 32-byte lane stride -- a 4-way bank conflict on every read, half of the
+    // kernel's LDS cycles (SQ_LDS_BANK_CONFLICT, profiles/r02_rocprof_fwbw_scaled.txt).  So members 0-3 and 4-7 of every
+    // octet live in two planes of float4: a reader takes two ds_read_b128 at a 16-byte lane stride, and the plane pitch
+    // (544 = 512 + 32, 144 = 128 + 16 words) puts the two planes of the writers' b64 / b32 stores on disjoint banks.
+    __shared__ __attribute__((aligned(16))) float sG1[2][kG1Pitch + 512];
+    __shared__ __attribute__((aligned(16))) float sG2[2][kG2Pitch + 128];
     __shared__ __attribute__((aligned(16))) float sZ[2][kThreads / 64];
     __shared__ float sRed[16];
     __shared__ __attribute__((aligned(16))) float sAcc[2][kThreads / 64][8];   // per-event sums of each wave (+ kappa), by event parity
@@ -227,6 +251,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
     const unsigned t = tau >> 1;
     const unsigned wave = tau >> 6, lane = tau & 63u;
     const unsigned j0 = tau * 8u;
+    stagger_block_priority();
 
     for (;;) {
         // The barrier comes BEFORE thread 0's fetch: it ends the previous window, and it keeps that window's closing
@@ -313,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
         const float rZ = 1.0f / P.ws_zfin[w];
         int Ib = 0;
         bool bad = false;
-        float acc_p = 0, acc_stay = 0, acc_skip = 0;
+        float acc_p = 0, acc_stay = 0, acc_p01 = 0;
 
         float4 nx_lo = *reinterpret_cast<const float4*>(rowp + j0);
         float4 nx_hi = *reinterpret_cast<const float4*>(rowp + j0 + 4);
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
                 for (int wv = 0; wv < kThreads / 64; ++wv) {
                     va += sAcc[ei & 1u][wv][th]; vb += sAcc[ei & 1u][wv][i_b]; vc += sAcc[ei & 1u][wv][0];
                 }
-                const float kappa = sAcc[ei & 1u][0][6];
+                const float kappa = sAcc[ei & 1u][0][7];
                 P.out_pm_sums[(e0 + (uint64_t)ei) * 6 + th] =
                     kappa * __builtin_fmaf(sCoef[th][0], va, __builtin_fmaf(sCoef[th][1], vb, sCoef[th][2] * vc));
             }
@@ -358,15 +383,14 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             // otherwise spills and reloads (each reload also waits for the alpha-row prefetch in flight).
             unsigned tl = tau;
             asm volatile("" : "+v"(tl));
-            const unsigned jl = tl * 8u;
             const unsigned buf = (unsigned)i & 1u;
-            const float x = nx_x, y = nx_y, ry = __builtin_amdgcn_rcpf(y);
+            const float x = nx_x, sry = __builtin_amdgcn_rsqf(nx_y), ysry = nx_y * sry;
             rowp -= kStates;
 #ifdef NCHMM_EXP_NOLOAD      // experiment only (wrong results): how much of the sweep is waiting for the alpha rows?
             nx_lo = make_float4(1e-3f, 2e-3f, 1e-3f, 3e-3f); nx_hi = nx_lo;
 #else
-            nx_lo = *reinterpret_cast<const float4*>(rowp + jl);
-            nx_hi = *reinterpret_cast<const float4*>(rowp + jl + 4);
+            nx_lo = *reinterpret_cast<const float4*>(rowp + tl * 8u);
+            nx_hi = *reinterpret_cast<const float4*>(rowp + tl * 8u + 4);
 #endif
             nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_ia = iexp[i - 1];
             // g = emission(event i) * beta_i; H1/H2 sums over consecutive successor groups (Forward_Backward.hpp:107-125)
@@ -377,22 +401,31 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const int q = 2 * pr + v;
-                    g[q] = ex2(k02[v] - xs(x, y, ry, mu[q], r2[q], eta[q], lq[q])) * bh[q];
+#ifdef NCHMM_EXP_NOEXP        // experiment only (wrong results): the transcendental's share of the dependent chain
+                    g[q] = (k02[v] - xs(x, ysry, sry, mu[q], r2[q], eta[q], lq[q])) * bh[q];
+#else
+                    g[q] = ex2(k02[v] - xs(x, ysry, sry, mu[q], r2[q], eta[q], lq[q])) * bh[q];
+#endif
                 }
             }
             const float a = (g[0] + g[1]) + (g[2] + g[3]);
             const float b = (g[4] + g[5]) + (g[6] + g[7]);
             const float s8 = a + b;
             const float s16 = s8 + swap1(s8);     // (DPP: both lanes of the pair must be active -- keep it outside the branch)
-            *reinterpret_cast<f2*>(&sG1[buf][2 * tl]) = f2{a, b};
-            if ((tl & 1u) == 0) sG2[buf][tl >> 1] = s16 * W2;
-            float z = s8;
-            wave_sum7_lane63(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], z);
-            if ((tl & 63u) == 63u) {
+            // groups 2 tl, 2 tl + 1 = octet tl >> 2, members 2 (tl & 3) + {0, 1}; group tl >> 1 = octet tl >> 4, member (tl >> 1) & 7
+            *reinterpret_cast<f2*>(&sG1[buf][((tl >> 1) & 1u) * kG1Pitch + 4u * (tl >> 2) + 2u * (tl & 1u)]) = f2{a, b};
+            if ((tl & 1u) == 0) sG2[buf][((tl >> 3) & 1u) * kG2Pitch + 4u * (tl >> 4) + ((tl >> 1) & 3u)] = s16 * W2;
+            // the six sums of the previous phase and this phase's column total: rows { ps0..ps3 } and { ps4, ps5, z, - }
+            float q0 = 0.0f, q1 = 0.0f;
+#ifndef NCHMM_EXP_NODPP      // experiment only (wrong results): the 7-way wave reduction's share
+            wave_sum7_rows(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], s8, q0, q1);
+#endif
+            if ((tl & 15u) == 0u) {      // lane 16 r files row r: sAcc[..][r] and [4 + r] (kappa takes the empty row's place)
+                const unsigned r = (tl >> 4) & 3u;
                 float* dst = &sAcc[pend_ei & 1u][tl >> 6][0];
-                *reinterpret_cast<float4*>(dst) = make_float4(ps[0], ps[1], ps[2], ps[3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(ps[4], ps[5], pend_kappa, 0.0f);
-                sZ[buf][tl >> 6] = z;
+                dst[r] = q0;
+                dst[4u + r] = r == 3u ? pend_kappa : q1;
+                if (r == 2u) sZ[buf][tl >> 6] = q1;
             }
 #ifndef NCHMM_EXP_NOBARRIER   // experiment only (wrong results): what does the per-event barrier cost?
             __syncthreads();
@@ -413,17 +446,21 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
                 bad = true;
             }
             const float al[8] = {nx_lo.x, nx_lo.y, nx_lo.z, nx_lo.w, nx_hi.x, nx_hi.y, nx_hi.z, nx_hi.w};
-            const float* ph1 = &sG1[buf][jl & 1023u];
-            const float* ph2 = &sG2[buf][jl & 255u];
+            const float* ph1 = &sG1[buf][4u * (tl & 127u)];
+            const float* ph2 = &sG2[buf][4u * (tl & 31u)];
+            const float4 h1a = *reinterpret_cast<const float4*>(ph1), h1b = *reinterpret_cast<const float4*>(ph1 + kG1Pitch);
+            const float4 h2a = *reinterpret_cast<const float4*>(ph2), h2b = *reinterpret_cast<const float4*>(ph2 + kG2Pitch);
+            const float h1s[8] = {h1a.x, h1a.y, h1a.z, h1a.w, h1b.x, h1b.y, h1b.z, h1b.w};
+            const float h2s[8] = {h2a.x, h2a.y, h2a.z, h2a.w, h2b.x, h2b.y, h2b.z, h2b.w};
 #pragma unroll
             for (int q = 0; q < 6; ++q) ps[q] = 0.0f;
-            float part_p = 0, part_stay = 0, part_skip = 0;
+            float part_p = 0, part_stay = 0, part_p01 = 0;
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 const f2 t02 = *reinterpret_cast<const f2*>(&sTab[0][tab_off(tl, pr)]);
                 const f2 w12 = *reinterpret_cast<const f2*>(&sTab[1][tab_off(tl, pr)]);
-                const f2 h1 = *reinterpret_cast<const f2*>(ph1 + 2 * pr);
-                const f2 h2 = *reinterpret_cast<const f2*>(ph2 + 2 * pr);
+                const f2 h1 = f2{h1s[2 * pr], h1s[2 * pr + 1]};
+                const f2 h2 = f2{h2s[2 * pr], h2s[2 * pr + 1]};
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const int u = 2 * pr + v;
@@ -438,28 +475,32 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
                     const float p01_b = __builtin_fminf(__builtin_fmaf(h1[v], p_step4, st_b), mbt);
                     part_p = __builtin_fmaf(al[u], mbt, part_p);
                     part_stay = __builtin_fmaf(al[u], st_b, part_stay);
-                    part_skip = __builtin_fmaf(al[u], mbt - p01_b, part_skip);
+                    part_p01 = __builtin_fmaf(al[u], p01_b, part_p01);      // skip share = p - p01 (:502-510), taken once per window
                     bh[u] = bt * sc;
                 }
             }
             acc_p = __builtin_fmaf(kappa, part_p, acc_p);
             acc_stay = __builtin_fmaf(kappa, part_stay, acc_stay);
-            acc_skip = __builtin_fmaf(kappa, part_skip, acc_skip);
+            acc_p01 = __builtin_fmaf(kappa, part_p01, acc_p01);
             pend_ei = (unsigned)(i - 1);
             pend_kappa = kappa;
         }
         {
-            float z = 0.0f;
-            wave_sum7_lane63(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], z);
-            if (lane == 63) {
+            float q0, q1;
+            wave_sum7_rows(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], 0.0f, q0, q1);
+            if ((lane & 15u) == 0u) {
+                const unsigned r = lane >> 4;
                 float* dst = &sAcc[pend_ei & 1u][wave][0];
-                *reinterpret_cast<float4*>(dst) = make_float4(ps[0], ps[1], ps[2], ps[3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(ps[4], ps[5], pend_kappa, 0.0f);
+                dst[r] = q0;
+                dst[4u + r] = r == 3u ? pend_kappa : q1;
             }
         }
         __syncthreads();
         publish(0u, tau);
         // window totals of the transition statistics
+        // every term of p - p01 is >= 0 (p01 is clamped to p cell by cell); as a difference of two window sums it can come
+        // out a rounding error below zero when nothing skips, hence the max
+        float acc_skip = __builtin_fmaxf(acc_p - acc_p01, 0.0f);
         acc_p = wave_sum(acc_p); acc_stay = wave_sum(acc_stay); acc_skip = wave_sum(acc_skip);
         __syncthreads();
         if (lane == 0) { sRed[wave] = acc_p; sRed[8 + wave] = acc_stay; }
