@@ -164,8 +164,13 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                 const float4 ev = sEv[c];
                 const unsigned i = base + c;
                 const unsigned buf = i & 1u;
-                float sc = 1.0f;
-                if (i > 0) {
+                // ONE uniform branch per event.  (Written as `i == 0 ? E : E * (...)` per state, hipcc kept eight branches in
+                // the loop body: eight serial emission chains, each LDS read waited for on its own.)
+                if (i == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)                                             // Forward_Backward.hpp:58-68
+                        ah[q] = ex2(k0[q] - xs(ev.x, ev.y, ev.z, mu[q], r2[q], eta[q], lq[q]));
+                } else {
                     // Forward_Backward.hpp:72-89: group sums of the previous column
                     const float a = (ah[0] + ah[2]) + (ah[4] + ah[6]);   // y = h
                     const float b = (ah[1] + ah[3]) + (ah[5] + ah[7]);   // y = h + 2
@@ -174,12 +179,25 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                     sG1[buf][(h << 8) | t] = a;
                     sG1[buf][((2u + h) << 8) | t] = b;
                     if (h == 0) sG2[buf][t] = s16 * W2;
+#ifdef NCHMM_EXP_FWD_NOREDUCE     // experiment only (wrong results): the column total's wave reduction
+                    const float z = s8;
+#else
                     const float z = wave_sum_lane63(s8);
+#endif
                     if (lane == 63) sZ[buf][wave] = z;
                     __syncthreads();
                     const float4 z0 = *reinterpret_cast<const float4*>(&sZ[buf][0]);
                     const float4 z1 = *reinterpret_cast<const float4*>(&sZ[buf][4]);
+                    const float* pa = &sG1[buf][r1_base];
+                    const float* pb = &sG2[buf][q_base];
+                    float in1[8], in2[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned kc = 4u * (unsigned)(q >> 1) + 2u * (unsigned)(q & 1);
+                        in1[q] = pa[kc << 6]; in2[q] = pb[kc << 4];
+                    }
                     const float Z = ((z0.x + z0.y) + (z0.z + z0.w)) + ((z1.x + z1.y) + (z1.z + z1.w));
+                    float sc = 1.0f;
                     if (Z >= kMinTotal) {
                         const int e = exponent_of(Z);
                         Ia += e;
@@ -187,18 +205,16 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                     } else {
                         bad = true;    // also NaN
                     }
-                }
-                const float* pa = &sG1[buf][r1_base];
-                const float* pb = &sG2[buf][q_base];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned kc = 4u * (unsigned)(q >> 1) + 2u * (unsigned)(q & 1);
-                    const float E = ex2(k0[q] - xs(ev.x, ev.y, ev.z, mu[q], r2[q], eta[q], lq[q]));
-                    if (i == 0) ah[q] = E;                                                   // Forward_Backward.hpp:58-68
-                    else ah[q] = E * __builtin_fmaf(W1[q], pa[kc << 6], __builtin_fmaf(T0[q], ah[q], pb[kc << 4])) * sc;
+                    for (int q = 0; q < 8; ++q) {
+                        const float E = ex2(k0[q] - xs(ev.x, ev.y, ev.z, mu[q], r2[q], eta[q], lq[q]));
+                        ah[q] = E * __builtin_fmaf(W1[q], in1[q], __builtin_fmaf(T0[q], ah[q], in2[q])) * sc;
+                    }
                 }
+#ifndef NCHMM_EXP_FWD_NOSTORE     // experiment only (the backward sweep reads garbage): what do the row stores cost the forward sweep?
 #pragma unroll
                 for (int q = 0; q < 8; ++q) rowp[jj[q]] = ah[q];
+#endif
                 rowp += kStates;
                 if (tau == 0) P.ws_exp[e0 + i] = Ia;
                 ref_sum += (double)(kmax - ev.w);

@@ -62,4 +62,5 @@ print(json.dumps({"metric": "FB+EM-statistics event-rounds/s", "value": round(to
                   "roofline": {"bound": "hbm", "bytes_per_event_round": 32780,
                                "achieved_GBs": round(32780 * total / (k_ms * 1e-3) / 1e9, 2), "peak_GBs": 8000.0,
                                "frac": round(32780 * total / (k_ms * 1e-3) / 1e9 / 8000.0, 5)},
+                  "shader_clock_mhz_under_load": round(ctx.shader_clock_mhz()),
                   "log_pr_data_mean": float(d_lpd.mean().item())}))
