@@ -35,6 +35,7 @@ using namespace fb;
 namespace {
 
 constexpr float kMinTotal = 0x1p-100f;
+constexpr unsigned kFwdG1Pitch = 72;                  // row pitch of the forward sweep's step-group sums (words)
 constexpr unsigned kG1Pitch = 544, kG2Pitch = 144;   // plane pitches of the backward sweep's group-sum arrays (words)
 constexpr int kMaxKappaExp = 100;     // |Ia + Ib - Ia_final| beyond this: forward and backward mass barely overlap
 
@@ -89,7 +90,10 @@ __device__ __forceinline__ void stagger_block_priority()
 // ================================================ forward ================================================
 __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwArgs P)
 {
-    __shared__ __attribute__((aligned(16))) float sG1[2][1024];
+    // step-group sums, 16 rows of 64 at a pitch of 72 words: the two halves of a wave (h = 0 / 1) read rows r and r + 1 at the
+    // same column and write rows 4 apart -- at a pitch of 64 both land on the same banks (SQ_LDS_BANK_CONFLICT was above
+    // SQ_ACTIVE_INST_LDS for this kernel); 72 = 64 + 8 and 4 * 72 = 288 = 4 * 64 + 32 separate them
+    __shared__ __attribute__((aligned(16))) float sG1[2][16 * kFwdG1Pitch];
     __shared__ __attribute__((aligned(16))) float sG2[2][256];
     __shared__ __attribute__((aligned(16))) float sZ[2][kThreads / 64];
     __shared__ __attribute__((aligned(16))) float4 sEv[kFbChunk];     // x, y rsq(y), rsq(y), log2e * 3 log(y) / 2
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
         for (int i = 0; i < 8; ++i) k0[i] -= kmax;
         // the skip weight c2[j] is the group weight w2[j >> 4] for every state: the producer of group t applies it
         const float W2 = ex2(P.trans[(size_t)ts * kTransFloats + kStates + 1024 + t] * kLog2e);
-        const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
+        const unsigned r1_base = kFwdG1Pitch * h + (t >> 2), q_base = (h << 4) + (t >> 4);
         int Ia = 0;
         bool bad = false;
         double ref_sum = 0.0;   // R_i of the file comment
@@ -176,8 +180,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                     const float b = (ah[1] + ah[3]) + (ah[5] + ah[7]);   // y = h + 2
                     const float s8 = a + b;
                     const float s16 = s8 + swap1(s8);     // (DPP: both lanes of the pair must be active -- keep it outside the branch)
-                    sG1[buf][(h << 8) | t] = a;
-                    sG1[buf][((2u + h) << 8) | t] = b;
+                    sG1[buf][kFwdG1Pitch * (4u * h + (t >> 6)) + (t & 63u)] = a;            // entry 256 h + t
+                    sG1[buf][kFwdG1Pitch * (4u * (2u + h) + (t >> 6)) + (t & 63u)] = b;     // entry 256 (2 + h) + t
                     if (h == 0) sG2[buf][t] = s16 * W2;
 #ifdef NCHMM_EXP_FWD_NOREDUCE     // experiment only (wrong results): the column total's wave reduction
                     const float z = s8;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const unsigned kc = 4u * (unsigned)(q >> 1) + 2u * (unsigned)(q & 1);
-                        in1[q] = pa[kc << 6]; in2[q] = pb[kc << 4];
+                        in1[q] = pa[kc * kFwdG1Pitch]; in2[q] = pb[kc << 4];     // entries 64 (h + kc) + (t >> 2), 16 (h + kc) + (t >> 4)
                     }
                     const float Z = ((z0.x + z0.y) + (z0.z + z0.w)) + ((z1.x + z1.y) + (z1.z + z1.w));
                     float sc = 1.0f;
