@@ -11,10 +11,15 @@
 // stay/step/skip-1 one (the device tables are built from (pr_skip, pr_stay)), gzip-compressed model files.
 // Extra options: --gpus N (devices to use, default all), --chunk-events N (events decoded per batch and device).
 #include <dirent.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
@@ -172,6 +177,7 @@ ValueArg<unsigned> num_threads("t", "threads", "Number of parallel threads.", fa
 ValueArg<int> gpus("", "gpus", "Number of GPUs to shard the reads over. (default: all visible)", false, 0, "int");
 ValueArg<unsigned long> chunk_events("", "chunk-events", "Events decoded per batch and GPU.", false, 32000000ul, "int");
 ValueArg<unsigned long> ed_cache_mb("", "ed-cache-mb", "Memory (MiB) in which event tables read by the summary pass are kept for the basecalling pass instead of re-reading the files.", false, 4096ul, "int");
+ValueArg<int> reader_procs("", "reader-procs", "Processes that read the input files (HDF5 serialises its calls inside one process). 0: read in this process. (default: min(threads, 16))", false, -1, "int");
 ValueArg<std::string> dump_params_fn("", "dump-params", "Write the exact (hex float) parameters and path log-probability of every basecalled strand.", false, "", "file");
 std::vector<std::string> input_fn;   // UnlabeledMultiArg "inputs"
 
@@ -379,6 +385,106 @@ template <typename F> static void host_parallel(size_t n, unsigned nt, F&& f)
     for (auto& t : th) t.join();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Reader processes.  The HDF5 library takes one global lock per call, so inside one process the event tables of 8000
+// files come in at 0.36 ms each however many threads ask (2.9 of the 4.1 s of the run recorded in
+// profiles/r02_bench_cli.json).  Separate processes do not share that lock.  K children are forked right after the
+// input list is known -- before this process creates a thread or touches the GPU, and they never do either --
+// child c reads files c, c + K, c + 2K, ... in order and streams each table down its own pipe; the parent takes file i
+// from pipe i mod K.  A full pipe blocks its child, which bounds the memory in flight.
+// ---------------------------------------------------------------------------------------------------------------
+class Reader_Procs {
+public:
+    ~Reader_Procs() { finish(); }
+    size_t size() const { return kids_.size(); }
+
+    void start(const std::vector<std::string>& files, const std::string& ed_group, unsigned k)
+    {
+        k = (unsigned)std::min<size_t>(k, files.size());
+        for (unsigned c = 0; c < k; ++c) {
+            int fd[2];
+            if (pipe(fd) != 0) break;
+#ifdef F_SETPIPE_SZ
+            (void)fcntl(fd[1], F_SETPIPE_SZ, 1 << 20);
+#endif
+            const pid_t pid = fork();
+            if (pid < 0) { close(fd[0]); close(fd[1]); break; }
+            if (pid == 0) {
+                signal(SIGPIPE, SIG_DFL);      // the parent going away ends the child at its next write
+                close(fd[0]);
+                for (const Kid& o : kids_) close(o.fd);
+                // (the stride k is fixed up front: if a later fork fails the whole pool is torn down again)
+                for (size_t i = c; i < files.size(); i += k) serve(fd[1], files[i], ed_group);
+                _exit(0);                      // no destructors, no atexit handlers of the libraries mapped here
+            }
+            close(fd[1]);
+            kids_.push_back(Kid{pid, fd[0]});
+        }
+        if (kids_.size() != k) finish();       // could not fork them all: the caller reads in-process
+    }
+
+    // table of file i; calls for one child must come in increasing i (the summary pass walks the files in order)
+    bool next(size_t i, Ed_Table& t)
+    {
+        const int fd = kids_[i % kids_.size()].fd;
+        Header h;
+        if (!read_all(fd, &h, sizeof(h))) throw Error(NCHMM_E_IO, "reader process: stream ended early");
+        std::string id(h.id_len, '\0');
+        if (h.id_len && !read_all(fd, &id[0], h.id_len)) throw Error(NCHMM_E_IO, "reader process: stream ended early");
+        t = Ed_Table();
+        t.events.resize(h.n_events);
+        if (h.n_events && !read_all(fd, t.events.data(), h.n_events * sizeof(nchmm_ed_event))) throw Error(NCHMM_E_IO, "reader process: stream ended early");
+        t.have_sampling_rate = h.have_sr != 0; t.have_events = h.have_ev != 0; t.sampling_rate = h.sampling_rate; t.read_id.swap(id);
+        return h.ok != 0;
+    }
+
+    void finish()
+    {
+        for (const Kid& k : kids_) close(k.fd);                          // a child still writing gets SIGPIPE
+        for (const Kid& k : kids_) { int st = 0; while (waitpid(k.pid, &st, 0) < 0 && errno == EINTR) {} }
+        kids_.clear();
+    }
+
+private:
+    struct Kid { pid_t pid; int fd; };
+    struct Header { uint8_t ok, have_sr, have_ev, pad; uint32_t id_len; double sampling_rate; uint64_t n_events; };
+    std::vector<Kid> kids_;
+
+    static bool read_all(int fd, void* p, size_t n)
+    {
+        char* c = static_cast<char*>(p);
+        while (n) {
+            const ssize_t r = read(fd, c, n);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) return false;
+            c += r; n -= (size_t)r;
+        }
+        return true;
+    }
+    static void write_all(int fd, const void* p, size_t n)
+    {
+        const char* c = static_cast<const char*>(p);
+        while (n) {
+            const ssize_t r = write(fd, c, n);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) _exit(1);
+            c += r; n -= (size_t)r;
+        }
+    }
+    static void serve(int fd, const std::string& fn, const std::string& ed_group)
+    {
+        Ed_Table t;
+        Header h{};
+        try { t = read_ed_table(fn, ed_group); h.ok = 1; }
+        catch (...) { t = Ed_Table(); h.ok = 0; }      // the parent's summarize() re-reads the file and reports the error
+        h.have_sr = t.have_sampling_rate; h.have_ev = t.have_events; h.sampling_rate = t.sampling_rate;
+        h.id_len = (uint32_t)t.read_id.size(); h.n_events = t.events.size();
+        write_all(fd, &h, sizeof(h));
+        write_all(fd, t.read_id.data(), h.id_len);
+        write_all(fd, t.events.data(), t.events.size() * sizeof(nchmm_ed_event));
+    }
+};
+
 // how far the summary pass has got: reads [0, ready) are summarised (the decode loop runs behind it)
 struct Read_Progress {
     std::mutex m;
@@ -393,7 +499,7 @@ struct Read_Progress {
 };
 
 static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, std::deque<Fast5_Summary_Type>& reads,
-                       Read_Progress& progress)
+                       Read_Progress& progress, Reader_Procs& readers)
 {
     // The reference summarises file after file on one thread (nanocall.cpp:263-273).  Here one thread reads the event
     // tables (HDF5 serialises its calls; from many threads the same reads take 3-4x longer) a block of files ahead, and
@@ -407,7 +513,10 @@ static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::
         tab.assign(b1 - b0, Ed_Table());
         ok.assign(b1 - b0, 0);
         for (size_t i = b0; i < b1; ++i) {
-            try { tab[i - b0] = read_ed_table(fv[i], Fast5_Summary_Type::eventdetection_group()); ok[i - b0] = 1; }
+            try {
+                if (readers.size()) ok[i - b0] = readers.next(i, tab[i - b0]) ? 1 : 0;
+                else { tab[i - b0] = read_ed_table(fv[i], Fast5_Summary_Type::eventdetection_group()); ok[i - b0] = 1; }
+            }
             catch (const Error&) { ok[i - b0] = 0; }   // summarize() re-reads it and reports the error as the reference does
         }
     };
@@ -683,6 +792,17 @@ static int real_main()
     { STAGE("init_models_s"); init_models(models); }
     init_transitions(default_transitions);
     { STAGE("init_files_s"); init_files(files); }
+    // reader processes: forked here, while this process is still single-threaded and has not touched the GPU
+    Reader_Procs readers;
+    {
+        int k = opts::reader_procs.get();
+        if (k < 0) k = files.size() >= 64 ? (int)std::min<unsigned>(opts::num_threads, 16u) : 0;
+        if (k > 1) {
+            const std::vector<std::string> fv(files.begin(), files.end());
+            readers.start(fv, Fast5_Summary_Type::eventdetection_group(), (unsigned)k);
+        }
+        LOG(info) << "reader_procs=" << readers.size() << std::endl;
+    }
     // devices: one context + host thread per GPU
     int n_dev = 0;
     if (nchmm_device_count(&n_dev) != NCHMM_OK || n_dev < 1) {
@@ -719,7 +839,7 @@ static int real_main()
     // the summary pass (init_reads) runs on its own threads; the decode loop follows it block by block
     reads.resize(files.size());
     Read_Progress progress;
-    std::thread summary_pass([&] { STAGE("init_reads_s"); init_reads(models, files, reads, progress); });
+    std::thread summary_pass([&] { STAGE("init_reads_s"); init_reads(models, files, reads, progress, readers); });
     try {
         if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters, progress); }
     } catch (...) {

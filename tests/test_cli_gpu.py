@@ -212,6 +212,33 @@ def test_two_contexts_shard_the_reads_and_gather_counters(tmp_path):
     assert "gathered_by=rccl_allreduce" in c4 and pick(c4, "events_decoded") == pick(c1, "events_decoded")
 
 
+def test_reader_processes_give_the_same_output(tmp_path):
+    """--reader-procs K: K forked children read the event tables (file i from child i mod K) and stream them to the
+    summary pass.  Same FASTA and --stats as the in-process reader, with more children than some have files, an
+    unreadable file in the list, FAST5 and text tables mixed, and the default (>= 64 inputs: on)."""
+    names = ["r73_2d_a", "r73_1d_b", "r73_short_c", "r73_2d_e", "r9_2d_d"]
+    files = [os.path.join(G, n + ".fast5") for n in names] + [os.path.join(G, "r73_2d_a.events")]
+    bad = tmp_path / "broken.fast5"
+    bad.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)          # HDF5 signature, nothing behind it
+    fofn = tmp_path / "reads.fofn"
+    fofn.write_text("".join(f + "\n" for f in files[:3]) + str(bad) + "\n" + "".join(f + "\n" for f in files[3:]))
+    base = ["--pore", "r73", "--no-train", "--log", "info", str(fofn)]
+    ref = run_cli(base + ["--reader-procs", "0", "--stats", str(tmp_path / "s0.tsv")])
+    assert "reader_procs=0" in ref.stderr and ref.stdout.count(">") >= 8
+    for k in (2, 3, 16):
+        got = run_cli(base + ["--reader-procs", str(k), "--stats", str(tmp_path / f"s{k}.tsv")])
+        assert f"reader_procs={min(k, 6)}" in got.stderr        # never more children than files (the broken one is not a valid input)
+        assert got.stdout == ref.stdout, k
+        assert (tmp_path / f"s{k}.tsv").read_text() == (tmp_path / "s0.tsv").read_text(), k
+    # default: on from 64 inputs (min(threads, 16) children)
+    many = tmp_path / "many.fofn"
+    many.write_text("".join(files[i % 5] + "\n" for i in range(70)))
+    a = run_cli(["--pore", "r73", "--no-train", "--log", "info", "-t", "4", str(many)])
+    b = run_cli(["--pore", "r73", "--no-train", "--log", "info", "-t", "4", "--reader-procs", "0", str(many)])
+    assert "reader_procs=4" in a.stderr and "reader_procs=0" in b.stderr
+    assert a.stdout == b.stdout and a.stdout.count(">") == 98     # 14 x (2 + 1 + 0 + 2 + 2) records
+
+
 def test_option_errors_and_help():
     assert "Required argument missing" in run_cli([], expect_rc=1).stderr
     assert "unknown pore type" in run_cli(["--pore", "r10", os.path.join(G, "r73_1d_b.fast5")], expect_rc=1).stderr
