@@ -267,21 +267,31 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     if (read_preferred) {
         for (size_t i = 0; i < 3 * n_reads; ++i) read_preferred[i] = -1;
         if (o->scaling_select_threshold < std::numeric_limits<float>::infinity()) {
+            // the jobs of each read, in job order (a scan of every job for every read is quadratic: 8000 reads x 16 000 jobs)
+            std::vector<uint32_t> first(n_reads + 1, 0), by_read(n_jobs);
+            for (size_t k = 0; k < n_jobs; ++k) if ((size_t)jobs[k].read < n_reads) ++first[(size_t)jobs[k].read + 1];
+            for (size_t r = 0; r < n_reads; ++r) first[r + 1] += first[r];
+            {
+                std::vector<uint32_t> fill(first.begin(), first.end() - 1);
+                for (size_t k = 0; k < n_jobs; ++k) if ((size_t)jobs[k].read < n_reads) by_read[fill[(size_t)jobs[k].read]++] = (uint32_t)k;
+            }
             for (size_t r = 0; r < n_reads; ++r)
                 for (int kind = 0; kind < 3; ++kind) {
                     long best = -1;
-                    for (size_t k = 0; k < n_jobs; ++k) {
+                    for (uint32_t q = first[r]; q < first[r + 1]; ++q) {
+                        const size_t k = by_read[q];
                         const Job& j = jobs[k];
                         const int jk = (j.m[0] >= 0 && j.m[1] >= 0) ? 2 : (j.m[0] >= 0 ? 0 : 1);
-                        if ((size_t)j.read != r || jk != kind || j.win.empty()) continue;
+                        if (jk != kind || j.win.empty()) continue;
                         if (best < 0 || j.fit > jobs[best].fit) best = (long)k;   // first maximum
                     }
                     if (best < 0) continue;
                     bool unique = true;
-                    for (size_t k = 0; k < n_jobs && unique; ++k) {
+                    for (uint32_t q = first[r]; q < first[r + 1] && unique; ++q) {
+                        const size_t k = by_read[q];
                         const Job& j = jobs[k];
                         const int jk = (j.m[0] >= 0 && j.m[1] >= 0) ? 2 : (j.m[0] >= 0 ? 0 : 1);
-                        if ((size_t)j.read != r || jk != kind || j.win.empty() || (long)k == best) continue;
+                        if (jk != kind || j.win.empty() || (long)k == best) continue;
                         if (!(j.fit + o->scaling_select_threshold < jobs[best].fit)) unique = false;
                     }
                     if (unique) read_preferred[3 * r + kind] = (int32_t)best;
