@@ -52,6 +52,12 @@ __device__ __forceinline__ float xs(float x, float ysry, float sry, float mu, fl
     return __builtin_fmaf(dx * dx, r2, dyp * dyp * lq);
 }
 
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p)
+{
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ float block_max(float v, float* sRed, unsigned wave, unsigned lane)
 {
     v = wave_max(v);
@@ -412,7 +418,10 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             nx_lo = *reinterpret_cast<const float4*>(rowp + tl * 8u);
             nx_hi = *reinterpret_cast<const float4*>(rowp + tl * 8u + 4);
 #endif
-            nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_ia = iexp[i - 1];
+            // wave-uniform addresses in memory no kernel writes while this one runs: read through the scalar cache, so that the
+            // vector-memory counter tracks the alpha rows alone (a vector load issued after them would make its first use wait
+            // for the rows as well)
+            nx_x = uniform_load(ex + (i - 1)); nx_y = uniform_load(ey + (i - 1)); nx_ia = uniform_load(iexp + (i - 1));
             // g = emission(event i) * beta_i; H1/H2 sums over consecutive successor groups (Forward_Backward.hpp:107-125)
             float g[8];
 #pragma unroll
@@ -447,6 +456,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
                 dst[4u + r] = r == 3u ? pend_kappa : q1;
                 if (r == 2u) sZ[buf][tl >> 6] = q1;
             }
+            asm volatile("" :: "s"(nx_ia));     // the scalar load must have landed by here (hipcc otherwise sinks it to its use
+                                                // right after the barrier, where its latency is exposed)
 #ifndef NCHMM_EXP_NOBARRIER   // experiment only (wrong results): what does the per-event barrier cost?
             __syncthreads();
 #endif
