@@ -801,7 +801,12 @@ static int real_main()
             const std::vector<std::string> fv(files.begin(), files.end());
             readers.start(fv, Fast5_Summary_Type::eventdetection_group(), (unsigned)k);
         }
-        LOG(info) << "reader_procs=" << readers.size() << std::endl;
+        unsigned n_threads = 0;      // fork() is only safe here because this process is still single-threaded: say so in the log
+        if (DIR* d = opendir("/proc/self/task")) {
+            while (const dirent* e = readdir(d)) if (e->d_name[0] != '.') ++n_threads;
+            closedir(d);
+        }
+        LOG(info) << "reader_procs=" << readers.size() << " threads_at_fork=" << n_threads << std::endl;
     }
     // devices: one context + host thread per GPU
     int n_dev = 0;

@@ -235,7 +235,7 @@ def test_reader_processes_give_the_same_output(tmp_path):
     many.write_text("".join(files[i % 5] + "\n" for i in range(70)))
     a = run_cli(["--pore", "r73", "--no-train", "--log", "info", "-t", "4", str(many)])
     b = run_cli(["--pore", "r73", "--no-train", "--log", "info", "-t", "4", "--reader-procs", "0", str(many)])
-    assert "reader_procs=4" in a.stderr and "reader_procs=0" in b.stderr
+    assert "reader_procs=4 threads_at_fork=1" in a.stderr and "reader_procs=0" in b.stderr     # forked while single-threaded
     assert a.stdout == b.stdout and a.stdout.count(">") == 98     # 14 x (2 + 1 + 0 + 2 + 2) records
 
 
