@@ -1,4 +1,4 @@
-// asan_host.cpp -- the host half of the C ABI (nchmm_host.cpp: no HIP) under AddressSanitizer + UBSan, edge sizes included.
+// asan_host.cpp -- the host half of the C ABI (nchmm_host.cpp, nchmm_reads.cpp: no HIP) under AddressSanitizer + UBSan, edge sizes included.
 // GPU sanitizers are not available on the pool, so this is the sanitized build the device-free code gets:
 //   make -C tools asan-host   (tests/test_host_prep.py::test_host_abi_under_sanitizers runs it)
 #include <cstdio>
@@ -27,4 +27,26 @@ int main(){
     if(nchmm_train_pm_finish(n,sums.data(),mean.data(),sd.data(),nullptr,0,crt,np_,&done)) return 11;
     std::vector<float> z(6*n,0.f); if(nchmm_train_pm_finish(n,z.data(),mean.data(),sd.data(),start.data(),1,crt,np_,&done)) return 12; printf("singular done=%d\n",done);
     float st3[12]={-1,-2,-3,-1,-2,-3,-1,-2,-3,-1,-2,-3}, ps,pk; if(nchmm_train_st_finish(4,st3,&ps,&pk)) return 13; if(nchmm_train_st_finish(0,nullptr,&ps,&pk)) return 14; }
+  // read summary (nchmm_reads.cpp): empty / tiny / ordinary 2D / no hairpin / all-abasic tables, both presets, --1d, trims larger than the read
+  for (const char* pore : {"r73", "r9"}) for (unsigned one_d : {0u, 1u}) for (size_t n : {0ul, 1ul, 9ul, 60ul, 400ul, 3000ul}) for (int shape = 0; shape < 4; ++shape) {
+    nchmm_segment_opts so; if (nchmm_segment_opts_default(&so, pore)) return 20; so.template_only = one_d;
+    if (shape == 3) { so.trim_margins[0] = so.trim_margins[1] = 5000; so.max_ed_events = 100; }
+    std::vector<nchmm_ed_event> ed(n); int64_t at = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const bool hp = shape == 0 && n >= 400 && i >= n / 2 && i < n / 2 + 12;   // a hairpin island of abasic-level events in the middle
+      const double lvl = shape == 2 ? 130.0 : (hp ? 125.0 + u(rng) : 55.0 + 30.0 * u(rng));
+      ed[i].mean = lvl; ed[i].stdv = (i % 53 == 0) ? 0.0 : 0.8 + u(rng); ed[i].start = at; ed[i].length = 3 + (int64_t)(rng() % 40); at += ed[i].length; }
+    nchmm_read_summary rs; if (nchmm_read_summarize(&so, n, ed.data(), 4000.f, 1, &rs)) return 21;
+    if (rs.num_ed_events > n) return 22;
+    for (int st = 0; st < 2; ++st) {
+      const size_t cap = rs.strand_bounds[2 * st + 1] >= rs.strand_bounds[2 * st] ? rs.strand_bounds[2 * st + 1] - rs.strand_bounds[2 * st] : 0;
+      std::vector<float> m(cap + 1), sd(cap + 1), stt(cap + 1), len(cap + 1); size_t got = 0;
+      if (rs.num_ed_events && nchmm_read_load_events(&rs, ed.data(), 4000.f, st, m.data(), sd.data(), stt.data(), len.data(), &got)) return 23;
+      if (got > cap) return 24;
+      float mean = 0, stdv = 0; if (nchmm_mean_stdv(got, m.data(), &mean, &stdv)) return 25; }
+  }
+  { float sc, sh; const float r0[2] = {70.f, 9.f}, r1[2] = {68.f, 10.f}, m0[2] = {66.f, 11.f}, m1[2] = {65.f, 12.f}, z[2] = {0.f, 0.f};
+    if (nchmm_initial_scaling(1, r0, r1, m0, m1, &sc, &sh)) return 26; if (nchmm_initial_scaling(0, r0, nullptr, m0, nullptr, &sc, &sh)) return 27;
+    (void)nchmm_initial_scaling(0, z, nullptr, z, nullptr, &sc, &sh);   // degenerate: must not trap
+    float mean, stdv; if (nchmm_mean_stdv(0, nullptr, &mean, &stdv)) return 28; if (nchmm_mean_stdv(1, r0, &mean, &stdv)) return 29; }
   puts("host ABI under ASan/UBSan: ok"); return 0; }
