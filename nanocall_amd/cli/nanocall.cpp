@@ -418,24 +418,30 @@ public:
                 _exit(0);                      // no destructors, no atexit handlers of the libraries mapped here
             }
             close(fd[1]);
-            kids_.push_back(Kid{pid, fd[0]});
+            kids_.push_back(Kid{pid, fd[0], false});
         }
         if (kids_.size() != k) finish();       // could not fork them all: the caller reads in-process
     }
 
     // table of file i; calls for one child must come in increasing i (the summary pass walks the files in order)
-    bool next(size_t i, Ed_Table& t)
+    enum Got { table_ok, table_failed, child_died_here, child_gone };
+    Got next(size_t i, Ed_Table& t)
     {
-        const int fd = kids_[i % kids_.size()].fd;
+        Kid& kid = kids_[i % kids_.size()];
+        if (kid.dead) return child_gone;
         Header h;
-        if (!read_all(fd, &h, sizeof(h))) throw Error(NCHMM_E_IO, "reader process: stream ended early");
-        std::string id(h.id_len, '\0');
-        if (h.id_len && !read_all(fd, &id[0], h.id_len)) throw Error(NCHMM_E_IO, "reader process: stream ended early");
+        std::string id;
         t = Ed_Table();
-        t.events.resize(h.n_events);
-        if (h.n_events && !read_all(fd, t.events.data(), h.n_events * sizeof(nchmm_ed_event))) throw Error(NCHMM_E_IO, "reader process: stream ended early");
+        bool got = read_all(kid.fd, &h, sizeof(h));
+        if (got) { id.assign(h.id_len, '\0'); got = !h.id_len || read_all(kid.fd, &id[0], h.id_len); }
+        if (got) { t.events.resize(h.n_events); got = !h.n_events || read_all(kid.fd, t.events.data(), h.n_events * sizeof(nchmm_ed_event)); }
+        if (!got) {      // the stream ended inside this file's record: the child died reading it (libhdf5 on a corrupt file)
+            kid.dead = true;
+            t = Ed_Table();
+            return child_died_here;
+        }
         t.have_sampling_rate = h.have_sr != 0; t.have_events = h.have_ev != 0; t.sampling_rate = h.sampling_rate; t.read_id.swap(id);
-        return h.ok != 0;
+        return h.ok ? table_ok : table_failed;
     }
 
     void finish()
@@ -446,7 +452,7 @@ public:
     }
 
 private:
-    struct Kid { pid_t pid; int fd; };
+    struct Kid { pid_t pid; int fd; bool dead = false; };
     struct Header { uint8_t ok, have_sr, have_ev, pad; uint32_t id_len; double sampling_rate; uint64_t n_events; };
     std::vector<Kid> kids_;
 
@@ -475,6 +481,8 @@ private:
     {
         Ed_Table t;
         Header h{};
+        if (const char* e = std::getenv("NANOCALL_TEST_READER_ABORT"))      // test hook: a file that takes its reader down
+            if (*e && fn.find(e) != std::string::npos) abort();
         try { t = read_ed_table(fn, ed_group); h.ok = 1; }
         catch (...) { t = Ed_Table(); h.ok = 0; }      // the parent's summarize() re-reads the file and reports the error
         h.have_sr = t.have_sampling_rate; h.have_ev = t.have_events; h.sampling_rate = t.sampling_rate;
@@ -514,8 +522,19 @@ static void init_reads(const Pore_Model_Dict_Type& models, const std::list<std::
         ok.assign(b1 - b0, 0);
         for (size_t i = b0; i < b1; ++i) {
             try {
-                if (readers.size()) ok[i - b0] = readers.next(i, tab[i - b0]) ? 1 : 0;
-                else { tab[i - b0] = read_ed_table(fv[i], Fast5_Summary_Type::eventdetection_group()); ok[i - b0] = 1; }
+                Reader_Procs::Got got = readers.size() ? readers.next(i, tab[i - b0]) : Reader_Procs::child_gone;
+                if (got == Reader_Procs::child_gone) {      // no reader processes, or this file's child is no more
+                    tab[i - b0] = read_ed_table(fv[i], Fast5_Summary_Type::eventdetection_group());
+                    got = Reader_Procs::table_ok;
+                }
+                if (got == Reader_Procs::child_died_here) {
+                    // the file took its reader process down: it is NOT opened again in this process (which holds the GPUs);
+                    // the empty table makes summarize() skip the read
+                    LOG(warning) << fv[i] << ": the reader process died on this file; read skipped" << std::endl;
+                    ok[i - b0] = 1;
+                } else {
+                    ok[i - b0] = got == Reader_Procs::table_ok ? 1 : 0;
+                }
             }
             catch (const Error&) { ok[i - b0] = 0; }   // summarize() re-reads it and reports the error as the reference does
         }

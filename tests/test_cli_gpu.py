@@ -239,6 +239,25 @@ def test_reader_processes_give_the_same_output(tmp_path):
     assert a.stdout == b.stdout and a.stdout.count(">") == 98     # 14 x (2 + 1 + 0 + 2 + 2) records
 
 
+def test_a_file_that_kills_its_reader_process_is_skipped_not_reopened(tmp_path):
+    """libhdf5 can crash on a corrupt file.  With reader processes that costs one child: the file is skipped
+    with a warning and never opened in the process that holds the GPU, the dead child's later files are read in-process,
+    everything else is unchanged.  (NANOCALL_TEST_READER_ABORT makes a child abort on a file name, as such a crash would.)"""
+    import shutil
+    names = ["r73_2d_a", "r73_1d_b", "r73_2d_e", "r73_2d_a", "r73_2d_e"]
+    files = []
+    for k, n in enumerate(names):
+        dst = tmp_path / (f"killer_{k}.fast5" if k == 1 else f"read_{k}.fast5")
+        shutil.copy(os.path.join(G, n + ".fast5"), dst)
+        files.append(str(dst))
+    base = ["--pore", "r73", "--no-train", "--log", "info"]
+    want = run_cli(base + ["--reader-procs", "0"] + [f for k, f in enumerate(files) if k != 1])
+    got = run_cli(base + ["--reader-procs", "2"] + files, env={"NANOCALL_TEST_READER_ABORT": "killer_"})
+    assert got.stdout == want.stdout and got.stdout.count(">") == 8
+    assert "killer_1.fast5: the reader process died on this file; read skipped" in got.stderr
+    assert "reader_procs=2" in got.stderr
+
+
 def test_option_errors_and_help():
     assert "Required argument missing" in run_cli([], expect_rc=1).stderr
     assert "unknown pore type" in run_cli(["--pore", "r10", os.path.join(G, "r73_1d_b.fast5")], expect_rc=1).stderr
