@@ -546,7 +546,9 @@ int nchmm_put_transitions_fast(nchmm_ctx* c, int first_slot, size_t n, const flo
     void* hp = nullptr;
     if ((rc = pinned(c, sizeof(float) * 64 * n, &hp))) return rc;
     float* const wm = (float*)hp;
-    for (size_t k = 0; k < n; ++k) mask_weights(p_skip[k], p_stay[k], wm + 64 * k);
+    // ~100 pow / log calls per slot: worth the host cores when an EM round brings thousands of (job, strand) tables
+    if (n >= 256) parallel_for(n, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) mask_weights(p_skip[k], p_stay[k], wm + 64 * k); });
+    else for (size_t k = 0; k < n; ++k) mask_weights(p_skip[k], p_stay[k], wm + 64 * k);
     void* dp = c->d_tab_stage;
     rc = ensure(c, &dp, &c->tab_stage_bytes, sizeof(float) * 64 * n);
     c->d_tab_stage = dp;
