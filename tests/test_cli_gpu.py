@@ -239,6 +239,18 @@ def test_reader_processes_give_the_same_output(tmp_path):
     assert a.stdout == b.stdout and a.stdout.count(">") == 98     # 14 x (2 + 1 + 0 + 2 + 2) records
 
 
+def test_fofn_from_stdin_and_duplicate_inputs():
+    """`-` reads the list of file names from standard input (nanocall.cpp:233-257); a file named twice is two reads."""
+    names = ["r73_2d_a", "r73_1d_b", "r73_2d_a"]
+    files = [os.path.join(G, n + ".fast5") for n in names]
+    want = run_cli(["--pore", "r73", "--no-train"] + files).stdout
+    e = dict(os.environ)
+    p = subprocess.run([CLI, "--pore", "r73", "--no-train", "-"], input="".join(f + "\n" for f in files), capture_output=True, text=True,
+                       env=e, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout == want and want.count(">") == 5
+
+
 def test_a_file_that_kills_its_reader_process_is_skipped_not_reopened(tmp_path):
     """libhdf5 can crash on a corrupt file.  With reader processes that costs one child: the file is skipped
     with a warning and never opened in the process that holds the GPU, the dead child's later files are read in-process,
