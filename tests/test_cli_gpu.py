@@ -239,6 +239,54 @@ def test_reader_processes_give_the_same_output(tmp_path):
     assert a.stdout == b.stdout and a.stdout.count(">") == 98     # 14 x (2 + 1 + 0 + 2 + 2) records
 
 
+def test_no_train_random_ragged_reads_byte_identical_over_batches_and_contexts(tmp_path):
+    """Thirty synthetic reads of random shape (1D and 2D, 120 to 5000 events per strand, both complement models, random affine
+    distortion) as event tables: the FASTA of `nanocall --no-train` must equal the oracle pipeline's byte for byte, with the
+    reads cut into many small batches, sharded over two contexts, and with reader processes on and off."""
+    rng = np.random.default_rng(20261002)
+    inputs = []
+    for k in range(30):
+        two_d = rng.random() < 0.7
+        nt = int(rng.integers(120, 5000))
+        nc = int(rng.integers(120, 5000)) if two_d else 0
+        ed = op.synth_ed_table("r73", nt, nc, seed=100 + k, hairpin=int(rng.integers(6, 20)),
+                               complement_model=("r73.c.p2.006.ont.model" if rng.random() < 0.5 else None),
+                               scale=float(rng.uniform(0.93, 1.08)), shift=float(rng.uniform(-5, 5)), drift=float(rng.uniform(-0.01, 0.01)))
+        rid = f"rnd-{k}" if k % 3 else None
+        path = tmp_path / f"rnd_{k}.events"
+        op.write_events_table(str(path), ed, 4000.0, rid)
+        inputs.append((str(path), dict(sampling_rate=4000.0, read_id=rid or "", events=ed)))
+    exp, reads, recs = op.run(op.Opts(pore="r73", train=False), inputs)
+    assert len(recs) >= 35
+    files = [i[0] for i in inputs]
+    base = ["--pore", "r73", "--no-train"]
+    assert run_cli(base + files).stdout == exp
+    assert run_cli(base + ["--chunk-events", "9000", "--reader-procs", "3"] + files, env={"NANOCALL_DEVICE_IDS": "0,0"}).stdout == exp
+    assert run_cli(base + ["--chunk-events", "2500", "-t", "8", "--reader-procs", "0"] + files).stdout == exp
+
+
+def test_trained_random_reads_teacher_forced_byte_identical(tmp_path):
+    """Twelve random 1D / 2D reads through the default pipeline (EM of both model pairs, selection, decode): whatever
+    parameters and models the EM arrived at (--dump-params), the oracle decoding with exactly those must give the same
+    FASTA byte for byte and the same path log-probabilities bit for bit."""
+    rng = np.random.default_rng(77)
+    inputs = []
+    for k in range(12):
+        two_d = k % 4 != 3
+        ed = op.synth_ed_table("r73", int(rng.integers(400, 2500)), int(rng.integers(400, 2500)) if two_d else 0, seed=300 + k,
+                               hairpin=int(rng.integers(6, 16)), complement_model=("r73.c.p2.006.ont.model" if k % 2 else None),
+                               scale=float(rng.uniform(0.94, 1.07)), shift=float(rng.uniform(-4, 4)), drift=float(rng.uniform(-0.008, 0.008)))
+        path = tmp_path / f"tr_{k}.events"
+        op.write_events_table(str(path), ed, 4000.0, f"tr-{k}")
+        inputs.append((str(path), dict(sampling_rate=4000.0, read_id=f"tr-{k}", events=ed)))
+    dump = tmp_path / "params.tsv"
+    p = run_cli(["--pore", "r73", "-t", "4", "--chunk-events", "7000", "--dump-params", str(dump)] + [i[0] for i in inputs])
+    d = op.read_dump(str(dump))
+    assert len(d) >= 12
+    recs = check_teacher_forced(op.Opts(pore="r73"), inputs, p.stdout, d)
+    assert len(recs) == len(d)
+
+
 def test_fofn_from_stdin_and_duplicate_inputs():
     """`-` reads the list of file names from standard input (nanocall.cpp:233-257); a file named twice is two reads."""
     names = ["r73_2d_a", "r73_1d_b", "r73_2d_a"]
