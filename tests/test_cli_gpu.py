@@ -299,6 +299,38 @@ def test_fofn_from_stdin_and_duplicate_inputs():
     assert p.stdout == want and want.count(">") == 5
 
 
+def test_validity_pass_over_many_inputs_runs_in_child_processes(tmp_path):
+    """From 256 candidates on, the is_valid_file pass over a directory / fofn / argument list is spread over forked children.
+    Same file list (order, ignored entries) and output as the in-process check."""
+    names = ["r73_2d_a", "r73_1d_b", "r73_short_c", "r73_2d_e"]
+    d = tmp_path / "reads"
+    d.mkdir()
+    lines = []
+    for k in range(300):
+        if k % 37 == 5:
+            p = d / f"junk_{k:03d}.txt"
+            p.write_text("not a read\n")
+        else:
+            p = d / f"read_{k:03d}.fast5"
+            os.symlink(os.path.join(G, names[k % 4] + ".fast5"), p)
+        lines.append(str(p))
+    fofn = tmp_path / "reads.fofn"
+    fofn.write_text("".join(l + "\n" for l in lines))
+    base = ["--pore", "r73", "--no-train", "--log", "info", "-t", "4"]
+    a = run_cli(base + [str(fofn)])
+    b = run_cli(base + ["--reader-procs", "0", str(fofn)])
+    added = lambda p: [l for l in p.stderr.splitlines() if "adding input file" in l]
+    n_junk = sum(1 for k in range(300) if k % 37 == 5)
+    assert a.stdout == b.stdout and added(a) == added(b) and len(added(a)) == 300 - n_junk
+    # a candidate that kills the child checking it: ignored with a warning, everything else as before
+    e = run_cli(base + [str(fofn)], env={"NANOCALL_TEST_VALIDATE_ABORT": "read_123.fast5"})
+    assert "read_123.fast5: the process checking this file died; file ignored" in e.stderr
+    assert [l for l in added(e)] == [l for l in added(a) if "read_123.fast5" not in l]
+    c = run_cli(base + [str(d)])                       # the directory itself: readdir order, compare as sets
+    assert split_fasta(c.stdout).keys() == split_fasta(a.stdout).keys()
+    assert sum("ignoring file" in l for l in c.stderr.splitlines()) == n_junk
+
+
 def test_a_file_that_kills_its_reader_process_is_skipped_not_reopened(tmp_path):
     """libhdf5 can crash on a corrupt file.  With reader processes that costs one child: the file is skipped
     with a warning and never opened in the process that holds the GPU, the dead child's later files are read in-process,
