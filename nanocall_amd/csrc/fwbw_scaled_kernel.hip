@@ -77,20 +77,6 @@ __device__ __forceinline__ void flag_window(const FwbwArgs& P, unsigned w)
     atomicAdd(P.fb_total, 1ull);
 }
 
-
-// Two blocks share a CU, two waves of each on every SIMD.  Each block alternates a VALU-bound phase with a wait (the
-// LDS exchange behind its per-event barrier, the alpha-row load), and with equal priorities the issue arbiter keeps the
-// two in step: both compute at half speed, then both wait.  Measured on the backward sweep: one block per CU 1.70 us per
-// event, two blocks 2.91 us per event EACH -- the second block bought 17 %.  A fixed priority order takes them out of
-// step: the first block runs as if alone and the second fills its waits (the queue gives the faster block more windows).
-__device__ __forceinline__ void stagger_block_priority()
-{
-#ifndef NCHMM_FB_NO_PRIO
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave slot [3:0]
-    if (((hw & 15u) >> 1) & 1u) __builtin_amdgcn_s_setprio(0);       // the block in wave slots 2,3 of each SIMD
-    else __builtin_amdgcn_s_setprio(3);
-#endif
-}
 }  // namespace
 
 // ================================================ forward ================================================
@@ -109,7 +95,6 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
     const unsigned tau = threadIdx.x;
     const unsigned t = tau >> 1, h = tau & 1u;
     const unsigned wave = tau >> 6, lane = tau & 63u;
-    stagger_block_priority();
 
     for (;;) {
         // The barrier comes BEFORE thread 0's fetch: it ends the previous window, and it keeps that window's closing
@@ -277,7 +262,6 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
     const unsigned t = tau >> 1;
     const unsigned wave = tau >> 6, lane = tau & 63u;
     const unsigned j0 = tau * 8u;
-    stagger_block_priority();
 
     for (;;) {
         // The barrier comes BEFORE thread 0's fetch: it ends the previous window, and it keeps that window's closing
