@@ -300,3 +300,34 @@ def test_unreachable_state_off_the_true_path_is_not_an_error(r73t):
     assert np.array_equal(states, ostates)
     assert_bits_equal(logp, ologp, "path probability")
     assert not np.isin(states, np.arange(16) * 256).any()
+
+
+def test_contexts_give_their_device_memory_back(r73t):
+    """A long-running host creates and destroys contexts (one per worker, per batch of work): every byte a context
+    allocated -- tables, staging, the back-pointer and alpha-row workspaces, the FB scratch -- must be free again after
+    nchmm_destroy, whatever the context did in between (Viterbi, raw-event Viterbi, forward-backward with sub-batching)."""
+    import torch
+    from nanocall_amd import synth
+    ev = synth.generate(r73t, 24, 700)
+    off, mean, stdv, start = synth.flat_batch(ev)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    src, ln = off[:-1].astype(np.uint64), np.diff(off).astype(np.uint32)
+    woff = (np.arange(25) * 100).astype(np.uint64)
+
+    def cycle():
+        ctx = na.Context(0)
+        ctx.put_model(0, na.scaled_model_table(r73t))
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        ctx.viterbi(off, cm, sd, ls)
+        ctx.viterbi_raw(mean, stdv, start, src, ln, np.zeros(24, np.float32))
+        ctx.fwbw(woff, cm[:2400], sd[:2400], ls[:2400], st_params=np.tile(np.float32([0.1, 0.3]), (24, 1)))
+        ctx.close()
+
+    cycle()                                     # first use pays for the runtime's own pools
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (32 << 20), f"{(free0 - free1) >> 20} MiB of device memory not returned after 12 create/destroy cycles"
