@@ -330,7 +330,11 @@ def main():
     dt = time.perf_counter() - t0
     # the hot kernels are VALU-issue bound, so their duration follows the shader clock -- and the boxes of one pool do not
     # all sustain the same clock (the same binary: 15.8 ms and 23.2 ms per launch on two boxes).  Probe it while still hot.
-    sclk_mhz = ctx.shader_clock_mhz()
+    try:
+        sclk_mhz = ctx.shader_clock_mhz()
+    except Exception as e:          # a diagnostic must not cost the run its line
+        sys.stderr.write(f"bench.py: shader clock probe failed: {e}\n")
+        sclk_mhz = float("nan")
     red_dev = dev if (world > 1 and not share_gpu0) else None      # gloo reduces host tensors
     dt = shard.max_over_ranks(dt, red_dev)
     local_counters = ctx.counters()
@@ -369,7 +373,7 @@ def main():
                        "grid_slots": ctx.grid_slots(), "forward_launches_per_step": launches_per_step,
                        "host_generation_s": round(t_gen, 1)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
-            "device": {"shader_clock_mhz_under_load": round(sclk_mhz, 0), "peak_shader_clock_mhz": round(SCLK_GHZ * 1e3, 0),
+            "device": {"shader_clock_mhz_under_load": (round(sclk_mhz, 0) if sclk_mhz == sclk_mhz else None), "peak_shader_clock_mhz": round(SCLK_GHZ * 1e3, 0),
                        "note": "rank 0, ~3 ms full-chip VALU probe right after the timed region (nchmm_shader_clock_mhz)"},
         }
         if events_per_launch:
@@ -414,7 +418,11 @@ def main():
             base["value"] = round(base["value"], 5)
             result["cpu_baseline"] = base
         if world == 1 and not args.no_fwbw:
-            result["fwbw"] = fwbw_leg(ctx, dev, max(3, args.steps))
+            try:
+                result["fwbw"] = fwbw_leg(ctx, dev, max(3, args.steps))
+            except Exception as e:      # the secondary leg must not cost the run its headline line
+                sys.stderr.write(f"bench.py: forward-backward leg failed: {e}\n")
+                result["fwbw"] = {"error": str(e)}
         print(json.dumps(result), flush=True)
     ctx.close()
     if world > 1:
