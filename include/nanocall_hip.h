@@ -418,6 +418,12 @@ typedef struct nchmm_pool nchmm_pool;
 
 int nchmm_device_count(int* n);   /* HIP devices visible to this process (0 and NCHMM_E_NO_DEVICE when none) */
 
+/* Free / total device memory of one GPU in bytes (hipMemGetInfo), asked through the library's own HIP runtime, after
+ * the device has drained.  What a long-running host checks the ownership contract with: the reference's DP object frees
+ * its matrix on scope exit (src/nanocall/Viterbi.hpp:50 -- a std::vector member), so every byte a context allocated
+ * must be free again after nchmm_destroy. */
+int nchmm_device_mem_info(int device_id, uint64_t* free_bytes, uint64_t* total_bytes);
+
 /* device_ids NULL = 0 .. n_devices-1.  An id may repeat (several contexts on one GPU: the host-thread / sharding logic
  * can then be exercised on a single-GPU machine; the counter reduction then runs on the host instead of RCCL). */
 int nchmm_pool_create(nchmm_pool** out, int n_devices, const int* device_ids);

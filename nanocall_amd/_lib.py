@@ -77,6 +77,7 @@ SIGNATURES = {
     "nchmm_profile_blocks": (C.c_int, [vp, vp]),
     "nchmm_grid_slots": (C.c_int, [vp, vp]),
     "nchmm_device_count": (C.c_int, [vp]),
+    "nchmm_device_mem_info": (C.c_int, [C.c_int, vp, vp]),
     "nchmm_pool_create": (C.c_int, [C.POINTER(vp), C.c_int, vp]),
     "nchmm_pool_destroy": (C.c_int, [vp]),
     "nchmm_pool_size": (C.c_int, [vp]),
@@ -124,14 +125,45 @@ class NchmmError(RuntimeError):
         super().__init__(f"{where}: {msg} (code {code})")
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  libnanocall_hip.so needs `libamdhip64.so.7` (found in /opt/rocm/lib); torch's
+    libtorch_hip.so needs `libamdhip64.so` (no version suffix) and finds its OWN bundled copy through its $ORIGIN
+    rpath.  The dynamic loader tells libraries apart by the name they were asked for and by file identity, so if the
+    product is loaded first the process ends up with two runtimes and the second one finds no GPU
+    ("RuntimeError: No HIP GPUs are available" from torch.cuda, round-2 GPUTEST).  Torch's copy carries the SONAME
+    libamdhip64.so.7, so mapping it first, globally, satisfies both: the product's NEEDED entry matches the loaded
+    SONAME, and torch later re-opens the same file.  Without torch installed (the C++ command line, a C host) nothing
+    happens and the product uses /opt/rocm's runtime.  NANOCALL_HIP_RUNTIME=system skips this."""
+    if os.environ.get("NANOCALL_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")     # locates the package without importing it
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
+_hip_runtime = None
+
+
 def lib():
     """Load the shared library (once).  Raises if it has not been built -- no fallback."""
-    global _lib
+    global _lib, _hip_runtime
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C nanocall_amd/csrc). nanocall_amd has no CPU/PyTorch fallback.")
+        _hip_runtime = _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the ABI and this table ever diverge

@@ -498,6 +498,13 @@ def device_count():
     return n.value
 
 
+def device_mem_info(device_id=0):
+    """nchmm_device_mem_info -> (free, total) bytes of one GPU, through the library's own HIP runtime."""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    check(lib().nchmm_device_mem_info(int(device_id), C.byref(f), C.byref(t)), "nchmm_device_mem_info")
+    return f.value, t.value
+
+
 def lpt_partition(weights, n_shards):
     """nchmm_lpt_partition -> shard index per item (int32)."""
     w = np.ascontiguousarray(weights, np.uint64)

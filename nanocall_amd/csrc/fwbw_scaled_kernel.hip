@@ -174,11 +174,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                     sG1[buf][kFwdG1Pitch * (4u * h + (t >> 6)) + (t & 63u)] = a;            // entry 256 h + t
                     sG1[buf][kFwdG1Pitch * (4u * (2u + h) + (t >> 6)) + (t & 63u)] = b;     // entry 256 (2 + h) + t
                     if (h == 0) sG2[buf][t] = s16 * W2;
-#ifdef NCHMM_EXP_FWD_NOREDUCE     // experiment only (wrong results): the column total's wave reduction
-                    const float z = s8;
-#else
                     const float z = wave_sum_lane63(s8);
-#endif
                     if (lane == 63) sZ[buf][wave] = z;
                     __syncthreads();
                     const float4 z0 = *reinterpret_cast<const float4*>(&sZ[buf][0]);
@@ -206,10 +202,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                         ah[q] = E * __builtin_fmaf(W1[q], in1[q], __builtin_fmaf(T0[q], ah[q], in2[q])) * sc;
                     }
                 }
-#ifndef NCHMM_EXP_FWD_NOSTORE     // experiment only (the backward sweep reads garbage): what do the row stores cost the forward sweep?
 #pragma unroll
                 for (int q = 0; q < 8; ++q) rowp[jj[q]] = ah[q];
-#endif
                 rowp += kStates;
                 if (tau == 0) P.ws_exp[e0 + i] = Ia;
                 ref_sum += (double)(kmax - ev.w);
@@ -396,12 +390,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             const unsigned buf = (unsigned)i & 1u;
             const float x = nx_x, sry = __builtin_amdgcn_rsqf(nx_y), ysry = nx_y * sry;
             rowp -= kStates;
-#ifdef NCHMM_EXP_NOLOAD      // experiment only (wrong results): how much of the sweep is waiting for the alpha rows?
-            nx_lo = make_float4(1e-3f, 2e-3f, 1e-3f, 3e-3f); nx_hi = nx_lo;
-#else
             nx_lo = *reinterpret_cast<const float4*>(rowp + tl * 8u);
             nx_hi = *reinterpret_cast<const float4*>(rowp + tl * 8u + 4);
-#endif
             // wave-uniform addresses in memory no kernel writes while this one runs: read through the scalar cache, so that the
             // vector-memory counter tracks the alpha rows alone (a vector load issued after them would make its first use wait
             // for the rows as well)
@@ -414,11 +404,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const int q = 2 * pr + v;
-#ifdef NCHMM_EXP_NOEXP        // experiment only (wrong results): the transcendental's share of the dependent chain
-                    g[q] = (k02[v] - xs(x, ysry, sry, mu[q], r2[q], eta[q], lq[q])) * bh[q];
-#else
                     g[q] = ex2(k02[v] - xs(x, ysry, sry, mu[q], r2[q], eta[q], lq[q])) * bh[q];
-#endif
                 }
             }
             const float a = (g[0] + g[1]) + (g[2] + g[3]);
@@ -430,9 +416,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             if ((tl & 1u) == 0) sG2[buf][((tl >> 3) & 1u) * kG2Pitch + 4u * (tl >> 4) + ((tl >> 1) & 3u)] = s16 * W2;
             // the six sums of the previous phase and this phase's column total: rows { ps0..ps3 } and { ps4, ps5, z, - }
             float q0 = 0.0f, q1 = 0.0f;
-#ifndef NCHMM_EXP_NODPP      // experiment only (wrong results): the 7-way wave reduction's share
             wave_sum7_rows(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], s8, q0, q1);
-#endif
             if ((tl & 15u) == 0u) {      // lane 16 r files row r: sAcc[..][r] and [4 + r] (kappa takes the empty row's place)
                 const unsigned r = (tl >> 4) & 3u;
                 float* dst = &sAcc[pend_ei & 1u][tl >> 6][0];
@@ -442,9 +426,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             }
             asm volatile("" :: "s"(nx_ia));     // the scalar load must have landed by here (hipcc otherwise sinks it to its use
                                                 // right after the barrier, where its latency is exposed)
-#ifndef NCHMM_EXP_NOBARRIER   // experiment only (wrong results): what does the per-event barrier cost?
             __syncthreads();
-#endif
             publish((unsigned)i, tl);    // the barrier made every wave's sums of event i visible
             const float4 z0 = *reinterpret_cast<const float4*>(&sZ[buf][0]);
             const float4 z1 = *reinterpret_cast<const float4*>(&sZ[buf][4]);

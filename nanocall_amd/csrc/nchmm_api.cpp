@@ -1108,7 +1108,7 @@ int em_round_range(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const ui
     g.mean = ev; g.stdv = ev + stride; g.start = ev + 2 * stride; g.lstdv = ev + 3 * stride;
     g.win_src = (const uint64_t*)(d + o_src); g.off = (const uint64_t*)(d + o_off); g.win_drift = (const float*)(d + o_dr);
     g.cmean = (float*)(d + o_cm); g.out_stdv = (float*)(d + o_sd); g.out_lstdv = (float*)(d + o_ls);
-    launch_em_gather(g, (unsigned)n_win, s);
+    launch_em_gather(g, (unsigned)n_win, s, (unsigned)max_events);
     HIP_TRY(c, hipGetLastError());
     rc = nchmm_fwbw_dev(c, n_win, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
                         (const float*)(d + o_ls), scaled_slot ? (const int32_t*)(d + o_ss) : nullptr,

@@ -152,7 +152,7 @@ struct EmReduceArgs {
     int train_drift;
     double* out;                     // [n_jobs][13]
 };
-void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream, unsigned max_events = 0);
+void launch_em_gather(const EmGatherArgs& a, unsigned n_win, hipStream_t stream, unsigned max_events);
 void launch_logf(const float* in, float* out, size_t n, hipStream_t stream);
 void launch_em_reduce(const EmReduceArgs& a, unsigned n_jobs, hipStream_t stream);
 void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream, bool scaled);

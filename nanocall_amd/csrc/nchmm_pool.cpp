@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <limits>
 #include <numeric>
 #include <set>
 #include <thread>
@@ -190,6 +191,25 @@ int nchmm_device_count(int* n)
     return NCHMM_OK;
 }
 
+int nchmm_device_mem_info(int device_id, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes) return NCHMM_E_INVALID;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return NCHMM_E_NO_DEVICE;
+    if (device_id < 0 || device_id >= c) return NCHMM_E_INVALID;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    size_t f = 0, t = 0;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemGetInfo(&f, &t);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return NCHMM_E_HIP;
+    *free_bytes = (uint64_t)f;
+    *total_bytes = (uint64_t)t;
+    return NCHMM_OK;
+}
+
 int nchmm_lpt_partition(size_t n_items, const uint64_t* weight, int n_shards, int32_t* shard_of_item)
 {
     if (n_shards < 1 || (n_items && (!weight || !shard_of_item))) return NCHMM_E_INVALID;
@@ -332,9 +352,17 @@ int nchmm_pool_basecall_reads(nchmm_pool* pool, const nchmm_train_opts* o, size_
                     pref[3 * i + q] = (int32_t)(it - s.jobs.begin());
                 }
         }
-        const int r = nchmm_basecall_reads(pool->ctx[d], o, n_models, model_states, nr, s.strand_off.data(), s.mean.data(), s.stdv.data(),
-                                           s.start.data(), nj, s.job_read.data(), s.job_m0.data(), s.job_m1.data(), pm.data(), st.data(),
-                                           read_preferred ? pref.data() : nullptr, states.data(), best.data(), logp.data());
+        int r = NCHMM_OK;
+        if (nj) {
+            r = nchmm_basecall_reads(pool->ctx[d], o, n_models, model_states, nr, s.strand_off.data(), s.mean.data(), s.stdv.data(),
+                                     s.start.data(), nj, s.job_read.data(), s.job_m0.data(), s.job_m1.data(), pm.data(), st.data(),
+                                     read_preferred ? pref.data() : nullptr, states.data(), best.data(), logp.data());
+        } else {
+            // a shard whose reads all fell under min_ed_events has reads but no jobs (and then empty, i.e. null, job arrays):
+            // nothing to decode -- report what the single-context call reports for a read without candidates
+            std::fill(best.begin(), best.end(), -1);
+            std::fill(logp.begin(), logp.end(), std::numeric_limits<float>::quiet_NaN());
+        }
         if (r != NCHMM_OK && r != NCHMM_E_NUMERIC) return r;
         for (size_t i = 0; i < nr; ++i) {
             const size_t g = s.reads[i];

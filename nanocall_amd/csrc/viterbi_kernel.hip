@@ -185,18 +185,6 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
     float m4[2]; unsigned x4[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {            // y = 2g + h, members i = 2x + g
-#ifdef NCHMM_SCAN_MAX3
-        // the maximum first (two ops), then the FIRST member equal to it: the ascending strict-> scan of the reference
-        // names exactly that one.  (NaN members never equal the maximum; an all-NaN group names member 3, which cannot
-        // matter: see below.)
-        const float a0 = S.alpha[g], a1 = S.alpha[2 + g], a2 = S.alpha[4 + g], a3 = S.alpha[6 + g];
-        const float bv = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3);
-        const mask_t e0 = ballot(a0 == bv), e1 = ballot(a1 == bv), e2 = ballot(a2 == bv);
-        unsigned bx;
-        asm("v_cndmask_b32_e64 %0, 3, 2, %1" : "=v"(bx) : "s"(e2));
-        asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(bx) : "v"(bx), "s"(e1));
-        bx = selm_zero(e0, bx);
-#else
         // starting from member 0 instead of -INF saves one compare-select; the results differ only
         // if member 0 is NaN while another member is not, which needs a NaN emission for some
         // states but not others -- no finite model/event does that (and an all-NaN column is
@@ -209,7 +197,6 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
             bv = selm(m, v, bv);
             bx = selm(m, (unsigned)xx, bx);
         }
-#endif
         m4[g] = bv; x4[g] = bx;
     }
     // own half of the skip group: k = 4x + y
@@ -260,9 +247,7 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
     sV1[(h << 8) | t] = ValSlot{s1[0], sl1[0]};
     sV1[((2u + h) << 8) | t] = ValSlot{s1[1], sl1[1]};
     if (h == 0) sV2[t] = ValSlot{s2, sl2};
-#ifndef NCHMM_EXP_NOBARRIER   // experiment only (wrong results): what does the per-event barrier cost?
     __syncthreads();
-#endif
 
     // ---------------- 3-way combine per state ----------------
     const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
@@ -312,17 +297,10 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
                                            S.reta[i], S.lam[i], cc_[u]);
             S.alpha[i] = best + e;
             bpw[c] |= slot << (8 * u);
-#ifdef NCHMM_SCHED_FENCE
-            if ((u & (NCHMM_SCHED_FENCE - 1)) == NCHMM_SCHED_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     }
     const unsigned w_lo = bpw[0], w_hi = bpw[1];
-#ifdef NCHMM_EXP_NOSTORE      // experiment only (no traceback possible): what do the back-pointer stores cost?
-    if (w_lo == 0x12345678u) *reinterpret_cast<uint2*>(bp_row + tau * 8u) = make_uint2(w_lo, w_hi);
-#else
     *reinterpret_cast<uint2*>(bp_row + tau * 8u) = make_uint2(w_lo, w_hi);
-#endif
 }
 
 __device__ __forceinline__ bool event_in_fast_range(float x, float y)

@@ -458,6 +458,39 @@ def test_em_round_edge_shapes(gpu_ctx, r73t):
     assert only["acc"].shape == (0, 13) and np.array_equal(only["log_pr_data"], ref["log_pr_data"][:3])
 
 
+def test_em_round_windows_longer_than_one_gather_chunk(gpu_ctx, r73t):
+    """em_gather_kernel covers a window in 4096-event chunks (blockIdx.y); nchmm_em_round has to launch enough of them
+    for its LONGEST window (--scaling-num-events above 8192 gives such windows).  A 9000-event and a 4097-event window
+    next to a short one, with a non-zero drift so that stale staging memory cannot pass for gathered events: identical
+    log-likelihoods / transition sums to nchmm_fwbw on host-gathered events, outer sums equal to the host finish."""
+    from nanocall_amd import api
+    ev = synth.generate(r73t, 1, 14000, first_read=9)
+    mean, stdv, start = ev["mean"][0], ev["stdv"][0], ev["start"][0]
+    _, stdv, lsd = na.events_prepare(mean, stdv, None, 0.0)
+    pm = np.float32([1.0, 0.1, 0.003, 1.0, 1.0, 1.0])
+    gpu_ctx.put_model(52, na.scaled_model_table(r73t, pm))
+    gpu_ctx.put_transitions(52, *na.transitions_fast(0.3, 0.1))
+    gpu_ctx.em_load_events(mean, stdv, start, lsd)
+    src, ln = [0, 9000, 13200], [9000, 4097, 100]
+    n_win = len(src)
+    stp = np.tile(np.float32([0.1, 0.3]), (n_win, 1))
+    # poison the staging area with a first round over other events, so an ungathered tail is visibly wrong
+    gpu_ctx.em_round([100, 200, 300], ln, np.zeros(n_win, np.float32), pm, np.full(n_win, 52), np.full(n_win, 52), stp, [0, 3])
+    got = gpu_ctx.em_round(src, ln, np.full(n_win, pm[2]), pm, np.full(n_win, 52), np.full(n_win, 52), stp, [0, 1, 2, 3])
+    off = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+    idx = np.concatenate([np.arange(b, b + n) for b, n in zip(src, ln)])
+    cm = np.concatenate([na.events_prepare(mean[b:b + n], stdv[b:b + n], start[b:b + n], float(pm[2]))[0] for b, n in zip(src, ln)])
+    ref = gpu_ctx.fwbw(off, cm, stdv[idx], lsd[idx], scaled_slot=np.full(n_win, 52), pm_params=pm, trans_slot=np.full(n_win, 52), st_params=stp)
+    assert np.array_equal(got["log_pr_data"], ref["log_pr_data"])
+    assert np.array_equal(got["st_sums"], ref["st_sums"])
+    for w in range(n_win):
+        a, b = int(off[w]), int(off[w + 1])
+        exp, exp_done = na.train_pm_finish(ref["pm_sums"][a:b], mean[idx[a:b]], stdv[idx[a:b]], start[idx[a:b]], pm, train_drift=True)
+        new, done = api.train_pm_solve(b - a, got["acc"][w], pm, train_drift=True)
+        assert done == exp_done
+        assert np.allclose(new, exp, rtol=1e-6, atol=1e-9), (w, new, exp)
+
+
 def test_forward_backward_budget_cuts_batches_into_ranges(r73t):
     """nchmm_fwbw / nchmm_em_round with an alpha-row budget far below the batch (NCHMM_FB_BUDGET_MB=16: 1024 events per
     launch): the batch runs as consecutive window (job) ranges through one workspace and returns exactly what the

@@ -143,3 +143,32 @@ def test_basecall_reads_picks_best_model_and_matches_oracle(gpu_ctx):
     out2 = gpu_ctx.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st, preferred=pref)
     assert out2["best_job"].tolist() == [[0, 0], [2, -1]]
     assert np.array_equal(out2["states"][0:600], exp[(0, 0)][0])
+
+
+def test_pool_shard_with_reads_but_no_jobs(gpu_ctx):
+    """Two contexts on device 0 (the sharding logic on a one-GPU box): the second read is too short to have a candidate, so
+    its shard has a read and NO job.  The pool must neither fail (null job arrays) nor leave that read's results unset: it
+    reports what the single-context call reports -- best_job -1, best_logp NaN -- and decodes the other shard as before."""
+    opts = api.train_opts()
+    names = ["r73.c.p1", "r73.c.p2", "r73.t"]
+    tables = [na.builtin_model(n) for n in names]
+    states10 = np.stack([na.model_load(t) for t in tables])
+    e0 = synth.generate(tables[2], 1, 500, first_read=810)
+    e1 = synth.generate(tables[2], 1, 30, first_read=811)
+    mean = np.concatenate([e0["mean"][0], e1["mean"][0]])
+    stdv = np.concatenate([e0["stdv"][0], e1["stdv"][0]])
+    start = np.concatenate([e0["start"][0], e1["start"][0]])
+    so = np.array([0, 500, 500, 530, 530], np.uint64)
+    jr, j0, j1 = np.int32([0]), np.int32([2]), np.int32([-1])        # read 1 has no candidate at all
+    pm = np.float32([[1, 0, 0, 1, 1, 1]])
+    st = np.float32([[0.1, 0.3, 0.1, 0.3]])
+    one = gpu_ctx.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st)
+    with api.Pool([0, 0]) as pool:
+        assert len(pool) == 2
+        two = pool.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st)
+        tr = pool.train_reads(opts, states10, so, mean, stdv, start, jr, j0, j1)
+    assert two["best_job"].tolist() == one["best_job"].tolist() == [[0, -1], [-1, -1]]
+    assert np.array_equal(two["states"][:500], one["states"][:500])
+    assert two["best_logp"][0, 0].tobytes() == one["best_logp"][0, 0].tobytes()
+    assert np.isnan(two["best_logp"][1]).all() and np.isnan(two["best_logp"][0, 1])
+    assert tr["rounds"].shape == (1,) and tr["rounds"][0] >= 1

@@ -2,6 +2,8 @@
 
 Contract (BASELINE.json north_star): called k-mer path bit-exact; Viterbi log-likelihood within
 1e-4 relative -- we hold it to bit-identical, which is stronger."""
+import os
+
 import numpy as np
 import pytest
 
@@ -305,8 +307,10 @@ def test_unreachable_state_off_the_true_path_is_not_an_error(r73t):
 def test_contexts_give_their_device_memory_back(r73t):
     """A long-running host creates and destroys contexts (one per worker, per batch of work): every byte a context
     allocated -- tables, staging, the back-pointer and alpha-row workspaces, the FB scratch -- must be free again after
-    nchmm_destroy, whatever the context did in between (Viterbi, raw-event Viterbi, forward-backward with sub-batching)."""
-    import torch
+    nchmm_destroy, whatever the context did in between (Viterbi, raw-event Viterbi, forward-backward with sub-batching).
+    The reference's DP objects own their matrix and free it on scope exit (Viterbi.hpp:50, SURVEY 8b "ownership").
+    Device memory is asked through the library itself (nchmm_device_mem_info = hipMemGetInfo in the library's runtime):
+    no second HIP runtime is involved."""
     from nanocall_amd import synth
     ev = synth.generate(r73t, 24, 700)
     off, mean, stdv, start = synth.flat_batch(ev)
@@ -324,10 +328,61 @@ def test_contexts_give_their_device_memory_back(r73t):
         ctx.close()
 
     cycle()                                     # first use pays for the runtime's own pools
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info(0)[0]
+    free0, total = na.device_mem_info(0)
+    assert 0 < free0 <= total
     for _ in range(12):
         cycle()
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info(0)[0]
+    free1, _ = na.device_mem_info(0)
     assert free0 - free1 < (32 << 20), f"{(free0 - free1) >> 20} MiB of device memory not returned after 12 create/destroy cycles"
+
+
+_ORDER_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+assert "torch" not in sys.modules
+import nanocall_amd as na
+from nanocall_amd import synth
+assert "torch" not in sys.modules, "the binding must not import torch by itself"
+table = na.builtin_model("r73.t")
+ev = synth.generate(table, 4, 300)
+off, mean, stdv, start = synth.flat_batch(ev)
+cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+ctx = na.Context(0)                              # the product initialises HIP BEFORE torch is imported
+ctx.put_model(0, na.scaled_model_table(table))
+ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+states, logp, status = ctx.viterbi(off, cm, sd, ls)
+import torch
+torch.cuda.synchronize()                         # round 2: "RuntimeError: No HIP GPUs are available" here
+assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+d_off, d_cm, d_sd, d_ls = t(off.astype(np.int64)), t(cm), t(sd), t(ls)
+d_state = torch.empty(int(off[-1]), dtype=torch.int16, device=dev)
+d_logp = torch.empty(4, dtype=torch.float32, device=dev)
+d_status = torch.empty(4, dtype=torch.int32, device=dev)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.viterbi_dev(4, 300, int(off[-1]), d_off, d_cm, d_sd, d_ls, d_state, d_logp, d_status)
+torch.cuda.synchronize()
+assert np.array_equal(d_state.cpu().numpy().view(np.uint16), states)
+assert d_logp.cpu().numpy().tobytes() == logp.tobytes()
+maps = open("/proc/self/maps").read()
+runtimes = sorted({l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l})
+assert len(runtimes) == 1, runtimes
+ctx.close()
+print("ok", runtimes[0])
+"""
+
+
+def test_product_before_torch_shares_one_hip_runtime(tmp_path):
+    """A host that creates a Context before it ever touches torch.cuda must still be able to use torch afterwards (the
+    *_dev entry points take torch tensors): one HIP runtime per process, whichever library is loaded first
+    (nanocall_amd/_lib.py: _share_torch_hip_runtime).  Run in a fresh interpreter because the order is the point."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "order_child.py"
+    script.write_text(_ORDER_CHILD)
+    p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.strip().startswith("ok"), p.stdout

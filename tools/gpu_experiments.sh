@@ -34,10 +34,13 @@ PY
 }
 case "${1:-}" in
 stalls)
+  # the experiment switches live in patches, not in the kernel sources (they build wrong-result kernels)
+  (cd nanocall_amd/csrc && patch -p0 < ../../tools/ubench/exp_switches_viterbi.patch && patch -p0 < ../../tools/ubench/exp_switches_fwbw_scaled.patch) || exit 1
   variant base ""
   variant noload "-DNCHMM_EXP_NOLOAD"
   variant nobarrier "-DNCHMM_EXP_NOBARRIER"
   variant nostore "-DNCHMM_EXP_NOSTORE"
+  (cd nanocall_amd/csrc && patch -R -p0 < ../../tools/ubench/exp_switches_viterbi.patch && patch -R -p0 < ../../tools/ubench/exp_switches_fwbw_scaled.patch)
   make -C nanocall_amd/csrc clean > /dev/null; make -C nanocall_amd/csrc -j16 > /dev/null 2>&1 ;;
 budgets)
   for mb in 0 65536 32768 16384 8192; do
