@@ -10,6 +10,11 @@
           per shard exceed the workspace budget, so a step is several forward+traceback launches.
           When the script is started directly (no RANK in the environment) it launches its N ranks itself
           (python -m torch.distributed.run) BEFORE touching the GPU, and fails if fewer than N GPUs are visible.
+  --scaling strong : BASELINE config 4 AS WRITTEN at every N -- the same 100 000 reads x 5 000 events split N ways by
+          lpt_partition (N = 1 decodes all 100 000 on one GPU, sub-batched through the back-pointer workspace), so that
+          value(N) / value(1) is the strong-scaling curve north_star asks for ("scaling": "strong").  --reads then
+          means the GLOBAL read count.  The default stays weak (per-GPU work fixed), which is what the driver's
+          N = 1 / 2 / 4 / 8 runs without extra flags measure.
 
 A "step" is one full pass of the hot path over the batch: forward sweep + back-pointer streaming + traceback
 for every read, inputs already resident in HBM.  Rank 0 prints ONE JSON line; at N = 1 it also carries
@@ -37,6 +42,7 @@ FB_BYTES_PER_EVENT_ROUND = 32780   # 16 384 B alpha written + 16 384 B alpha rea
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 SCLK_GHZ = 2.4               # same guide: peak engine clock
 C4_READS_PER_GPU = 12500     # BASELINE config 4: 100 000 reads over 8 GPUs
+C4_TOTAL_READS = 100000
 
 
 def kernel_source_hash():
@@ -44,6 +50,14 @@ def kernel_source_hash():
     cannot outlive the kernel they were measured on."""
     h = hashlib.sha256()
     for f in ("viterbi_kernel.hip", "nchmm_device.h"):
+        h.update(open(os.path.join(ROOT, "nanocall_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def fb_kernel_source_hash():
+    """the same for the forward-backward kernels the `fwbw` leg times"""
+    h = hashlib.sha256()
+    for f in ("fwbw_scaled_kernel.hip", "fwbw_common.hpp", "nchmm_device.h"):
         h.update(open(os.path.join(ROOT, "nanocall_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -73,15 +87,15 @@ def physical_cores():
     return len(usable), (len(cores) or len(usable))
 
 
-def cpu_baseline(table, n_events, threads, reads_per_thread=4):
+def cpu_baseline(table, n_events, threads, n_reads):
     """Time the CPU oracle (port of the reference's Viterbi, reference memory layout) on a bounded sample of the
-    same workload, read-parallel like the reference's pfor (one read per worker at a time)."""
+    same workload, read-parallel like the reference's pfor (one read per worker at a time): `threads` workers
+    (default: one per PHYSICAL core of the host) share `n_reads` reads; T = 1 beside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nc_oracle as oracle
     import nanocall_amd as na
     from nanocall_amd import synth
 
-    n_reads = reads_per_thread * threads
     ev = synth.generate(table, n_reads, n_events)
     om = oracle.Model(table, (1.0, 0.0, 0.0, 1.0, 1.0, 1.0))
     ot = oracle.Transitions(0.3, 0.1)
@@ -105,9 +119,10 @@ def cpu_baseline(table, n_events, threads, reads_per_thread=4):
     logical, physical = physical_cores()
     return dict(value=n_reads * n_events / dt / 1e6, unit="Mevents/s", cores=threads, kind="port",
                 host_logical_cpus=logical, host_physical_cores=physical,
-                sample=f"{n_reads} reads x {n_events} events of the same synthetic workload, {threads} read-parallel threads "
-                       f"(one per usable logical CPU, {physical} physical cores), oracle/nc_oracle.c (reference matrix "
-                       f"layout), {dt:.1f} s wall = {dt * threads:.0f} CPU-seconds",
+                sample=f"{n_reads} reads x {n_events} events of the same synthetic workload on {threads} read-parallel threads "
+                       f"(host: {logical} usable logical CPUs, {physical} physical cores; {-(-n_reads // threads)} read(s) per thread), "
+                       f"oracle/nc_oracle.c (reference matrix layout, 8 B per cell), {dt:.1f} s wall = {dt * threads:.0f} CPU-seconds; "
+                       f"single_thread_value = 2 of those reads on one thread, {dt1:.1f} s",
                 single_thread_value=round(min(2, n_reads) * n_events / dt1 / 1e6, 5)), results, prepped
 
 
@@ -122,7 +137,21 @@ def committed_pmc(n_reads, n_events):
         except Exception:
             continue
         if t.get("workload") == {"reads": n_reads, "events": n_events} and t.get("kernel_source_sha256_16") == kernel_source_hash():
-            best = t
+            best = dict(t, _file=os.path.relpath(f, ROOT))
+    return best
+
+
+def committed_pmc_fb(n_win, n_events):
+    """the FB kernels' PMC figures (profiles/*hbm_traffic_fwbw*.json), same keying"""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_fwbw*.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == {"windows": n_win, "events": n_events} and t.get("kernel_source_sha256_16") == fb_kernel_source_hash():
+            best = dict(t, _file=os.path.relpath(f, ROOT))
     return best
 
 
@@ -154,6 +183,31 @@ def generate_shard(table, read_ids, n_events, threads):
         list(ex.map(work, chunks))
     off = np.arange(n + 1, dtype=np.uint64) * np.uint64(n_events)
     return off, mean.reshape(-1), stdv.reshape(-1), start.reshape(-1)
+
+
+def end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, reps):
+    """SURVEY 8d's second figure: the same batch through the HOST-pointer entry point (nchmm_viterbi: pageable host arrays in,
+    H2D of 12 B/event, forward + traceback kernels, D2H of 2 B/event + 4 B/read, host arrays out), wall clock around the
+    call.  Never the headline `value`; output compared with the device-resident run of the timed region."""
+    import torch
+    n_reads = off.shape[0] - 1
+    total = int(off[-1])
+    ctx.viterbi(off, cm, sd, ls)                 # first call sizes the library's staging buffers
+    wall = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        states, logp, status = ctx.viterbi(off, cm, sd, ls)
+        wall.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    assert (status == 0).all()
+    assert np.array_equal(states, d_state.cpu().numpy().view(np.uint16)), "host-pointer path decodes differently"
+    assert logp.tobytes() == d_logp.cpu().numpy().tobytes()
+    ms = float(np.median(wall)) * 1e3
+    return {"metric": "Mevents/s Viterbi, host pointers in and out (PCIe inclusive)", "value": round(total / ms / 1e3, 3), "unit": "Mevents/s",
+            "ms_per_call": round(ms, 3), "calls": reps,
+            "path": "nchmm_viterbi: pageable host SoA events -> H2D -> viterbi_kernel + traceback_kernel -> D2H -> host states / log-probs",
+            "pcie_bytes_per_call": int(12 * total + 8 * (n_reads + 1) + 2 * total + 8 * n_reads),
+            "identical_to_device_resident_run": True}
 
 
 def fwbw_leg(ctx, dev, steps):
@@ -199,11 +253,20 @@ def fwbw_leg(ctx, dev, steps):
     achieved = FB_BYTES_PER_EVENT_ROUND * total / (k_ms * 1e-3) / 1e9
     lpd = d_lpd.cpu().numpy()
     assert np.isfinite(lpd).all()
+    traffic, traffic_src = None, None
+    pmc = committed_pmc_fb(n_win, n_ev)
+    if pmc:
+        # FETCH_SIZE counts the backward sweep's 16-byte-per-lane streaming row reads at half their bytes on gfx950
+        # (MI355X_MICROARCH.md, HBM section): doubled here, as that guide prescribes; writes as reported
+        traffic = int(sum((2.0 * k.get("FETCH_SIZE_KiB", 0.0) + k.get("WRITE_SIZE_KiB", 0.0)) * 1024
+                          for name, k in pmc.items() if name.startswith("fwbw_") and isinstance(k, dict)))
+        traffic_src = pmc["_file"]
     return {"metric": "FB + EM-statistics event-rounds/s", "value": round(total * steps / dt / 1e6, 3), "unit": "Mevent-rounds/s",
             "workload": "4096 windows x 100 events (config-3 shape: 1024 2D reads x 2 strands x 2 windows), r73.t / r73.c.p1",
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_source_sha256_16": fb_kernel_source_hash(),
                          "kernel": "nchmm::fwbw_forward_scaled_kernel + nchmm::fwbw_backward_scaled_kernel",
                          "kernel_ms": round(k_ms, 3), "bytes_per_event_round": FB_BYTES_PER_EVENT_ROUND,
                          "event_rounds_per_launch": total},
@@ -236,7 +299,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 1024 at N=1 = config 2, 12500 at N>1 = config-4 shard)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 1024 at N=1 = config 2, 12500 at N>1 = config-4 shard); "
+                                                          "with --scaling strong: reads in total (default 100000 = config 4)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: per-GPU work fixed (default).  strong: BASELINE config 4 as written, the same 100 000 reads split over N")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--events", type=int, default=5000, help="events per read")
     ap.add_argument("--model", default="r73.t")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -282,12 +349,18 @@ def main():
 
     table = na.builtin_model(args.model)
     n_events = args.events
-    reads_per_gpu = args.reads or (1024 if world == 1 else C4_READS_PER_GPU)
+    strong = args.scaling == "strong"
+    if strong:
+        global_reads = args.reads or C4_TOTAL_READS
+        reads_per_gpu = -(-global_reads // world)          # nominal (LPT gives every rank floor or ceil of it)
+    else:
+        reads_per_gpu = args.reads or (1024 if world == 1 else C4_READS_PER_GPU)
+        global_reads = reads_per_gpu * world
     # the global read set and its partition: every rank computes the same LPT assignment and takes its own shard
-    global_lengths = np.full(reads_per_gpu * world, n_events, np.int64)
+    global_lengths = np.full(global_reads, n_events, np.int64)
     mine = shard.lpt_partition(global_lengths, world)[rank]
     n_reads = len(mine)
-    host_threads = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    host_threads = max(1, min(32 if strong else 8, (os.cpu_count() or 1) // max(1, world)))
     t_gen = time.perf_counter()
     off, mean, stdv, start = generate_shard(table, mine, n_events, host_threads)
     cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
@@ -353,23 +426,38 @@ def main():
     assert arc_ok.all(), "decoded path leaves the stay/step/skip graph"
 
     if rank == 0:
-        value = world * total * args.steps / dt / 1e6
+        value = global_reads * n_events * args.steps / dt / 1e6
         k_ms = float(np.mean([k[0] for k in kernel_ms]))
         tb_ms = float(np.mean([k[1] for k in kernel_ms]))
         # the library times the LAST sub-batch launch of a call; algorithmic bytes of that launch only
         events_per_launch = total if launches_per_step <= 1 else None
-        which = "config 2" if (world == 1 and reads_per_gpu == 1024 and n_events == 5000) else (
-            "config-4 shard" if reads_per_gpu == C4_READS_PER_GPU and n_events == 5000 else "custom")
+        if strong:
+            which = "config 4 as written" if (global_reads == C4_TOTAL_READS and n_events == 5000) else "custom (strong scaling)"
+            workload = (f"BASELINE {which}: {global_reads} reads x {n_events} events in total, split over {world} GPU(s) by lpt_partition "
+                        f"({n_reads} reads on rank 0), template-only Viterbi, builtin {args.model} 6-mer model, identity scaling, "
+                        f"transitions p_skip=.3 p_stay=.1")
+        else:
+            which = "config 2" if (world == 1 and reads_per_gpu == 1024 and n_events == 5000) else (
+                "config-4 shard" if reads_per_gpu == C4_READS_PER_GPU and n_events == 5000 else "custom")
+            workload = (f"BASELINE {which}: {reads_per_gpu} reads x {n_events} events per GPU ({reads_per_gpu * world} reads "
+                        f"over {world} GPU(s)), template-only Viterbi, builtin {args.model} 6-mer model, identity scaling, "
+                        f"transitions p_skip=.3 p_stay=.1")
+        if world == 1:
+            collective = "none (one rank)"
+        elif share_gpu0:
+            collective = f"gloo, communicator of {dist.get_world_size()} ranks all on GPU 0 (test hook)"
+        else:
+            collective = (f"rccl: one all-reduce of 8 counters + one max of the step time over a communicator of "
+                          f"{dist.get_world_size()} ranks (one per GPU); nothing on the data path")
         result = {
             "metric": "Mevents/s Viterbi (4096-state HMM)", "value": round(value, 3), "unit": "Mevents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {which}: {reads_per_gpu} reads x {n_events} events per GPU ({reads_per_gpu * world} reads "
-                                   f"over {world} GPU(s)), template-only Viterbi, builtin {args.model} 6-mer model, identity scaling, "
-                                   f"transitions p_skip=.3 p_stay=.1",
-                       "reads_per_gpu": reads_per_gpu, "events_per_read": n_events, "parallelism": f"read-sharded x{world} (LPT, no data-path collective)",
-                       "collective": ("gloo, all ranks on GPU 0 (test hook)" if share_gpu0 else ("rccl all-reduce of 8 counters + max of the step time" if world > 1 else "none")),
+            "config": {"workload": workload,
+                       "reads_per_gpu": reads_per_gpu, "reads_total": global_reads, "events_per_read": n_events,
+                       "parallelism": f"read-sharded x{world} (LPT, no data-path collective)",
+                       "collective": collective,
                        "grid_slots": ctx.grid_slots(), "forward_launches_per_step": launches_per_step,
                        "host_generation_s": round(t_gen, 1)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
@@ -387,6 +475,14 @@ def main():
             if pmc:
                 k = pmc["viterbi_kernel"]
                 roof["traffic"] = int((k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
+                tb = pmc.get("traceback_kernel")
+                if tb and "FETCH_SIZE_KiB" in tb and "WRITE_SIZE_KiB" in tb:
+                    # the 4113 B/event include the traceback's back-pointer read and state write, so its launch belongs in the
+                    # measured traffic as well (it fetches whole 64-byte sectors for the bytes it needs)
+                    roof["traffic_forward_kernel"] = roof["traffic"]
+                    roof["traffic_traceback_kernel"] = int((tb["FETCH_SIZE_KiB"] + tb["WRITE_SIZE_KiB"]) * 1024)
+                    roof["traffic"] += roof["traffic_traceback_kernel"]
+                roof["traffic_source"] = pmc.get("_file")
                 valu = float(k["SQ_INSTS_VALU"])
                 roof["valu_instructions_per_thread_event"] = round(valu / (n_reads * n_events * 8.0), 1)
                 # the kernel is VALU-issue bound: floor = wave-instructions / SIMDs x 2 cycles (wave64 on a 32-lane-per-clock
@@ -403,9 +499,17 @@ def main():
                                   "kernel": f"nchmm::viterbi_kernel x{launches_per_step} + nchmm::traceback_kernel x{launches_per_step} per step (wall)",
                                   "bytes_per_event": BYTES_PER_EVENT, "events_per_step": total,
                                   "last_launch_kernel_ms": round(k_ms, 3)}
+        if world == 1 and not args.no_end_to_end and total <= 64 * 1024 * 1024:
+            try:
+                result["end_to_end"] = end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, max(3, min(args.steps, 10)))
+            except Exception as e:      # a secondary leg must not cost the run its headline line
+                sys.stderr.write(f"bench.py: end-to-end leg failed: {e}\n")
+                result["end_to_end"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and n_events <= 5000:
-            threads = args.cpu_threads or min(physical_cores()[0], 64)
-            base, oracle_results, prepped = cpu_baseline(table, n_events, threads)
+            logical, physical = physical_cores()
+            threads = args.cpu_threads or max(1, min(physical, logical))      # T = physical cores
+            # bounded sample: 256 reads (2 per thread on a 128-core host) -- ~10-20 s of wall, 164 MB of matrix per thread
+            base, oracle_results, prepped = cpu_baseline(table, n_events, threads, max(256, threads))
             # parity in the same run: every read the CPU timed must match the GPU output bit for bit
             states = d_state.cpu().numpy().view(np.uint16)
             logp = d_logp.cpu().numpy()

@@ -8,7 +8,8 @@ Python here is only the test/bench binding over that ABI:
 """
 from . import _lib  # noqa: F401
 from .api import (Context, model_load, model_scale, model_pack6, transitions_fast, events_prepare,  # noqa: F401
-                  base_seq, write_fasta, st_train_kmers, scaled_model_table, train_pm_finish, train_st_finish)
+                  base_seq, write_fasta, st_train_kmers, scaled_model_table, train_pm_finish, train_st_finish,
+                  device_count, device_mem_info)
 from .models import builtin_model, builtin_names, builtin_strands  # noqa: F401
 
 __version__ = "0.1.0"

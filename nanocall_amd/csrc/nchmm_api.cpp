@@ -610,7 +610,7 @@ int launch_batch(nchmm_ctx* c, size_t first, size_t count, uint64_t ev_base, uin
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_vit2, c->stream));
     c->vit_timed = true;
-    c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kStates;
+    c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kBpRowBytes;
     c->counters[3] += 2;
     return NCHMM_OK;
 }
@@ -631,16 +631,16 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
     int rc = ensure(c, &p, &c->last_state_bytes, sizeof(unsigned) * n_reads);
     c->d_last_state = (unsigned*)p;
     if (rc != NCHMM_OK) return rc;
-    // Back-pointer workspace: 4 KiB per event.  When the whole batch fits the budget it is one
+    // Back-pointer workspace: kBpRowBytes (1.5 KiB) per event.  When the whole batch fits the budget it is one
     // forward + one traceback launch; otherwise the batch is cut into contiguous read ranges.
     if (c->ws_budget == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
         const char* e = std::getenv("NCHMM_WS_BUDGET_MB");
         c->ws_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : (free_b / 10) * 6;
-        if (c->ws_budget < ((size_t)64 << 20)) c->ws_budget = (size_t)64 << 20;
+        if (c->ws_budget < ((size_t)16 << 20)) c->ws_budget = (size_t)16 << 20;
     }
-    const size_t need_all = std::max<size_t>(total_events, 1) * (size_t)kStates;
+    const size_t need_all = std::max<size_t>(total_events, 1) * (size_t)kBpRowBytes;
     c->counters[0] += n_reads;
     c->counters[1] += total_events;
     if (need_all <= std::max(c->ws_budget, c->ws_bytes)) {
@@ -655,9 +655,9 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
     std::vector<uint64_t> off(n_reads + 1);
     HIP_TRY(c, hipMemcpyAsync(off.data(), d_off, sizeof(uint64_t) * (n_reads + 1), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint64_t budget_events = std::max<uint64_t>(c->ws_budget / kStates, max_events);
+    const uint64_t budget_events = std::max<uint64_t>(c->ws_budget / kBpRowBytes, max_events);
     p = c->d_ws;
-    rc = ensure(c, &p, &c->ws_bytes, (size_t)budget_events * kStates);
+    rc = ensure(c, &p, &c->ws_bytes, (size_t)budget_events * kBpRowBytes);
     c->d_ws = (uint8_t*)p;
     if (rc != NCHMM_OK) return rc;
     size_t first = 0;

@@ -27,14 +27,18 @@
 //   * Selects are written as v_cndmask_b32_e64 with an SGPR-pair mask: on gfx950 the VOP2 form
 //     reading a VCC that was not written by the immediately preceding VALU op issues ~8x slower
 //     (tools/ubench/valu_rate.hip).
-//   * Back-pointers are one byte per state (0 stay, 1+x step, 5+xy skip); row i of a read at
-//     ws + i*4096, state j at byte (t<<4) | (h<<3) | (x<<1) | (y>>1): each thread stores its 8
-//     bytes as one dwordx2 (a wave writes 512 B contiguous), and the 21 candidates of the next
-//     traceback step sit in three 16-byte groups.
-//   * Traceback is a second kernel (traceback_kernel, one wave per read, every read of the batch
-//     at once): the chase is a dependent pointer walk, so it is latency-bound and wants many reads
-//     in flight rather than CUs parked behind a barrier.  Each round trip fetches every 16-byte
-//     group that can hold the byte of rows i, i-1, i-2 (27 lanes x 16 B) and resolves three events.
+//   * Back-pointers are BIT-PLANES (nchmm_device.h, kBpRowBytes).  The 3-way combine compares each
+//     candidate with the maximum anyway; those compares leave 64-bit lane masks in SGPRs, and two of
+//     them -- "stay wins", "step wins" -- are the back-pointer class of 64 cells at once.  They are
+//     written as they are with one s_store_dwordx4 per cell (the scalar unit and the scalar data
+//     cache are otherwise idle), instead of being turned into per-lane byte codes by two
+//     v_cndmask + one v_lshl_or per cell on the VALU, which is the unit this kernel is bound by
+//     (compare / select class ops issue at half the rate of add / mul / fma, profiles/r03_sstore_rate.txt).
+//     Which member won inside a step / skip group is known to the thread that scanned the group:
+//     one byte per thread and event, a plain vector store.  1.5 KiB per event instead of 4 KiB.
+//   * Traceback is a second kernel (traceback_kernel, one wave per read segment, every read of the
+//     batch at once): the chase is a dependent pointer walk, wave-uniform, so it runs on the scalar
+//     unit -- three scalar loads (class planes, step byte, skip byte) and a few SALU ops per event.
 //
 // Float contract: -ffp-contract=off (the only FMAs are the explicit residual corrections and the
 // next-float probe), denormals on, no device log/exp: every log comes from the host libm.
@@ -54,8 +58,36 @@ constexpr unsigned kChunk = 256;   // events staged in LDS at a time
 
 struct __attribute__((aligned(8))) ValSlot {
     float v;
-    unsigned s;   // back-pointer slot code of the group winner (1+x or 5+xy); the state index in sRed
+    unsigned s;   // winning member of the group (x or 4x + y): read only by the exact tie rule; the state index in sRed
 };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: the body receives its index as a type, so that it can be an instruction immediate
+template <int V> struct IC { static constexpr int value = V; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Step-group exchange array: 1024 entries in 16 rows of 64, row pitch 72.  A wave's combine reads rows kc + h (h = lane & 1)
+// at columns t >> 2: with a pitch of 64 entries both rows start on the same bank (the 2-way conflicts PMC counted as 75 %
+// extra LDS cycles in rounds 1 and 2); 72 entries = 144 words puts the odd row 16 banks further.
+constexpr unsigned kV1Pitch = 72;
+constexpr unsigned kV1Entries = 16 * kV1Pitch;
+
+// The two class masks of one cell go to the back-pointer row as they are: 16 bytes from an SGPR quad, one scalar store.
+// (No "memory" clobber: nothing in this kernel reads these bytes back, and the LDS traffic around it must stay free to
+// move.  The data SGPRs may be overwritten as soon as the store has issued: profiles/r03_sstore_rate.txt, test A.)
+template <int OFF>
+__device__ __forceinline__ void store_planes(mask_t p0, mask_t p1, const uint8_t* wave_row)
+{
+    const u32x4 q = {(unsigned)p0, (unsigned)(p0 >> 32), (unsigned)p1, (unsigned)(p1 >> 32)};
+    asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(q), "s"(wave_row), "n"(OFF));
+}
 
 // v_cndmask_b32_e64 dst, a, b, mask : mask bit set -> b, clear -> a
 __device__ __forceinline__ float selm(mask_t m, float if_set, float if_clear)
@@ -70,18 +102,20 @@ __device__ __forceinline__ unsigned selm(mask_t m, unsigned if_set, unsigned if_
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
 }
-// mask bit set -> 0 (inline constant: no VGPR, no v_mov), clear -> if_clear
-__device__ __forceinline__ unsigned selm_zero(mask_t m, unsigned if_clear)
-{
-    unsigned r;
-    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(r) : "v"(if_clear), "s"(m));
-    return r;
-}
 __device__ __forceinline__ mask_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // a wave-uniform float held in an SGPR instead of a VGPR
 __device__ __forceinline__ float uniform(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// a wave-uniform pointer held in an SGPR pair (scalar loads / stores take their base there)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((uintptr_t)hi << 32) | lo);
 }
 
 // swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
@@ -93,9 +127,6 @@ __device__ __forceinline__ unsigned swap1(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
-
-// byte of state j inside its 16-byte group: k = j >> 8 = 4x + y  ->  ((y&1)<<3) | (x<<1) | (y>>1)
-__device__ __forceinline__ unsigned bp_pos(unsigned k) { return ((k & 1u) << 3) | ((k >> 2) << 1) | ((k >> 1) & 1u); }
 
 // n / d with r = RN(1/d) precomputed: q0 = RN(n r), one exact residual (FMA), one correction (FMA) -- three
 // VALU ops, bit-identical to the IEEE quotient.  Markstein's theorem gives this whenever q0 is a faithful
@@ -174,9 +205,10 @@ __device__ __forceinline__ void merge_lower(float& av, unsigned& ai, float bv, u
 
 template <bool FAST>
 __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], ValSlot* sV1, ValSlot* sV2,
-                                       uint8_t* bp_row, unsigned tau, float x, float y, float ry, float ly3,
+                                       const uint8_t* bp_row, const uint8_t* bp_wave, unsigned tau, float4& ev, const float4* next_ev,
                                        float log_2pi)
 {
+    const float x = ev.x, y = ev.y, ly3 = ev.z, ry = ev.w;     // staged per event: x, y, 3 log y, 1 / y (wave-uniform, in SGPRs)
     const float NEG_INF = -__builtin_inff();
     const unsigned t = tau >> 1, h = tau & 1u;
 
@@ -208,8 +240,6 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
 
     float s1[2] = {S.w1[0] + m4[0], S.w1[1] + m4[1]};
     float s2 = S.w2 + m16;
-    unsigned sl1[2] = {1u + x4[0], 1u + x4[1]};
-    unsigned sl2 = 5u + k16;
     // Is any smaller alpha rounded to the same sum?  probe the next float below the maximum
     // (exact for negative normal maxima; anything else reports "unsafe").
     {
@@ -230,7 +260,7 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
                     bv = selm(m, v, bv);
                     bx = selm(m, (unsigned)xx, bx);
                 }
-                s1[g] = bv; sl1[g] = 1u + bx;
+                s1[g] = bv; x4[g] = bx;
             }
             float bv = NEG_INF; unsigned bk = h;
 #pragma unroll
@@ -241,66 +271,103 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
                 bk = selm(m, 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h, bk);
             }
             merge_lower(bv, bk, swap1(bv), swap1(bk));
-            s2 = bv; sl2 = 5u + bk;
+            s2 = bv; k16 = bk;
         }
     }
-    sV1[(h << 8) | t] = ValSlot{s1[0], sl1[0]};
-    sV1[((2u + h) << 8) | t] = ValSlot{s1[1], sl1[1]};
-    if (h == 0) sV2[t] = ValSlot{s2, sl2};
+    // group r = (y << 8) | t is entry r of the step array: row r >> 6 = 4y + (t >> 6), column t & 63
+    ValSlot* const pw = sV1 + kV1Pitch * (4u * h + (t >> 6)) + (t & 63u);
+    pw[0] = ValSlot{s1[0], x4[0]};
+    pw[8 * kV1Pitch] = ValSlot{s1[1], x4[1]};
+    if (h == 0) sV2[t] = ValSlot{s2, k16};
+    // who won inside this thread's groups: the second half of the back-pointer row, one byte per thread
+    // (scalar base + 32-bit lane offset, spelled out: hipcc otherwise keeps a 64-bit per-lane address alive across the loop
+    // and spills it; nothing in this kernel reads the byte back, so no "memory" clobber)
+    asm volatile("global_store_byte %0, %1, %2 offset:%3" :: "v"(tau), "v"(x4[0] | (x4[1] << 2) | (k16 << 4)), "s"(bp_row), "n"(kBpGroupOff));
+
+    // ---------------- emissions of this event ----------------
+    // They depend on nothing the exchange delivers, so they sit between the LDS writes and the barrier: their table reads
+    // wait for "all LDS and scalar-memory operations" (one counter), and here the previous event's scalar stores have had the
+    // whole scan phase to land; right after the combine they would wait for stores issued a few cycles earlier.
+    __builtin_amdgcn_sched_barrier(0);
+    float em[8];
+    static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const unsigned o = tab_off(tau, (unsigned)i >> 2) + ((unsigned)i & 3u);
+        em[i] = emission<FAST>(x, y, ry, ly3, log_2pi, S.mu[i], S.sg[i], S.rsg[i], sTab[0][o], S.eta[i], S.reta[i], S.lam[i], sTab[1][o]);
+    });
+    // (pins the computation here: without a use in front of the barrier LLVM sinks it to the alpha update after the combine)
+    asm volatile("" : "+v"(em[0]), "+v"(em[1]), "+v"(em[2]), "+v"(em[3]), "+v"(em[4]), "+v"(em[5]), "+v"(em[6]), "+v"(em[7]));
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 
     // ---------------- 3-way combine per state ----------------
+    // entry r1 = 64 (kc + h) + (t >> 2) of the step array = row kc + h, column t >> 2; entry q = 16 (kc + h) + (t >> 4) of the skip array
     const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
     // one per-thread base pointer per exchange array; every cell is then an immediate offset
-    const ValSlot* const pa = sV1 + r1_base;
+    const ValSlot* const pa = sV1 + h * kV1Pitch + (t >> 2);
     const ValSlot* const pb = sV2 + q_base;
-    unsigned bpw[2] = {0, 0};
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const float4 nls4 = *reinterpret_cast<const float4*>(&sTab[0][tab_off(tau, c)]);
-        const float4 cc4 = *reinterpret_cast<const float4*>(&sTab[1][tab_off(tau, c)]);
-        const float4 w04 = *reinterpret_cast<const float4*>(&sTab[2][tab_off(tau, c)]);
-        const float nls_[4] = {nls4.x, nls4.y, nls4.z, nls4.w};
-        const float cc_[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
-        const float w0_[4] = {w04.x, w04.y, w04.z, w04.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 4 * c + u;
-            // k = kc + h with kc a compile-time constant: the LDS addresses are one per-thread base
-            // (r1_base, q_base) plus an immediate offset
-            const unsigned kc = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1);
-            const unsigned k = kc + h;
-            const unsigned r1 = r1_base + (kc << 6), q = q_base + (kc << 4);
-            const ValSlot a = pa[kc << 6];
-            const ValSlot b = pb[kc << 4];
-            const float s0 = w0_[u] + S.alpha[i];
-            // fast path: the winner is unique unless two class values are equal
-            float best = __builtin_fmaxf(__builtin_fmaxf(s0, a.v), b.v);
-            const mask_t e0 = ballot(s0 == best), e1 = ballot(a.v == best), e2 = ballot(b.v == best);
-            unsigned slot = selm_zero(e0, selm(e1, a.s, b.s));
-            // two or more of the three equal the maximum?  (all three NaN cannot happen for a cell that
-            // matters: the read is then reported NCHMM_E_NUMERIC by the final arg-max)
-            const mask_t tie = (e0 & e1) | ((e0 | e1) & e2);
-            if (tie != 0) {
-                ++S.n_tie;
-                // exact rule: first maximum in ascending predecessor order (strict >, NaN never wins)
-                const unsigned j = t + 256u * k;
-                const unsigned p1 = ((a.s - 1u) << 10) | r1;
-                const unsigned p2 = ((b.s - 5u) << 8) | q;
-                float bb = NEG_INF; unsigned bp = (unsigned)kStates, sl = 255u;
-                if (s0 > bb) { bb = s0; bp = j; sl = 0; }
-                if (a.v > bb || (a.v == bb && p1 < bp)) { bb = a.v; bp = p1; sl = a.s; }
-                if (b.v > bb || (b.v == bb && p2 < bp)) { bb = b.v; bp = p2; sl = b.s; }
-                best = bb; slot = sl;
-            }
-            const float e = emission<FAST>(x, y, ry, ly3, log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls_[u], S.eta[i],
-                                           S.reta[i], S.lam[i], cc_[u]);
-            S.alpha[i] = best + e;
-            bpw[c] |= slot << (8 * u);
-        }
+    // Fast path for all eight cells first, no branch in between: the winner is unique unless two class values are equal, and
+    // then the three compares with the maximum name it -- as lane masks, which go to memory as they are.  Cells where two or
+    // more candidates equal the maximum are collected in `tie` and the whole column is redone by the exact rule below (one
+    // wave-uniform branch per event instead of one per cell).
+    float s0[8], best[8];
+    mask_t tie = 0;
+    // every group winner this thread consumes and its eight stay weights: 18 LDS reads issued back to back, ONE wait.  (Left
+    // alone, hipcc reads the three values of a cell right before their use and waits for each cell -- and each of those
+    // waits would also wait for the scalar store of the cell before.)
+    float av[8], bv[8];
+    static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        // k = kc + h with kc a compile-time constant: the LDS addresses are one per-thread base plus an immediate offset
+        constexpr unsigned kc = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1);
+        av[i] = pa[kc * kV1Pitch].v;
+        bv[i] = pb[kc << 4].v;
+    });
+    const float4 w0lo = *reinterpret_cast<const float4*>(&sTab[2][tab_off(tau, 0)]);
+    const float4 w0hi = *reinterpret_cast<const float4*>(&sTab[2][tab_off(tau, 1)]);
+    const float w0[8] = {w0lo.x, w0lo.y, w0lo.z, w0lo.w, w0hi.x, w0hi.y, w0hi.z, w0hi.w};
+    float4 nev = *next_ev;
+    asm volatile("" : "+v"(nev.x), "+v"(nev.y), "+v"(nev.z), "+v"(nev.w));
+    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]),
+                      "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]));
+    static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        s0[i] = w0[i] + S.alpha[i];
+        best[i] = __builtin_fmaxf(__builtin_fmaxf(s0[i], av[i]), bv[i]);
+        // the class of the winner, 64 cells at a time: these masks are the back-pointer
+        const mask_t e0 = ballot(s0[i] == best[i]), e1 = ballot(av[i] == best[i]), e2 = ballot(bv[i] == best[i]);
+        // two or more of the three equal the maximum?  (all three NaN cannot happen for a cell that
+        // matters: the read is then reported NCHMM_E_NUMERIC by the final arg-max)
+        tie |= (e0 & e1) | ((e0 | e1) & e2);
+        // cell i = (x << 1) | (y >> 1) sits at position ((y >> 1) << 2) | x of the wave's 128 bytes
+        store_planes<16 * (((i & 1) << 2) | (i >> 1))>(e0, e1, bp_wave);
+    });
+    if (tie != 0) {
+        ++S.n_tie;
+        // the planes of this column are written a second time: the first stores must have landed (scalar stores of one wave
+        // are not ordered among themselves)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<0, 8>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            constexpr unsigned kc = 4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1);
+            // exact rule: first maximum in ascending predecessor order (strict >, NaN never wins)
+            const ValSlot a = pa[kc * kV1Pitch], b = pb[kc << 4];
+            const unsigned j = t + 256u * (kc + h);
+            const unsigned p1 = (a.s << 10) | (r1_base + (kc << 6));
+            const unsigned p2 = (b.s << 8) | (q_base + (kc << 4));
+            float bb = NEG_INF; unsigned bp = (unsigned)kStates, cls = 3u;    // 3: no predecessor (every candidate -INF / NaN)
+            if (s0[i] > bb) { bb = s0[i]; bp = j; cls = 0u; }
+            if (a.v > bb || (a.v == bb && p1 < bp)) { bb = a.v; bp = p1; cls = 1u; }
+            if (b.v > bb || (b.v == bb && p2 < bp)) { bb = b.v; bp = p2; cls = 2u; }
+            best[i] = bb;
+            store_planes<16 * (((i & 1) << 2) | (i >> 1))>(ballot(cls == 0u) | ballot(cls == 3u), ballot(cls == 1u) | ballot(cls == 3u), bp_wave);
+        });
     }
-    const unsigned w_lo = bpw[0], w_hi = bpw[1];
-    *reinterpret_cast<uint2*>(bp_row + tau * 8u) = make_uint2(w_lo, w_hi);
+    static_for<0, 8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        S.alpha[i] = best[i] + em[i];
+    });
+    ev = make_float4(uniform(nev.x), uniform(nev.y), uniform(nev.z), uniform(nev.w));
 }
 
 __device__ __forceinline__ bool event_in_fast_range(float x, float y)
@@ -317,7 +384,7 @@ __device__ __forceinline__ bool event_in_fast_range(float x, float y)
 __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(ViterbiArgs P)
 {
     __shared__ __attribute__((aligned(16))) float sTab[3][kStates];   // -log sigma | log lambda - log 2pi | w0
-    __shared__ ValSlot sV1[2][1024];   // step-group winners
+    __shared__ ValSlot sV1[2][kV1Entries];   // step-group winners (16 rows of 64, pitch 72)
     __shared__ ValSlot sV2[2][256];    // skip-group winners
     __shared__ __attribute__((aligned(16))) float4 sEv[kChunk];     // per event: x, y, 3*log y, 1/y
     ValSlot* const sRed = &sV1[0][0];  // the final arg-max reduction reuses the exchange buffer
@@ -372,8 +439,9 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         const float* __restrict__ ex = P.cmean + e0;
         const float* __restrict__ ey = P.stdv + e0;
         const float* __restrict__ el = P.lstdv + e0;
-        // back-pointer row i of this read: one 4 KiB row per event of the batch, in event order
-        uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
+        // back-pointer row i of this read: one kBpRowBytes row per event of the batch, in event order
+        uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kBpRowBytes;
+        const unsigned wave_off = __builtin_amdgcn_readfirstlane(tau >> 6) * 128u;   // this wave's class planes inside a row
 
         State S;
 #pragma unroll
@@ -432,19 +500,24 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 lo = 1;
             }
             // ---- columns (Viterbi.hpp:72-96) ----
-            if (fast) {
-                for (unsigned c = lo; c < hi; ++c) {
-                    const float4 ev = sEv[c];
-                    const unsigned i = base + c;
-                    column<true>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
-                                 uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
-                }
-            } else {
-                for (unsigned c = lo; c < hi; ++c) {
-                    const float4 ev = sEv[c];
-                    const unsigned i = base + c;
-                    column<false>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
-                                  uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
+            // The staged event of column c + 1 is fetched inside column c, in the same batch of LDS reads as the group winners
+            // (one wait for all of them); fetched at the top of its own column it would be a second wait, right behind the
+            // scalar stores that end the column before.
+            if (lo < hi) {
+                float4 ev = sEv[lo];
+                ev = make_float4(uniform(ev.x), uniform(ev.y), uniform(ev.z), uniform(ev.w));
+                if (fast) {
+                    for (unsigned c = lo; c < hi; ++c) {
+                        const unsigned i = base + c;
+                        const uint8_t* const row = ws + (uint64_t)i * kBpRowBytes;
+                        column<true>(S, sTab, sV1[i & 1u], sV2[i & 1u], row, row + wave_off, tau, ev, &sEv[c + 1 < kChunk ? c + 1 : c], P.log_2pi);
+                    }
+                } else {
+                    for (unsigned c = lo; c < hi; ++c) {
+                        const unsigned i = base + c;
+                        const uint8_t* const row = ws + (uint64_t)i * kBpRowBytes;
+                        column<false>(S, sTab, sV1[i & 1u], sV2[i & 1u], row, row + wave_off, tau, ev, &sEv[c + 1 < kChunk ? c + 1 : c], P.log_2pi);
+                    }
                 }
             }
             __syncthreads();   // sEv is rewritten by the next chunk
@@ -463,6 +536,9 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
             }
             sRed[tau] = ValSlot{bv, bi};
         }
+        // the class planes went through the scalar data cache: write it back (the traceback is another kernel; the end of
+        // this one flushes L2-bound vector stores, but a scalar store only leaves the scalar cache when told to)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
         __syncthreads();   // also publishes every back-pointer store of this block (vmcnt(0) + barrier)
         unsigned long long c1 = 0;
         if (P.prof) c1 = wall_clock64();
@@ -510,103 +586,79 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     }
 }
 
-// branch-free pred_of for the (wave-uniform) chase
-__device__ __forceinline__ unsigned pred_uniform(unsigned j, unsigned slot, unsigned& shift_class)
-{
-    const unsigned sc = slot == 0 ? 0u : (slot < 5u ? 1u : 2u);
-    const unsigned hi = (slot - (sc == 1u ? 1u : 5u)) << (12u - 2u * sc);
-    shift_class = sc;
-    return sc == 0 ? j : ((hi | (j >> (2u * sc))) & 4095u);
-}
-
 constexpr int kTbWaves = 8;      // traceback segments per read (one wave each)
 
-// One wave follows the back-pointers from (event ev_hi, state s) down to event ev_lo, writing
-// out_state[e] for ev_lo <= e <= min(ev_hi - 1, ev_write_hi) (the start event itself is the caller's).
-// Per round trip it fetches every 16-byte group that can hold the byte it will need in rows cur,
-// cur-1 (1 + 3 groups; LEVELS == 2) and cur-2 (+ 23 groups; LEVELS == 3) and resolves two or three
-// events from LDS.  Three levels minimise round trips (one read per wave: latency-bound); two levels
-// fetch 4.5x fewer sectors per event, which is what matters once 8 waves per read make the
-// traceback bandwidth-bound (every 16-byte group costs a whole 64-byte sector).  Decoded states
-// are collected in LDS and written 192 at a time so that no store sits in front of the next loads.
-// Returns the state at ev_lo; *mark_state receives the state at event `mark` if the walk passes it.
-template <int LEVELS>
-__device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsigned s, int ev_hi, int ev_lo, int ev_write_hi,
-                                          int mark, unsigned* mark_state, unsigned lane, uint8_t (*sStage)[16],
-                                          uint16_t* sOut, unsigned& bad, int bad_hi)
+// One step of the chase: state s at event `cur` -> its predecessor at event cur - 1, decoded from back-pointer row `cur`
+// (layout: nchmm_device.h).  s is wave-uniform, so this is scalar work: the class planes of s's cell (16 bytes), the byte
+// of the thread that scanned s's step group and the byte of the thread that scanned its skip group sit at addresses that
+// depend on s alone -- three scalar loads in flight together, one wait, a dozen SALU ops.  `none` collects the
+// "no predecessor" marker (both class bits set).
+__device__ __forceinline__ unsigned tb_step(const uint8_t* row, unsigned s, unsigned& none)
 {
-    unsigned rowoff, sh, msk, hi;
-    if (lane == 0) { rowoff = 0; sh = 0; msk = 255; hi = 0; }
-    else if (lane < 4) { rowoff = 1; sh = 2 * (lane - 1); msk = 255; hi = 0; }
-    else if (lane < 7) { rowoff = 2; sh = 2 * (lane - 4); msk = 255; hi = 0; }
-    else if (lane < 11) { rowoff = 2; sh = 6; msk = 63; hi = (lane - 7) << 6; }
-    else { rowoff = 2; sh = 8; msk = 15; hi = ((lane - 11) & 15u) << 4; }
-    const bool lane_on = lane < (LEVELS == 3 ? 27u : 4u);
-    int cur = ev_hi;                 // row cur holds the back-pointer from event cur to event cur-1
-    int pending_top = cur - 1;       // event index of sOut[0]
-    unsigned n_pending = 0;
+    const unsigned t = s & 255u, k = s >> 8, y = k & 3u;
+    const unsigned tau = 2u * t + (y & 1u), lane = tau & 63u;
+    const unsigned o_cls = (tau >> 6) * 128u + (((y >> 1) << 2) | (k >> 2)) * 16u;
+    // step group r = s >> 2 = (y1 << 8) | t1 was scanned by thread 2 t1 + (y1 & 1): member bits 2 (y1 >> 1) of its byte
+    const unsigned r = s >> 2, y1 = r >> 8;
+    const unsigned o_step = kBpGroupOff + 2u * (r & 255u) + (y1 & 1u);
+    // skip group q = s >> 4 was scanned by threads 2q and 2q + 1, which both hold the merged winner: high nibble of byte 2q
+    const unsigned o_skip = kBpGroupOff + 2u * (s >> 4);
+    u32x4 cls;
+    unsigned w_step, w_skip;
+    asm volatile("s_load_dwordx4 %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(cls), "=&s"(w_step), "=&s"(w_skip)
+                 : "s"(row), "s"(o_cls), "s"(o_step & ~3u), "s"(o_skip & ~3u)
+                 : "memory");
+    const unsigned p0 = (((lane & 32u) ? cls.y : cls.x) >> (lane & 31u)) & 1u;     // stay
+    const unsigned p1 = (((lane & 32u) ? cls.w : cls.z) >> (lane & 31u)) & 1u;     // step
+    const unsigned b_step = (w_step >> (8u * (o_step & 3u))) & 255u, b_skip = (w_skip >> (8u * (o_skip & 3u))) & 255u;
+    const unsigned pred_step = (((b_step >> (2u * (y1 >> 1))) & 3u) << 10) | r;
+    const unsigned pred_skip = ((b_skip >> 4) << 8) | (s >> 4);
+    none |= p0 & p1;
+    return p0 ? s : (p1 ? pred_step : pred_skip);
+}
+
+// One wave follows the back-pointers from (event ev_hi, state s) down to event ev_lo, writing out_state[e] for
+// ev_lo <= e <= min(ev_hi - 1, ev_write_hi) (the start event itself is the caller's).  The walk is scalar (tb_step); the
+// vector lanes only collect the decoded states, one per lane, and write them 64 at a time.
+// Returns the state at ev_lo; *mark_state receives the state at event `mark` if the walk passes it.  `bad` collects
+// "no predecessor" cells met at rows <= bad_hi (rows above belong to the speculative run-in of a segment).
+__device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsigned s, int ev_hi, int ev_lo, int ev_write_hi,
+                                          int mark, unsigned* mark_state, unsigned lane, unsigned& bad, int bad_hi)
+{
+    // everything that steers the walk is wave-uniform; say so, and the loop runs on the scalar unit
+    s = __builtin_amdgcn_readfirstlane(s);
+    ws = uniform_ptr(ws);
+    ev_lo = __builtin_amdgcn_readfirstlane(ev_lo);
+    ev_write_hi = __builtin_amdgcn_readfirstlane(ev_write_hi);
+    mark = __builtin_amdgcn_readfirstlane(mark);
+    bad_hi = __builtin_amdgcn_readfirstlane(bad_hi);
+    int cur = __builtin_amdgcn_readfirstlane(ev_hi);   // row cur holds the back-pointer from event cur to event cur - 1
+    int pending_top = 0;             // event of lane 0's pending state
+    unsigned n_pending = 0, acc = 0;
     while (cur > ev_lo) {
-        const int row = cur - (int)rowoff;
-        const unsigned grp = hi | ((s >> sh) & msk);
-        if (lane_on && row > ev_lo)
-            *reinterpret_cast<uint4*>(&sStage[lane][0]) =
-                *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
-        __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
-        __builtin_amdgcn_wave_barrier();
-        unsigned sc0, sc1, sc2;
+        unsigned none = 0;
+        s = tb_step(ws + (uint64_t)cur * kBpRowBytes, s, none);
         // an unreachable cell (no predecessor: every candidate -INF/NaN) carries no back-pointer.  It only counts when the
         // walk is known to be on the true path: rows above bad_hi belong to the speculative run-in of a segment.
-        unsigned slot = sStage[0][bp_pos(s >> 8)];
-        bad |= (slot > 20u) & (unsigned)(cur <= bad_hi);
-        s = pred_uniform(s, slot > 20u ? 0u : slot, sc0);
-        const unsigned s_a = s;
-        unsigned s_b = s, s_c = s;
-        int done = 1;
-        if (cur - 1 > ev_lo) {
-            slot = sStage[1 + sc0][bp_pos(s >> 8)];
-            bad |= (slot > 20u) & (unsigned)(cur - 1 <= bad_hi);
-            s = pred_uniform(s, slot > 20u ? 0u : slot, sc1);
-            s_b = s; done = 2;
-            if (LEVELS == 3 && cur - 2 > ev_lo) {
-                const unsigned tot = sc0 + sc1;
-                const unsigned ln = tot <= 2 ? 4u + tot : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
-                slot = sStage[ln][bp_pos(s >> 8)];
-                bad |= (slot > 20u) & (unsigned)(cur - 2 <= bad_hi);
-                s = pred_uniform(s, slot > 20u ? 0u : slot, sc2);
-                s_c = s; done = 3;
-            }
+        bad |= none & (unsigned)(cur <= bad_hi);
+        --cur;                       // s is the state of event cur now
+        if (mark_state && cur == mark) *mark_state = s;
+        if (cur <= ev_write_hi) {
+            if (n_pending == 0) pending_top = cur;
+            acc = lane == n_pending ? s : acc;
+            ++n_pending;
         }
-        if (mark_state) {
-            if (cur - 1 == mark) *mark_state = s_a;
-            if (done > 1 && cur - 2 == mark) *mark_state = s_b;
-            if (done > 2 && cur - 3 == mark) *mark_state = s_c;
-        }
-        if (lane == 0) {
-            sOut[n_pending] = (uint16_t)s_a;
-            if (done > 1) sOut[n_pending + 1] = (uint16_t)s_b;
-            if (done > 2) sOut[n_pending + 2] = (uint16_t)s_c;
-        }
-        n_pending += (unsigned)done;
-        cur -= done;
-        if (n_pending + 3 > 192u || cur <= ev_lo) {
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            // sOut[k] is the state of event pending_top - k
-            for (unsigned k = lane; k < n_pending; k += 64) {
-                const int e = pending_top - (int)k;
-                if (e <= ev_write_hi) os[e] = sOut[k];
-            }
-            pending_top -= (int)n_pending;
+        if (n_pending == 64u || (cur <= ev_lo && n_pending != 0u)) {
+            if (lane < n_pending) os[pending_top - (int)lane] = (uint16_t)acc;
             n_pending = 0;
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
         }
     }
     return s;
 }
 
 // Viterbi::fill_state_seq, Viterbi.hpp:134-141.  The chase is a dependent pointer walk bound by
-// HBM latency (~1 us per three events), so a read is cut into up to 8 segments walked by 8 waves
+// memory latency (one round trip per event), so a read is cut into up to 8 segments walked by 8 waves
 // at once.  Only the top segment knows its start state; the others start tb_margin (256) events above
 // their segment from an arbitrary state and rely on Viterbi survivor paths coalescing: if the
 // speculative walk is in the same state as the true path at the first event it owns, everything
@@ -615,8 +667,6 @@ __device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsig
 // so the result is exact either way.
 __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sStage[kTbWaves][32][16];
-    __shared__ uint16_t sOut[kTbWaves][192];
     __shared__ unsigned sLow[kTbWaves + 1], sTent[kTbWaves], sBad[kTbWaves];
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned r = P.first_read + blockIdx.x;
@@ -626,7 +676,7 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
         if (threadIdx.x == 0 && P.out_status) P.out_status[r] = 0;
         return;
     }
-    const uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
+    const uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kBpRowBytes;
     uint16_t* __restrict__ os = P.out_state + e0;
     const unsigned s_last = P.last_state[r];
     if (s_last >= (unsigned)kStates) {
@@ -641,8 +691,7 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
         const int lo = (int)wave * L;
         if ((int)wave == K - 1) {
             if (lane == 0) os[n - 1] = (uint16_t)s_last;
-            const unsigned s_lo = K == 1 ? chase<3>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad, n)
-                                         : chase<2>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad, n);
+            const unsigned s_lo = chase(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, bad, n);
             if (lane == 0) sLow[wave] = s_lo;
         } else {
             const int own_hi = lo + L - 1;             // highest event this segment owns
@@ -652,8 +701,7 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
             // the state at event own_hi+1 is the first one compared with the segment above
             // `bad` of this walk is only meaningful from the boundary row down, and only if the walk turns out to have
             // merged with the true path there (wave 0 decides; otherwise the segment is walked again)
-            const unsigned s_lo = chase<2>(ws, os, 0u, start, lo, own_hi, own_hi + 1, &tent, lane, sStage[wave], sOut[wave], bad,
-                                           own_hi + 1);
+            const unsigned s_lo = chase(ws, os, 0u, start, lo, own_hi, own_hi + 1, &tent, lane, bad, own_hi + 1);
             if (start == own_hi + 1) tent = 0u;        // no margin left: the guess itself sits on the boundary
             if (lane == 0) { sLow[wave] = s_lo; sTent[wave] = tent; }
         }
@@ -670,8 +718,7 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
             } else {
                 // speculation had not merged: walk this segment again from the true state
                 unsigned b2 = 0;
-                const unsigned s_lo = chase<3>(ws, os, truth, (w + 1) * L, w * L, (w + 1) * L - 1, -1, nullptr, lane, sStage[0],
-                                            sOut[0], b2, n);
+                const unsigned s_lo = chase(ws, os, truth, (w + 1) * L, w * L, (w + 1) * L - 1, -1, nullptr, lane, b2, n);
                 any_bad |= b2;
                 if (lane == 0) sLow[w] = s_lo;
                 __builtin_amdgcn_s_waitcnt(0);

@@ -172,3 +172,37 @@ def test_pool_shard_with_reads_but_no_jobs(gpu_ctx):
     assert two["best_logp"][0, 0].tobytes() == one["best_logp"][0, 0].tobytes()
     assert np.isnan(two["best_logp"][1]).all() and np.isnan(two["best_logp"][0, 1])
     assert tr["rounds"].shape == (1,) and tr["rounds"][0] >= 1
+
+
+@pytest.mark.skipif(api.device_count() < 2, reason="needs two distinct GPUs (the driver's multi-GPU node)")
+def test_pool_over_two_distinct_devices_uses_rccl_for_the_counters(gpu_ctx):
+    """nchmm_pool_* on two DIFFERENT devices: the read-parallel contract of nanocall.cpp:611-621 (every read decoded once,
+    results in input order whatever device took it) and the one collective of the design -- the RCCL all-reduce of the
+    counters (used_rccl == 1).  Same reads through the single context give the same bytes."""
+    opts = api.train_opts()
+    names = ["r73.c.p1", "r73.c.p2", "r73.t"]
+    tables = [na.builtin_model(n) for n in names]
+    states10 = np.stack([na.model_load(t) for t in tables])
+    lens = [700, 300, 520, 640, 410, 333]
+    evs = [synth.generate(tables[2], 1, n, first_read=900 + i) for i, n in enumerate(lens)]
+    mean = np.concatenate([e["mean"][0] for e in evs])
+    stdv = np.concatenate([e["stdv"][0] for e in evs])
+    start = np.concatenate([e["start"][0] for e in evs])
+    so = np.zeros(2 * len(lens) + 1, np.uint64)
+    so[1::2] = np.cumsum(lens)          # strand 0 = the read, strand 1 empty
+    so[2::2] = np.cumsum(lens)
+    jr, j0, j1 = api.train_enumerate(opts, [1, 1, 0], so, [0] * len(lens))
+    pm = np.tile(np.float32([1, 0, 0, 1, 1, 1]), (len(jr), 1))
+    st = np.tile(np.float32([0.1, 0.3, 0.1, 0.3]), (len(jr), 1))
+    before = gpu_ctx.counters().astype(np.int64)
+    one = gpu_ctx.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st)
+    delta = gpu_ctx.counters().astype(np.int64) - before
+    with api.Pool([0, 1]) as pool:
+        two = pool.basecall_reads(opts, states10, so, mean, stdv, start, jr, j0, j1, pm, st)
+        counters, used_rccl = pool.counters()
+    assert used_rccl
+    # reads and events decoded: the two fresh contexts together did exactly what the single context did
+    assert counters[0] == delta[0] and counters[1] == delta[1] == sum(lens)
+    assert np.array_equal(two["states"], one["states"])
+    assert two["best_job"].tolist() == one["best_job"].tolist()
+    assert two["best_logp"].tobytes() == one["best_logp"].tobytes()

@@ -52,3 +52,19 @@ if "viterbi_kernel" in traffic and "FETCH_SIZE_KiB" in traffic["viterbi_kernel"]
     doc.update(traffic)
     json.dump(doc, open(os.path.join(out, "hbm_traffic_c2.json"), "w"), indent=1)
     print("== wrote", os.path.join(out, "hbm_traffic_c2.json"))
+fb = {k: v for k, v in traffic.items() if k.startswith("fwbw_") and "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v}
+if fb:
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("fwbw_scaled_kernel.hip", "fwbw_common.hpp", "nchmm_device.h"):
+        h.update(open(os.path.join(root, "nanocall_amd", "csrc", f), "rb").read())
+    doc = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_profile_fwbw.sh), per-dispatch means, AS REPORTED. "
+                       "The backward sweep streams its alpha rows with 16-byte-per-lane loads, which gfx950's FETCH_SIZE counts at half their "
+                       "bytes (MI355X_MICROARCH.md, HBM section): bench.py doubles FETCH_SIZE when it fills fwbw.roofline.traffic.",
+           "workload": {"windows": int(os.environ.get("PROF_WINDOWS", 4096)), "events": int(os.environ.get("PROF_EVENTS_PER_WINDOW", 100))},
+           "kernel_source_sha256_16": h.hexdigest()[:16]}
+    doc.update(fb)
+    json.dump(doc, open(os.path.join(out, "hbm_traffic_fwbw.json"), "w"), indent=1)
+    print("== wrote", os.path.join(out, "hbm_traffic_fwbw.json"))

@@ -1,0 +1,283 @@
+// sstore_rate.hip -- can the Viterbi forward sweep export its decisions as the SGPR masks the compares already
+// produce (bit-planes, one bit per lane) with scalar stores, instead of turning them into per-lane codes with
+// v_cndmask / v_lshl_or and storing bytes?  Three questions, answered on the device:
+//   A  semantics: s_store_dwordx4 of v_cmp results lands in memory (after s_dcache_wb), also when the data SGPRs
+//      are overwritten by the next v_cmp right after the store was issued;
+//   B  cost: a Viterbi-shaped loop (512 threads, 2 blocks per CU, one barrier per iteration, ~280 VALU ops per
+//      thread-iteration in the kernel's double-rate / single-rate mix) with 0 / 4 / 12 / 24 scalar stores per
+//      wave-iteration, and with extra SALU mask logic;
+//   C  ns per wave-instruction per SIMD at this occupancy for the VALU ops a redesign would lean on.
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize sstore_rate.hip -o sstore_rate ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef unsigned long long u64;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// ---------------------------------------------------------------- A: semantics
+__global__ __launch_bounds__(64) void sstore_semantics(u64* out, int iters)
+{
+    const unsigned lane = threadIdx.x;
+    u64* base = out + (size_t)blockIdx.x * iters * 2;
+    for (int it = 0; it < iters; ++it) {
+        const float v0 = (float)((lane * 7u + (unsigned)it * 13u + blockIdx.x) & 63u);
+        const float v1 = (float)((lane * 11u + (unsigned)it * 5u + 3u * blockIdx.x) & 63u);
+        const float w0 = (float)((lane * 3u + (unsigned)it) & 63u);
+        u64* p = base + 2 * it;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
+        const u64 addr = ((u64)hi << 32) | lo;
+        // two masks into one aligned SGPR quad, stored, and the quad overwritten at once by other compares
+        asm volatile(
+            "v_cmp_gt_f32_e64 s[20:21], %1, %3\n\t"
+            "v_cmp_gt_f32_e64 s[22:23], %2, %3\n\t"
+            "s_store_dwordx4 s[20:23], %0, 0x0\n\t"
+            "v_cmp_gt_f32_e64 s[20:21], %4, %3\n\t"
+            "v_cmp_lt_f32_e64 s[22:23], %4, %3\n\t"
+            "s_mov_b64 s[20:21], -1\n\t"
+            "s_mov_b64 s[22:23], 0\n\t"
+            :: "s"(addr), "v"(v0), "v"(v1), "v"(31.5f), "v"(w0)
+            : "s20", "s21", "s22", "s23", "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------- B: cost inside a Viterbi-shaped loop
+// per thread-iteration: 8 cells x (19 "emission" double-rate ops: 8 fma + 11 add/mul; 3 compares; 1 max3; SELS selects;
+// 2 adds) + ~40 scan-like single-rate ops.  STORES scalar stores (dwordx4) per wave-iteration; SALU extra s_and/s_or pairs.
+template <int STORES, int SELS, int SALU, bool X2>
+__global__ __launch_bounds__(512, 4) void vit_shape(float* out, u64* planes, int iters)
+{
+    __shared__ float sX[2][1024];
+    const unsigned tau = threadIdx.x, wave = tau >> 6;
+    float a[8], mu[8], sg[8];
+    for (int i = 0; i < 8; ++i) { a[i] = -1.0f - 0.001f * tau - i; mu[i] = 50.0f + i + 0.01f * tau; sg[i] = 1.0f + 0.001f * (tau + i); }
+    float x = 55.0f + 0.001f * blockIdx.x;
+    unsigned bp = 0;
+    u64 acc = 0;
+    u64* row = planes + ((size_t)blockIdx.x * 8 + wave) * 32;   // 256 B per wave, rewritten every iteration (hot in cache)
+    for (int it = 0; it < iters; ++it) {
+        // scan-like phase: 40 single-rate ops on alpha
+        float m = a[0];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+#pragma unroll
+            for (int i = 1; i < 8; ++i) {
+                asm volatile("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(a[i]));
+            }
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(x));
+        }
+        sX[it & 1][tau] = m; sX[it & 1][512 + (tau ^ 37u)] = m;
+        __syncthreads();
+        const float g1 = sX[it & 1][(tau * 5u + 3u) & 1023u], g2 = sX[it & 1][(tau * 9u + 1u) & 1023u];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)row);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)row >> 32));
+        const u64 addr = ((u64)hi << 32) | lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // emission-like: 8 fma + 11 add/mul
+            float d = x - mu[i];
+            float q = d * sg[i];
+            float e = __builtin_fmaf(-q, sg[i], d);
+            q = __builtin_fmaf(e, sg[i], q);
+            float t = q * q + 1.8378f;
+            float d2 = x - sg[i];
+            float q2 = d2 * mu[i];
+            float e2 = __builtin_fmaf(-q2, mu[i], d2);
+            q2 = __builtin_fmaf(e2, sg[i], q2);
+            float l = mu[i] * q2; l = l * q2;
+            float q3 = l * x;
+            float e3 = __builtin_fmaf(-q3, x, l);
+            q3 = __builtin_fmaf(e3, x, q3);
+            float u = sg[i] - x; u = u - q3;
+            float n = __builtin_fmaf(-0.5f, t, mu[i]);
+            float em = __builtin_fmaf(0.5f, u, n);
+            // combine-like: add, max3, 3 compares, SELS selects (+ lshl_or when selecting), add
+            const float s0 = a[i] + sg[i];
+            float best;
+            asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(s0), "v"(g1), "v"(g2));
+            if (STORES > 0 || SALU > 0) {
+                // masks straight into a fixed SGPR quad + pair; tie logic on the scalar unit
+                asm volatile(
+                    "v_cmp_eq_f32_e64 s[20:21], %1, %4\n\t"
+                    "v_cmp_eq_f32_e64 s[22:23], %2, %4\n\t"
+                    "v_cmp_eq_f32_e64 s[24:25], %3, %4\n\t"
+                    "s_and_b64 s[26:27], s[20:21], s[22:23]\n\t"
+                    "s_or_b64 s[28:29], s[20:21], s[22:23]\n\t"
+                    "s_and_b64 s[28:29], s[28:29], s[24:25]\n\t"
+                    "s_or_b64 s[26:27], s[26:27], s[28:29]\n\t"
+                    "s_or_b64 %0, %0, s[26:27]\n\t"
+                    : "+s"(acc) : "v"(s0), "v"(g1), "v"(g2), "v"(best)
+                    : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
+                if (STORES >= 8 || (STORES == 4 && (i & 1))) {
+                    if (X2) {
+                        asm volatile("s_store_dwordx2 s[20:21], %0, %1\n\ts_store_dwordx2 s[22:23], %0, %2" :: "s"(addr), "n"(i * 16), "n"(i * 16 + 8) : "memory");
+                    } else {
+                        asm volatile("s_store_dwordx4 s[20:23], %0, %1" :: "s"(addr), "n"(i * 16) : "memory");
+                    }
+                }
+                if (STORES >= 12 && i < 4) {
+                    asm volatile("s_store_dwordx4 s[24:27], %0, %1" :: "s"(addr), "n"(128 + i * 16) : "memory");
+                }
+#pragma unroll
+                for (int k = 0; k < SALU; ++k)
+                    asm volatile("s_andn2_b64 s[28:29], s[28:29], s[24:25]\n\ts_or_b64 %0, %0, s[28:29]" : "+s"(acc) :: "s28", "s29");
+            } else {
+                u64 e0, e1, e2;
+                asm volatile("v_cmp_eq_f32_e64 %0, %1, %2" : "=s"(e0) : "v"(s0), "v"(best));
+                asm volatile("v_cmp_eq_f32_e64 %0, %1, %2" : "=s"(e1) : "v"(g1), "v"(best));
+                asm volatile("v_cmp_eq_f32_e64 %0, %1, %2" : "=s"(e2) : "v"(g2), "v"(best));
+                acc |= (e0 & e1) | ((e0 | e1) & e2);
+                if (SELS == 2) {
+                    unsigned slot;
+                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(slot) : "v"(tau), "v"(bp), "s"(e1));
+                    asm volatile("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(slot) : "v"(slot), "s"(e0));
+                    asm volatile("v_lshl_or_b32 %0, %1, 8, %0" : "+v"(bp) : "v"(slot));
+                }
+            }
+            a[i] = best + em;
+        }
+        x += 0.25f;
+        if (STORES > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // what the next iteration's LDS wait amounts to
+    }
+    if (STORES > 0) asm volatile("s_dcache_wb" ::: "memory");
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 512 + tau] = s + (float)bp + (float)(acc & 1);
+}
+
+// ---------------------------------------------------------------- C: VALU op rates at 16 waves per CU
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
+{
+    float a[8], b = 1.0001f, c = 0.5f;
+    for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 0.001f + i;
+    u64 msk = 0x5555555555555555ull ^ (u64)iters;
+    unsigned sv = (unsigned)iters;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (MODE == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 2) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 3) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(msk));
+                if (MODE == 4) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 5) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 6) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 7) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[i]));
+                if (MODE == 8) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a[i]));
+                if (MODE == 9) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 10) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 11) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 12) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 13) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 14) asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(a[i]) : "s"(sv));
+                if (MODE == 15) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "s"(sv));
+                if (MODE == 16) asm volatile("v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+                if (MODE == 17) asm volatile("v_cmp_eq_u32_e64 %1, %0, %2" : : "v"(a[i]), "s"(msk), "v"(b));
+                if (MODE == 18) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 19) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 20) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 21) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 22) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 23) asm volatile("v_cmp_gt_f32_e64 %1, %0, %2" : : "v"(a[i]), "s"(msk), "v"(b));
+                if (MODE == 24) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 25) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 26) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+                if (MODE == 27) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 28) asm volatile("v_cmp_class_f32_e64 %1, %0, %2" : : "v"(a[i]), "s"(msk), "v"(b));
+                if (MODE == 29) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (MODE == 30) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 31) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sv) : "v"(a[i]));
+            }
+        }
+    }
+    float s = (float)sv;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <typename F> static float time_ms(F launch)
+{
+    launch(); CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    return best;
+}
+
+template <int MODE> static void run_rate(const char* name, float* d)
+{
+    const int iters = 20000, grid = 512;
+    const float ms = time_ms([&] { hipLaunchKernelGGL(rate<MODE>, dim3(grid), dim3(512), 0, 0, d, iters); });
+    // 512 blocks x 8 waves over 1024 SIMDs = 4 waves per SIMD, each 32 * iters instructions
+    printf("rate  %-22s %8.3f ms  -> %.3f ns per wave-instruction per SIMD (4 waves/SIMD)\n", name, ms, ms * 1e6 / (4.0 * 32.0 * iters));
+}
+
+template <int STORES, int SELS, int SALU, bool X2> static double run_shape(const char* name, float* d, u64* planes)
+{
+    const int iters = 4000, grid = 512;
+    const float ms = time_ms([&] { hipLaunchKernelGGL((vit_shape<STORES, SELS, SALU, X2>), dim3(grid), dim3(512), 0, 0, d, planes, iters); });
+    const double ns = ms * 1e6 / iters;      // per block-iteration pair (two blocks per CU run concurrently)
+    printf("shape %-52s %8.3f ms  -> %.1f ns per event per block-pair\n", name, ms, ns);
+    return ns;
+}
+
+int main()
+{
+    float* d; CHECK(hipMalloc(&d, 64 << 20));
+    u64* planes; CHECK(hipMalloc(&planes, 64 << 20));
+    CHECK(hipMemset(planes, 0xAB, 64 << 20));
+    // ---- A
+    {
+        const int iters = 1000, grid = 512;
+        hipLaunchKernelGGL(sstore_semantics, dim3(grid), dim3(64), 0, 0, planes, iters);
+        CHECK(hipDeviceSynchronize());
+        std::vector<u64> h((size_t)grid * iters * 2);
+        CHECK(hipMemcpy(h.data(), planes, h.size() * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (int b = 0; b < grid; ++b)
+            for (int it = 0; it < iters; ++it) {
+                u64 m0 = 0, m1 = 0;
+                for (unsigned lane = 0; lane < 64; ++lane) {
+                    if ((float)((lane * 7u + (unsigned)it * 13u + b) & 63u) > 31.5f) m0 |= 1ull << lane;
+                    if ((float)((lane * 11u + (unsigned)it * 5u + 3u * b) & 63u) > 31.5f) m1 |= 1ull << lane;
+                }
+                const u64* p = &h[((size_t)b * iters + it) * 2];
+                if (p[0] != m0 || p[1] != m1) { if (bad < 5) printf("  mismatch block %d it %d: %016llx %016llx vs %016llx %016llx\n", b, it, p[0], p[1], m0, m1); ++bad; }
+            }
+        printf("A  s_store_dwordx4 of v_cmp masks, data SGPRs overwritten right after issue: %zu mismatches of %d stores\n", bad, grid * iters);
+    }
+    // ---- B
+    const double base = run_shape<0, 2, 0, false>("selects + lshl_or (today's shape), no scalar stores", d, planes);
+    const double nosel = run_shape<0, 0, 0, false>("no selects, no stores (the VALU floor of the plane form)", d, planes);
+    const double salu0 = run_shape<0, 0, 1, false>("masks in fixed SGPRs + tie logic on SALU, no stores", d, planes);
+    const double st4 = run_shape<4, 0, 0, false>("4 s_store_dwordx4 per wave-event", d, planes);
+    const double st8 = run_shape<8, 0, 0, false>("8 s_store_dwordx4 per wave-event", d, planes);
+    const double st12 = run_shape<12, 0, 0, false>("12 s_store_dwordx4 per wave-event", d, planes);
+    const double st16x2 = run_shape<8, 0, 0, true>("16 s_store_dwordx2 per wave-event", d, planes);
+    const double salu4 = run_shape<12, 0, 4, false>("12 stores + 64 extra SALU ops per wave-event", d, planes);
+    printf("B  relative to today's shape: no-select %.3f, SALU-masks %.3f, 4 stores %.3f, 8 stores %.3f, 12 stores %.3f, 16 x2 %.3f, 12 + SALU %.3f\n",
+           nosel / base, salu0 / base, st4 / base, st8 / base, st12 / base, st16x2 / base, salu4 / base);
+    // ---- C
+    run_rate<0>("v_add_f32", d); run_rate<21>("v_sub_f32", d); run_rate<22>("v_mul_f32", d); run_rate<1>("v_fma_f32", d);
+    run_rate<2>("v_max_f32", d); run_rate<24>("v_max3_f32", d); run_rate<13>("v_med3_f32", d);
+    run_rate<3>("v_cndmask_b32_e64", d); run_rate<23>("v_cmp_gt_f32 -> sgpr", d); run_rate<17>("v_cmp_eq_u32 -> sgpr", d);
+    run_rate<28>("v_cmp_class_f32 -> sgpr", d);
+    run_rate<27>("v_and_b32", d); run_rate<4>("v_or_b32", d); run_rate<5>("v_xor_b32", d); run_rate<30>("v_add_u32", d); run_rate<6>("v_sub_u32", d);
+    run_rate<7>("v_lshlrev_b32", d); run_rate<8>("v_ashrrev_i32", d); run_rate<25>("v_lshl_or_b32", d); run_rate<18>("v_lshl_add_u32", d);
+    run_rate<19>("v_add3_u32", d); run_rate<20>("v_mad_u32_u24", d); run_rate<9>("v_perm_b32", d); run_rate<10>("v_bfi_b32", d);
+    run_rate<11>("v_and_or_b32", d); run_rate<12>("v_min_u32", d); run_rate<29>("v_min3_u32", d);
+    run_rate<26>("v_mov_b32_dpp", d); run_rate<16>("v_max_f32_dpp", d);
+    run_rate<15>("v_mov_b32 from sgpr", d); run_rate<14>("v_writelane_b32", d); run_rate<31>("v_readlane_b32", d);
+    return 0;
+}
