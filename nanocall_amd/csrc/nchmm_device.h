@@ -15,17 +15,14 @@ constexpr int kTransFloats = kStates + 1024 + 256;      // w0[4096] | w1[1024] |
 constexpr int kMaxSlots = 64;
 constexpr unsigned kNoState = 0xFFFFu;
 
-// Back-pointer row of one event (decisions column i-1 -> column i), 1536 bytes:
-//   [0, 1024)     class planes.  Thread tau = 2t + h of wave w = tau >> 6 owns cell c = (x << 1) | (y >> 1) of the states
-//                 j = t + 256 (4x + y), y & 1 == h.  The forward sweep's compares leave one 64-bit lane mask per (wave, cell)
-//                 and candidate; two of them ARE the back-pointer class of 64 cells at once: P0 = "stay wins", P1 = "step
-//                 wins" (neither = skip, both = no predecessor at all).  They go to memory as they are, with one scalar
-//                 store per cell: 16 bytes {P0, P1} at  w * 128 + ((y >> 1) << 2 | x) * 16,  bit (tau & 63).
-//   [1024, 1536)  group winners, one byte per thread tau at 1024 + tau:  bits 0-1 / 2-3 the winning member x of the two
-//                 step groups this thread scans (predecessors (x << 10) | r with r = (y << 8) | t, y = h / h + 2),
-//                 bits 4-7 the winning member 4x + y of skip group t (predecessors ((4x + y) << 8) | t).
-constexpr unsigned kBpRowBytes = 1536;
-constexpr unsigned kBpGroupOff = 1024;
+// Back-pointer row of one event: one byte per state (viterbi_kernel.hip).  The bit-plane experiment of round 3
+// (tools/ubench/viterbi_bitplane_kernel.hip.txt) builds with -DNCHMM_BP_ROW_BYTES=1536.
+#ifdef NCHMM_BP_ROW_BYTES
+constexpr unsigned kBpRowBytes = NCHMM_BP_ROW_BYTES;
+#else
+constexpr unsigned kBpRowBytes = kStates;
+#endif
+constexpr unsigned kBpGroupOff = 1024;   // (bit-plane experiment only)
 
 // device image of a pore model: field-major so thread t reads field f of state t+256k at [f][t+256k]
 enum ModelField {

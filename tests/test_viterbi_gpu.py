@@ -188,7 +188,7 @@ def test_out_of_range_model_takes_true_division_path(gpu_ctx, r73t):
 def test_workspace_split_into_sub_batches(r73t):
     """With a tiny workspace budget a call is cut into several forward+traceback launches."""
     import os
-    os.environ["NCHMM_WS_BUDGET_MB"] = "16"       # 10 922 events of 1.5 KiB per launch (read at the first Viterbi call)
+    os.environ["NCHMM_WS_BUDGET_MB"] = "16"       # 4 096 events per launch, or one read if longer (read at the first Viterbi call)
     lens = [9000, 5000, 7000, 3, 12000, 800]
     off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=40)
     try:
