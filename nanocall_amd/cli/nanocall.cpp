@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <cmath>
 #include <deque>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <list>
@@ -457,10 +458,25 @@ template <typename F> static void host_parallel(size_t n, unsigned nt, F&& f)
 {
     nt = std::max(1u, std::min<unsigned>(nt, (unsigned)std::max<size_t>(n, 1)));
     if (nt == 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    // An exception leaving a std::thread body is std::terminate (a core dump with the GPUs held): keep the first one,
+    // let the other workers run dry, rethrow on the caller's thread -- where main() turns it into LOG(error) + EXIT_FAILURE
+    // as the reference does (nanocall.cpp: `LOG(error) << ...; exit(EXIT_FAILURE)`).
     std::atomic<size_t> next{0};
+    std::exception_ptr first;
+    std::mutex first_mutex;
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&] { for (size_t i; (i = next++) < n;) f(i); });
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            try {
+                for (size_t i; (i = next++) < n;) f(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(first_mutex);
+                if (!first) first = std::current_exception();
+                next = n;      // nothing more to hand out
+            }
+        });
     for (auto& t : th) t.join();
+    if (first) std::rethrow_exception(first);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -941,7 +957,20 @@ static int real_main()
     // the summary pass (init_reads) runs on its own threads; the decode loop follows it block by block
     reads.resize(files.size());
     Read_Progress progress;
-    std::thread summary_pass([&] { STAGE("init_reads_s"); init_reads(models, files, reads, progress, readers); });
+    // (an exception must not leave the thread body -- std::terminate with the GPUs held -- and the decode loop must not wait
+    // forever for summaries that will never come: keep it, declare the pass finished with what is ready, rethrow after the join)
+    std::exception_ptr summary_error;
+    std::thread summary_pass([&] {
+        try {
+            STAGE("init_reads_s");
+            init_reads(models, files, reads, progress, readers);
+        } catch (...) {
+            summary_error = std::current_exception();
+            size_t ready;
+            { std::lock_guard<std::mutex> g(progress.m); ready = progress.ready; }
+            progress.publish(ready, true);
+        }
+    });
     try {
         if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters, progress); }
     } catch (...) {
@@ -949,6 +978,7 @@ static int real_main()
         throw;
     }
     summary_pass.join();
+    if (summary_error) std::rethrow_exception(summary_error);
     os_p->flush();
     uint64_t dev[8];
     int used_rccl = 0;

@@ -27,7 +27,16 @@ constexpr unsigned kAccRdOnly = 0x0000u;
     X(H5Aexists) X(H5Aopen) X(H5Aread) X(H5Aget_type) X(H5Aclose) X(H5Tget_class) X(H5Tis_variable_str) X(H5Tget_size)  \
     X(H5Tcopy) X(H5Tset_size) X(H5Tclose) X(H5Dopen2) X(H5Dget_space) X(H5Sget_simple_extent_npoints) X(H5Dget_type)    \
     X(H5Tget_member_index) X(H5Tcreate) X(H5Tinsert) X(H5Dread) X(H5Dclose) X(H5Sclose) X(H5free_memory)                \
-    X(H5Tset_cset) X(H5Tset_strpad)
+    X(H5Tset_cset) X(H5Tset_strpad) X(H5get_libversion)
+
+// The struct layouts, the width of hid_t and the H5Literate callback signature are those of the HEADERS this file was
+// compiled against; the library is whatever dlopen finds at run time, and H5check() -- the guard the headers normally
+// plant -- is bypassed on purpose (no link-time reference).  With 1.12+ headers `H5Literate` is a macro for H5Literate2
+// (another callback type): the X-macro above would then declare a member of the new type and look the OLD symbol up by
+// its spelled-out name.  So: refuse such headers at compile time, and refuse a library of another major.minor at run time.
+#if H5_VERS_MAJOR != 1 || H5_VERS_MINOR > 10
+#error "nchmm_fast5.cpp is written against the HDF5 1.8 / 1.10 API (H5Literate with H5L_info_t); build with those headers or extend H5_FUNCS to the versioned symbols"
+#endif
 
 struct Hdf5 {
     void* handle = nullptr;
@@ -55,6 +64,12 @@ struct Hdf5 {
     if (!f) { why = std::string("libhdf5 lacks ") + #f; return; }
         H5_FUNCS(X)
 #undef X
+        unsigned maj = 0, min = 0, rel = 0;
+        if (H5get_libversion(&maj, &min, &rel) < 0 || maj != (unsigned)H5_VERS_MAJOR || min != (unsigned)H5_VERS_MINOR) {
+            why = "libhdf5 " + std::to_string(maj) + "." + std::to_string(min) + "." + std::to_string(rel) + " found at run time, but this library was compiled against the " +
+                  std::to_string(H5_VERS_MAJOR) + "." + std::to_string(H5_VERS_MINOR) + " headers (set NCHMM_HDF5_LIB to a matching libhdf5)";
+            return;
+        }
         if (H5open() < 0) { why = "H5open failed"; return; }
         auto glob = [&](const char* name) -> hid_t {
             void* p = dlsym(handle, name);
