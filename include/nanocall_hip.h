@@ -450,7 +450,11 @@ int nchmm_pool_basecall_reads(nchmm_pool* pool, const nchmm_train_opts* opts, si
 /* nchmm_counters summed over the pool's contexts.  With two or more DISTINCT devices the sum is one RCCL all-reduce
  * (ncclCommInitAll over the pool's devices, single process; librccl is loaded at run time) and *used_rccl = 1;
  * otherwise (one device, repeated ids, librccl missing) it is a host sum and *used_rccl = 0.  NCHMM_POOL_FORCE_RCCL=1
- * takes the RCCL path even for a single device.  used_rccl may be NULL. */
+ * takes the RCCL path even for a single device.  used_rccl may be NULL.
+ * Threading: a pool keeps one host thread per device for its whole life and runs ONE batched call at a time (concurrent
+ * callers queue).  RCCL prints a banner on stdout when its communicators are created; for that moment this call points
+ * the process's fd 1 at stderr (a host may be streaming FASTA on stdout) -- so do not write to stdout from another
+ * thread while nchmm_pool_counters runs (the command line calls it once, after its last record is flushed). */
 int nchmm_pool_counters(nchmm_pool* pool, uint64_t out[8], int* used_rccl);
 
 #ifdef __cplusplus

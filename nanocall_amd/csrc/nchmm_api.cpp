@@ -34,7 +34,8 @@ struct nchmm_ctx {
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
     bool profile = false;
-    int tb_margin = 256;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path)
+    int tb_margin = 128;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path); profiles/r03_tb_margin.txt:
+                                    // 0 of 86 016 speculative segments un-merged at 64, 384 at 32 -- and a miss only costs a re-walk
     uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace (4 KiB per event of a batch)
     size_t ws_bytes = 0;
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)

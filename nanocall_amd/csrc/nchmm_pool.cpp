@@ -11,6 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <limits>
 #include <numeric>
@@ -18,9 +22,56 @@
 #include <thread>
 #include <vector>
 
+// One host thread per device, alive as long as the pool: the batched entry points keep "only grows" host staging with
+// their calling thread (thread_local), so a thread spawned per call would allocate and page-fault it again for every chunk
+// of a run -- the cost that buffer exists to avoid.  run_per_device hands each worker its closure and waits for all.
+struct Device_Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> task;     // set by the caller, cleared by the worker
+    int rc = 0;
+    bool has_task = false, done = false, quit = false;
+
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || quit; });
+            if (quit) return;
+            std::function<int()> f = std::move(task);
+            lk.unlock();
+            int r;
+            try { r = f(); } catch (...) { r = NCHMM_E_NOMEM; }     // std::bad_alloc is what can come out of the staging code
+            lk.lock();
+            rc = r; has_task = false; done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> f)
+    {
+        { std::lock_guard<std::mutex> g(m); task = std::move(f); has_task = true; done = false; }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> g(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct nchmm_pool {
     std::vector<int> device;
     std::vector<nchmm_ctx*> ctx;
+    std::vector<std::unique_ptr<Device_Worker>> worker;     // one per context when there are two or more
+    std::mutex call_mutex;                                  // one batched call at a time per pool
 };
 
 namespace {
@@ -169,9 +220,11 @@ int run_per_device(nchmm_pool* pool, F&& f)
     const size_t n = pool->ctx.size();
     std::vector<int> rc(n, NCHMM_OK);
     if (n == 1) return f(0);
-    std::vector<std::thread> th;
-    for (size_t d = 0; d < n; ++d) th.emplace_back([&, d] { rc[d] = f(d); });
-    for (auto& t : th) t.join();
+    {
+        std::lock_guard<std::mutex> one_call(pool->call_mutex);
+        for (size_t d = 0; d < n; ++d) pool->worker[d]->post([&f, d] { return f(d); });
+        for (size_t d = 0; d < n; ++d) rc[d] = pool->worker[d]->wait();
+    }
     int worst = NCHMM_OK;
     for (int v : rc)
         if (v != NCHMM_OK && (worst == NCHMM_OK || worst == NCHMM_E_NUMERIC)) worst = v;
@@ -248,6 +301,12 @@ int nchmm_pool_create(nchmm_pool** out, int n_devices, const int* device_ids)
         p->device.push_back(id);
         p->ctx.push_back(c);
     }
+    if (p->ctx.size() > 1)
+        for (size_t d = 0; d < p->ctx.size(); ++d) {
+            p->worker.emplace_back(new Device_Worker());
+            Device_Worker* w = p->worker.back().get();
+            w->th = std::thread([w] { w->loop(); });
+        }
     *out = p;
     return NCHMM_OK;
 }
@@ -255,6 +314,7 @@ int nchmm_pool_create(nchmm_pool** out, int n_devices, const int* device_ids)
 int nchmm_pool_destroy(nchmm_pool* p)
 {
     if (!p) return NCHMM_E_INVALID;
+    for (auto& w : p->worker) w->stop();
     for (nchmm_ctx* c : p->ctx) nchmm_destroy(c);
     delete p;
     return NCHMM_OK;

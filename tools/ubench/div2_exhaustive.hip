@@ -1,0 +1,111 @@
+// div2_exhaustive.hip -- for which binary32 divisors is the TWO-operation division by a known divisor exact?
+//
+//     q = fma(n, zh, RN(n * zl)),   zh = RN(1 / d),   zl = RN(1 / d - zh)        (Brisebarre, Muller, Raina 2004)
+//
+// For most divisors it returns RN(n / d) for every numerator; for about 1.4 % of the divisor significands exactly one
+// numerator significand comes out one ulp off.  This tool settles it by enumeration on the GPU, all 2^23 divisor
+// significands x all 2^23 numerator significands (exponents and signs do not enter while nothing leaves the normal range):
+//   pass 1  per divisor, the number of numerators on which the formula differs from the 3-operation Markstein quotient
+//           (itself proven equal to IEEE division on all 2^46 pairs: profiles/r01_markstein_exhaustive.txt);
+//   pass 2  for every divisor that fails, the same count with zl moved by -1, +1, -2, +2, -3, +3 ulps: the first variant
+//           with NO failing numerator is that divisor's zl.
+// Output: div2_table.bin -- sorted uint32 entries (significand << 3) | code for the divisors whose plain zl does not work,
+// code 1..6 = the variant above that does, 7 = none does (such a divisor keeps the 3-operation division).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off div2_exhaustive.hip -o div2_exhaustive ; ./div2_exhaustive [out.bin]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#pragma clang fp contract(off)
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ float sig(uint32_t m) { return __builtin_bit_cast(float, (127u << 23) | m); }
+__device__ __forceinline__ float ulps(float v, int k) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) + (uint32_t)k); }   // moves |v| by k ulps
+
+__device__ __forceinline__ uint32_t count_fails(float d, float zh, float zl)
+{
+    uint32_t f = 0;
+    for (uint32_t nm = 0; nm < (1u << 23); ++nm) {
+        const float n = sig(nm);
+        const float q2 = __builtin_fmaf(n, zh, n * zl);
+        const float q0 = n * zh;
+        const float q3 = __builtin_fmaf(__builtin_fmaf(-q0, d, n), zh, q0);
+        f += (__builtin_bit_cast(uint32_t, q2) != __builtin_bit_cast(uint32_t, q3));
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void pass1(uint32_t first, uint8_t* fails)
+{
+    const uint32_t m = first + blockIdx.x * 256u + threadIdx.x;
+    const float d = sig(m);
+    const float zh = 1.0f / d;
+    const float zl = __builtin_fmaf(-zh, d, 1.0f) / d;
+    const uint32_t f = count_fails(d, zh, zl);
+    fails[m] = (uint8_t)(f > 255u ? 255u : f);
+}
+
+__global__ __launch_bounds__(64) void pass2(const uint32_t* bad, uint32_t n_bad, uint8_t* code)
+{
+    // one wave per divisor: lane v < 6 tries variant v
+    const uint32_t i = blockIdx.x;
+    if (i >= n_bad) return;
+    const int ks[6] = {-1, 1, -2, 2, -3, 3};
+    const uint32_t v = threadIdx.x;
+    uint32_t f = 1;
+    if (v < 6) {
+        const float d = sig(bad[i]);
+        const float zh = 1.0f / d;
+        float zl = __builtin_fmaf(-zh, d, 1.0f) / d;
+        // zl may be of either sign: "k ulps" moves its magnitude; do it on the value line instead
+        const int k = ks[v];
+        zl = zl >= 0.0f ? ulps(zl, k) : ulps(zl, -k);
+        f = count_fails(d, zh, zl);
+    }
+    const unsigned long long ok = __builtin_amdgcn_ballot_w64(f == 0);
+    if (v == 0) code[i] = ok ? (uint8_t)(__builtin_ctzll(ok) + 1) : 7;
+}
+
+int main(int argc, char** argv)
+{
+    const char* out = argc > 1 ? argv[1] : "div2_table.bin";
+    uint8_t* d_fails;
+    CHECK(hipMalloc(&d_fails, 1u << 23));
+    const uint32_t per_launch = 1u << 17;
+    for (uint32_t first = 0; first < (1u << 23); first += per_launch) {
+        hipLaunchKernelGGL(pass1, dim3(per_launch / 256), dim3(256), 0, 0, first, d_fails);
+        CHECK(hipDeviceSynchronize());
+    }
+    std::vector<uint8_t> fails(1u << 23);
+    CHECK(hipMemcpy(fails.data(), d_fails, fails.size(), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> bad;
+    unsigned long long total = 0, hist[4] = {0, 0, 0, 0};
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+        if (fails[m]) { bad.push_back(m); total += fails[m]; }
+        ++hist[fails[m] > 2 ? 3 : fails[m]];
+    }
+    printf("pass 1: %zu of 8388608 divisor significands fail (%.4f %%), %llu failing pairs; per divisor 0: %llu, 1: %llu, 2: %llu, >2: %llu\n", bad.size(),
+           100.0 * bad.size() / 8388608.0, total, hist[0], hist[1], hist[2], hist[3]);
+    uint32_t* d_bad; uint8_t* d_code;
+    CHECK(hipMalloc(&d_bad, bad.size() * 4 + 4)); CHECK(hipMalloc(&d_code, bad.size() + 1));
+    CHECK(hipMemcpy(d_bad, bad.data(), bad.size() * 4, hipMemcpyHostToDevice));
+    for (size_t first = 0; first < bad.size(); first += 16384) {
+        const uint32_t n = (uint32_t)std::min<size_t>(16384, bad.size() - first);
+        hipLaunchKernelGGL(pass2, dim3(n), dim3(64), 0, 0, d_bad + first, n, d_code + first);
+        CHECK(hipDeviceSynchronize());
+    }
+    std::vector<uint8_t> code(bad.size());
+    CHECK(hipMemcpy(code.data(), d_code, code.size(), hipMemcpyDeviceToHost));
+    unsigned long long by_code[8] = {0};
+    std::vector<uint32_t> table(bad.size());
+    for (size_t i = 0; i < bad.size(); ++i) { ++by_code[code[i] & 7]; table[i] = (bad[i] << 3) | (code[i] & 7u); }
+    printf("pass 2: zl -1 ulp fixes %llu, +1: %llu, -2: %llu, +2: %llu, -3: %llu, +3: %llu, none of them: %llu\n", by_code[1], by_code[2], by_code[3], by_code[4],
+           by_code[5], by_code[6], by_code[7]);
+    FILE* f = fopen(out, "wb");
+    if (!f || fwrite(table.data(), 4, table.size(), f) != table.size()) { printf("cannot write %s\n", out); return 1; }
+    fclose(f);
+    printf("wrote %s: %zu entries (significand << 3 | code), sorted\n", out, table.size());
+    return 0;
+}
