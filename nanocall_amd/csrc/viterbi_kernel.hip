@@ -20,10 +20,16 @@
 //     unless a smaller alpha rounds to the same sum, which is ruled out per group by probing the
 //     next float below the maximum -- otherwise the wave takes the exact sum-by-sum scan.  Ties
 //     resolve to the lowest predecessor index as the reference's ascending strict-> scan does.
-//   * Divisions: divisors are per-state constants (sigma, eta) or per-event constants (stdv): the
-//     quotient comes from a correctly rounded reciprocal + two FMA residual corrections
-//     (Markstein), bit-identical to IEEE division inside the validated operand range (checked per
-//     model on upload, per 512-event chunk here), true division otherwise.
+//   * Divisions: divisors are per-state constants (sigma, eta) or per-event constants (stdv).  By stdv: a
+//     correctly rounded reciprocal, one exact residual, one correction (Markstein: 3 ops).  By sigma and
+//     eta: TWO ops, q = fma(n, zh, RN(n zl)) with zh ~ RN(1/d), zl = RN(1/d - zh) (Brisebarre, Muller,
+//     Raina 2004).  The plain pair is exact for every numerator for 98.73 % of the binary32 divisor
+//     significands, one of 24 neighbouring pairs for all but 1547 of the rest: settled by enumeration of
+//     all 2^46 significand pairs on the GPU (tools/ubench/div2_exhaustive.hip), shipped as one byte per
+//     significand, looked up once per read and state.  A wave with one of the 1547 among its 1024
+//     divisors (17 % of the waves) keeps the 3-op form.  All of it bit-identical to IEEE division inside
+//     the validated operand range (checked per model on upload, per 256-event chunk here), true division
+//     otherwise.
 //   * Selects are written as v_cndmask_b32_e64 with an SGPR-pair mask: on gfx950 the VOP2 form
 //     reading a VCC that was not written by the immediately preceding VALU op issues ~8x slower
 //     (tools/ubench/valu_rate.hip).
@@ -104,10 +110,12 @@ __device__ __forceinline__ unsigned bp_pos(unsigned k) { return ((k & 1u) << 3) 
 // tools/ubench/markstein_exhaustive.c, profiles/r01_markstein_exhaustive.txt.
 // Exponents do not enter as long as nothing leaves the normal range: needs n == 0 or 2^-100 <= |n| <= 2^100
 // and d, r normal (the range validation below; outside it the true division is used).
-template <bool FAST>
+// DIV: 0 = IEEE division, 3 = the three-operation form below for every divisor, 2 = the two-operation form (quot2) for the
+// per-state divisors and the three-operation form for the per-event one
+template <int DIV>
 __device__ __forceinline__ float quot(float n, float d, float r)
 {
-    if constexpr (FAST) {
+    if constexpr (DIV != 0) {
         const float q = n * r;
         const float e = __builtin_fmaf(-q, d, n);
         return __builtin_fmaf(e, r, q);
@@ -116,21 +124,43 @@ __device__ __forceinline__ float quot(float n, float d, float r)
     }
 }
 
+// n / d in two operations with a pair (zh, zl) the enumeration vouches for (file comment): zh + zl is 1 / d to 2^-49, the
+// product n zl is rounded once (2^-49 of the quotient), the FMA rounds the sum once -- to RN(n / d) unless the quotient lies
+// within those 2^-48 of a rounding boundary, which is what the enumeration rules out numerator by numerator.
+__device__ __forceinline__ float quot2(float n, float zh, float zl)
+{
+    return __builtin_fmaf(n, zh, n * zl);
+}
+
+// The pair of variant v for divisor d, EXACTLY as tools/ubench/div2_exhaustive.hip builds it (v = 0: the plain pair;
+// v = 1 .. 24: zh = RN(1/d) moved by dzh ulps, zl = RN(1/d - zh) moved by dzl ulps along the value line).
+__device__ __forceinline__ float ulps(float v, int k) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) + (unsigned)k); }
+__device__ __forceinline__ void div2_pair(float d, unsigned v, float& zh, float& zl)
+{
+    const int order[5] = {0, -1, 1, -2, 2};
+    const int dzh = order[v / 5u], dzl = order[v % 5u];
+    zh = ulps(1.0f / d, dzh);
+    zl = __builtin_fmaf(-zh, d, 1.0f) / d;      // 1 - zh d is exact for zh within a few ulps of 1 / d; one correctly rounded division
+    if (dzl != 0) zl = zl >= 0.0f ? ulps(zl, dzl) : ulps(zl, -dzl);
+}
+constexpr unsigned kDiv2None = 255;             // table byte: no pair divides by this significand in two operations
+
 // Pore_Model_State::log_pr_corrected_emission, Pore_Model.hpp:145-149 with log_normal_pdf :24-31
 // and log_invgauss_pdf :33-40, operation for operation:
 //   a = (x - mu) / sigma;            N  = -log_sigma - (log_2pi + a*a) / 2
 //   b = (y - eta) / eta;             IG = (log_lambda - log_2pi - 3*log_y - lambda*b*b / y) / 2
 // nls = -log_sigma (exact negation), c = log_lambda - log_2pi (first subtraction of the reference's
 // left-to-right expression), ly3 = 3.0f * log_y.
-template <bool FAST>
+// DIV == 2: rsg / reta are the zh of sigma's / eta's pair, sg carries zl(sigma) and zle zl(eta)
+template <int DIV>
 __device__ __forceinline__ float emission(float x, float y, float ry, float ly3, float log_2pi, float mu, float sg,
-                                          float rsg, float nls, float eta, float reta, float lam, float c)
+                                          float rsg, float nls, float eta, float reta, float lam, float c, float zle)
 {
-    const float a = quot<FAST>(x - mu, sg, rsg);
-    const float b = quot<FAST>(y - eta, eta, reta);
+    const float a = DIV == 2 ? quot2(x - mu, rsg, sg) : quot<DIV>(x - mu, sg, rsg);
+    const float b = DIV == 2 ? quot2(y - eta, reta, zle) : quot<DIV>(y - eta, eta, reta);
     const float t = log_2pi + a * a;
-    const float u = c - ly3 - quot<FAST>(lam * b * b, y, ry);
-    if constexpr (FAST) {
+    const float u = c - ly3 - quot<DIV>(lam * b * b, y, ry);
+    if constexpr (DIV != 0) {
         // Halving is exact: t >= log 2pi, and u / 2 is inexact only when |u| < 2^-125 (a subnormal quotient), where
         // the lost 2^-150 cannot move RN(n + u / 2) unless |n| is itself below 2^-100 -- two O(1) expressions
         // cancelling to that depth at once.  So the reference's  n = nls - t / 2,  ig = u / 2,  n + ig  are these two
@@ -147,6 +177,10 @@ __device__ __forceinline__ float emission(float x, float y, float ry, float ly3,
 struct State {
     // index i = (x<<1) | (y>>1), state j = t + 256*(4x + y), y = 2*(i&1) + h
     float mu[8], sg[8], rsg[8], eta[8], reta[8], lam[8], alpha[8];
+    // two-operation division (file comment), chosen per wave (div_mode, an SGPR): 2 = (rsg, sg) hold sigma's pair (zh, zl)
+    // and (reta, zle) eta's; 3 = sg holds sigma, rsg / reta the correctly rounded reciprocals, zle is unused
+    float zle[8];
+    unsigned div_mode;
     float w1[2];   // step groups r = (y<<8)|t for y = h, h+2
     float w2;      // skip group q = t
     // wave-uniform tallies (SGPRs) of the two exactness branches, reported through P.prof[6..7]:
@@ -172,7 +206,39 @@ __device__ __forceinline__ void merge_lower(float& av, unsigned& ai, float bv, u
     ai = selm(m, bi, ai);
 }
 
-template <bool FAST>
+// Division mode of the wave for this chunk of events (set_division_mode): sigma, or sigma's and eta's pairs, in the registers
+__device__ __forceinline__ void set_division_mode(State& S, const float* __restrict__ M, const uint8_t* __restrict__ tab, unsigned t,
+                                                  unsigned h, bool two_op)
+{
+    unsigned cs[8], ce[8];
+    bool none = !two_op || tab == nullptr;
+    if (!none) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned j = t + 256u * (4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h);
+            cs[i] = tab[__builtin_bit_cast(unsigned, M[MF_SIGMA * kStates + j]) & 0x7FFFFFu];
+            ce[i] = tab[__builtin_bit_cast(unsigned, S.eta[i]) & 0x7FFFFFu];
+            none = none || cs[i] == kDiv2None || ce[i] == kDiv2None;
+        }
+    }
+    const bool three = ballot(none) != 0;     // one lane without a pair: the wave keeps the three-operation form
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned j = t + 256u * (4u * (unsigned)(i >> 1) + 2u * (unsigned)(i & 1) + h);
+        if (three) {
+            S.sg[i] = M[MF_SIGMA * kStates + j];
+            S.rsg[i] = M[MF_RSIGMA * kStates + j];
+            S.reta[i] = M[MF_RETA * kStates + j];
+            S.zle[i] = 0.0f;
+        } else {
+            div2_pair(M[MF_SIGMA * kStates + j], cs[i], S.rsg[i], S.sg[i]);
+            div2_pair(S.eta[i], ce[i], S.reta[i], S.zle[i]);
+        }
+    }
+    S.div_mode = three ? 3u : 2u;
+}
+
+template <int DIV>
 __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], ValSlot* sV1, ValSlot* sV2,
                                        uint8_t* bp_row, unsigned tau, float x, float y, float ry, float ly3,
                                        float log_2pi)
@@ -293,8 +359,8 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
                 if (b.v > bb || (b.v == bb && p2 < bp)) { bb = b.v; bp = p2; sl = b.s; }
                 best = bb; slot = sl;
             }
-            const float e = emission<FAST>(x, y, ry, ly3, log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls_[u], S.eta[i],
-                                           S.reta[i], S.lam[i], cc_[u]);
+            const float e = emission<DIV>(x, y, ry, ly3, log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls_[u], S.eta[i],
+                                          S.reta[i], S.lam[i], cc_[u], S.zle[i]);
             S.alpha[i] = best + e;
             bpw[c] |= slot << (8 * u);
         }
@@ -395,6 +461,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         S.w1[1] = W[kStates + ((2u + h) << 8) + t];
         S.w2 = W[kStates + 1024 + t];
         S.n_rescan = 0; S.n_tie = 0;
+        set_division_mode(S, M, P.div2, t, h, model_fast);
 
         for (unsigned base = 0; base < n; base += kChunk) {
             {
@@ -414,6 +481,8 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 ok = event_in_fast_range(x, y);
             }
             const bool fast = __syncthreads_and(ok) && model_fast;
+            // a chunk that divides for real needs sigma itself back in the registers of the waves that hold its pair
+            if (!fast && S.div_mode == 2u) set_division_mode(S, M, P.div2, t, h, false);
             const unsigned hi = (n - base < kChunk) ? n - base : kChunk;
             unsigned lo = 0;
             if (base == 0) {
@@ -423,30 +492,42 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 for (int i = 0; i < 8; ++i) {
                     const unsigned o = tab_off(tau, (unsigned)i >> 2) + ((unsigned)i & 3u);
                     const float nls = sTab[0][o], cc = sTab[1][o];
-                    const float e = fast ? emission<true>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i],
-                                                          nls, S.eta[i], S.reta[i], S.lam[i], cc)
-                                         : emission<false>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i],
-                                                           nls, S.eta[i], S.reta[i], S.lam[i], cc);
+                    float e;
+                    if (!fast)
+                        e = emission<0>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls, S.eta[i], S.reta[i], S.lam[i], cc, S.zle[i]);
+                    else if (S.div_mode == 2u)
+                        e = emission<2>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls, S.eta[i], S.reta[i], S.lam[i], cc, S.zle[i]);
+                    else
+                        e = emission<3>(ev.x, ev.y, ev.w, ev.z, P.log_2pi, S.mu[i], S.sg[i], S.rsg[i], nls, S.eta[i], S.reta[i], S.lam[i], cc, S.zle[i]);
                     S.alpha[i] = e - P.log_n_states;
                 }
                 lo = 1;
             }
             // ---- columns (Viterbi.hpp:72-96) ----
-            if (fast) {
+            // (the waves of a block may sit in different loops here: each passes exactly one barrier per event)
+            if (!fast) {
                 for (unsigned c = lo; c < hi; ++c) {
                     const float4 ev = sEv[c];
                     const unsigned i = base + c;
-                    column<true>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
-                                 uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
+                    column<0>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
+                              uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
+                }
+            } else if (S.div_mode == 2u) {
+                for (unsigned c = lo; c < hi; ++c) {
+                    const float4 ev = sEv[c];
+                    const unsigned i = base + c;
+                    column<2>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
+                              uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
                 }
             } else {
                 for (unsigned c = lo; c < hi; ++c) {
                     const float4 ev = sEv[c];
                     const unsigned i = base + c;
-                    column<false>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
-                                  uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
+                    column<3>(S, sTab, sV1[i & 1u], sV2[i & 1u], ws + (uint64_t)i * kStates, tau, uniform(ev.x),
+                              uniform(ev.y), uniform(ev.w), uniform(ev.z), P.log_2pi);
                 }
             }
+            if (!fast && model_fast) set_division_mode(S, M, P.div2, t, h, true);    // back to the pairs (where the wave has them)
             __syncthreads();   // sEv is rewritten by the next chunk
         }
 

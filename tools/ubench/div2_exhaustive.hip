@@ -7,10 +7,11 @@
 // significands x all 2^23 numerator significands (exponents and signs do not enter while nothing leaves the normal range):
 //   pass 1  per divisor, the number of numerators on which the formula differs from the 3-operation Markstein quotient
 //           (itself proven equal to IEEE division on all 2^46 pairs: profiles/r01_markstein_exhaustive.txt);
-//   pass 2  for every divisor that fails, the same count with zl moved by -1, +1, -2, +2, -3, +3 ulps: the first variant
-//           with NO failing numerator is that divisor's zl.
-// Output: div2_table.bin -- sorted uint32 entries (significand << 3) | code for the divisors whose plain zl does not work,
-// code 1..6 = the variant above that does, 7 = none does (such a divisor keeps the 3-operation division).
+//   pass 2  for every divisor that fails, the same count with zl moved by -1, +1, -2, +2 ulps,
+//           then zh one or two floats below / above RN(1/d) with its own zl (0, -1, +1, -2, +2 ulps): the first variant with NO
+//           failing numerator is that divisor's pair.
+// Output: div2_table.bin -- sorted uint32 entries (significand << 8) | code for the divisors whose plain pair does not work,
+// code 1..24 = the variant (variant_pair below) that does, 255 = none does (such a divisor keeps the 3-operation division).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off div2_exhaustive.hip -o div2_exhaustive ; ./div2_exhaustive [out.bin]
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -19,6 +20,9 @@
 #include <vector>
 
 #pragma clang fp contract(off)
+#ifndef WIDE_VARIANTS
+#define WIDE_VARIANTS 0
+#endif
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 __device__ __forceinline__ float sig(uint32_t m) { return __builtin_bit_cast(float, (127u << 23) | m); }
@@ -47,25 +51,48 @@ __global__ __launch_bounds__(256) void pass1(uint32_t first, uint8_t* fails)
     fails[m] = (uint8_t)(f > 255u ? 255u : f);
 }
 
+// Variant v = 1 .. kVariants of the pair for divisor d (0 is the plain pair): zh = RN(1/d) moved by dzh ulps, zl = RN(1/d - zh)
+// moved by dzl ulps along the value line, (dzh, dzl) in the order below -- closest to the plain pair first.
+constexpr int kVariants = WIDE_VARIANTS ? 62 : 24;
+__device__ __forceinline__ void variant_offsets(unsigned v, int& dzh, int& dzl)
+{
+#if WIDE_VARIANTS
+    // exploration only: zh 0, -1, +1, ... -4, +4 (9) x zl 0, -1, +1, ... -3, +3 (7), minus the plain pair
+    const int zh_order[9] = {0, -1, 1, -2, 2, -3, 3, -4, 4};
+    const int zl_order[7] = {0, -1, 1, -2, 2, -3, 3};
+    dzh = zh_order[v / 7u];
+    dzl = zl_order[v % 7u];
+#else
+    // v = 1..4: zh as is, zl -1, +1, -2, +2; then zh -1, +1, -2, +2 each with zl 0, -1, +1, -2, +2
+    const int order[5] = {0, -1, 1, -2, 2};
+    dzh = order[v / 5u];
+    dzl = order[v % 5u];
+#endif
+}
+__device__ __forceinline__ void variant_pair(float d, unsigned v, float& zh, float& zl)
+{
+    int dzh = 0, dzl = 0;
+    if (v) variant_offsets(v, dzh, dzl);
+    zh = ulps(1.0f / d, dzh);                   // (1/d > 0: bit pattern order = value order)
+    zl = __builtin_fmaf(-zh, d, 1.0f) / d;      // the residual 1 - zh d is exact for zh within a few ulps of 1/d
+    if (dzl != 0) zl = zl >= 0.0f ? ulps(zl, dzl) : ulps(zl, -dzl);     // dzl ulps along the value line
+}
+
 __global__ __launch_bounds__(64) void pass2(const uint32_t* bad, uint32_t n_bad, uint8_t* code)
 {
-    // one wave per divisor: lane v < 6 tries variant v
+    // one wave per divisor: lane v - 1 tries variant v
     const uint32_t i = blockIdx.x;
     if (i >= n_bad) return;
-    const int ks[6] = {-1, 1, -2, 2, -3, 3};
-    const uint32_t v = threadIdx.x;
+    const uint32_t v = threadIdx.x + 1u;
     uint32_t f = 1;
-    if (v < 6) {
+    if (v <= (uint32_t)kVariants) {
         const float d = sig(bad[i]);
-        const float zh = 1.0f / d;
-        float zl = __builtin_fmaf(-zh, d, 1.0f) / d;
-        // zl may be of either sign: "k ulps" moves its magnitude; do it on the value line instead
-        const int k = ks[v];
-        zl = zl >= 0.0f ? ulps(zl, k) : ulps(zl, -k);
+        float zh, zl;
+        variant_pair(d, v, zh, zl);
         f = count_fails(d, zh, zl);
     }
     const unsigned long long ok = __builtin_amdgcn_ballot_w64(f == 0);
-    if (v == 0) code[i] = ok ? (uint8_t)(__builtin_ctzll(ok) + 1) : 7;
+    if (threadIdx.x == 0) code[i] = ok ? (uint8_t)(__builtin_ctzll(ok) + 1) : 255;
 }
 
 int main(int argc, char** argv)
@@ -98,14 +125,15 @@ int main(int argc, char** argv)
     }
     std::vector<uint8_t> code(bad.size());
     CHECK(hipMemcpy(code.data(), d_code, code.size(), hipMemcpyDeviceToHost));
-    unsigned long long by_code[8] = {0};
+    unsigned long long by_code[256] = {0};
     std::vector<uint32_t> table(bad.size());
-    for (size_t i = 0; i < bad.size(); ++i) { ++by_code[code[i] & 7]; table[i] = (bad[i] << 3) | (code[i] & 7u); }
-    printf("pass 2: zl -1 ulp fixes %llu, +1: %llu, -2: %llu, +2: %llu, -3: %llu, +3: %llu, none of them: %llu\n", by_code[1], by_code[2], by_code[3], by_code[4],
-           by_code[5], by_code[6], by_code[7]);
+    for (size_t i = 0; i < bad.size(); ++i) { ++by_code[code[i]]; table[i] = (bad[i] << 8) | code[i]; }
+    printf("pass 2: fixed by variant");
+    for (int c = 1; c <= kVariants; ++c) printf(" %d: %llu", c, by_code[c]);
+    printf("; by none: %llu\n", by_code[255]);
     FILE* f = fopen(out, "wb");
     if (!f || fwrite(table.data(), 4, table.size(), f) != table.size()) { printf("cannot write %s\n", out); return 1; }
     fclose(f);
-    printf("wrote %s: %zu entries (significand << 3 | code), sorted\n", out, table.size());
+    printf("wrote %s: %zu entries (significand << 8 | code), sorted\n", out, table.size());
     return 0;
 }
