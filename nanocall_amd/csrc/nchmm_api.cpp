@@ -32,7 +32,6 @@ struct nchmm_ctx {
     uint8_t* d_train_mask = nullptr; // [512] transition-training k-mers, one bit per state
     unsigned* d_queue = nullptr;    // [2] work-queue heads (viterbi, fwbw)
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
-    uint8_t* d_div2 = nullptr;       // [2^23] the two-operation division's variant per divisor significand (viterbi_kernel.hip)
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
     bool profile = false;
     int tb_margin = 128;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path); profiles/r03_tb_margin.txt:
@@ -370,16 +369,6 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         for (uint32_t i = 0; i < nk; ++i) mask[km[i] >> 3] |= (uint8_t)(1u << (km[i] & 7));
         if (hipMemcpy(c->d_train_mask, mask.data(), 512, hipMemcpyHostToDevice) != hipSuccess) return fail(NCHMM_E_HIP);
     }
-    {
-        // the two-operation division's table: 8 MiB, built once per process from the embedded list, uploaded per context
-        // (NCHMM_DIV2=0 leaves it out: every wave then keeps the three-operation division -- the A/B switch of tools/ubench)
-        const char* e = std::getenv("NCHMM_DIV2");
-        if (!(e && e[0] == '0') && div2_table_entries() > 0) {
-            static const std::vector<unsigned char> table = [] { std::vector<unsigned char> t((size_t)1 << 23); expand_div2_table(t.data()); return t; }();
-            if ((rc = dev_alloc(c, (void**)&c->d_div2, table.size()))) return fail(rc);
-            if (hipMemcpy(c->d_div2, table.data(), table.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(NCHMM_E_HIP);
-        }
-    }
     if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * (16 + 4096)))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 6200))) return fail(rc);
     if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 6200) != hipSuccess) return fail(NCHMM_E_HIP);
@@ -420,7 +409,6 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_train_mask) (void)hipFree(c->d_train_mask);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_model_fast) (void)hipFree(c->d_model_fast);
-    if (c->d_div2) (void)hipFree(c->d_div2);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_last_state) (void)hipFree(c->d_last_state);
@@ -605,7 +593,7 @@ int launch_batch(nchmm_ctx* c, size_t first, size_t count, uint64_t ev_base, uin
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
-    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast; a.div2 = c->d_div2;
+    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
     a.prof = c->profile ? c->d_prof : nullptr;
     a.ws = c->d_ws; a.ev_base = ev_base; a.first_read = (unsigned)first; a.last_state = c->d_last_state;
     a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;

@@ -7,8 +7,6 @@
 extern "C" {
 extern const unsigned char nchmm_builtin_blob[];
 extern const unsigned char nchmm_builtin_blob_end[];
-extern const unsigned char nchmm_div2_blob[];
-extern const unsigned char nchmm_div2_blob_end[];
 }
 
 #define NCHMM_STR2(x) #x
@@ -21,33 +19,6 @@ __asm__(".section .rodata\n"
         ".global nchmm_builtin_blob_end\n"
         "nchmm_builtin_blob_end:\n"
         ".previous\n");
-// The two-operation division's table (viterbi_kernel.hip): for every binary32 divisor significand whose plain (zh, zl) pair
-// fails on some numerator, which neighbouring pair works for all of them -- the result of enumerating all 2^46 significand
-// pairs on an MI355X (tools/ubench/div2_exhaustive.hip wrote nanocall_amd/data/div2_table.bin: sorted little-endian uint32,
-// significand << 8 | variant, 255 = none).
-__asm__(".section .rodata\n"
-        ".balign 64\n"
-        ".global nchmm_div2_blob\n"
-        "nchmm_div2_blob:\n"
-        ".incbin \"" NCHMM_STR(NCHMM_DIV2_BIN) "\"\n"
-        ".global nchmm_div2_blob_end\n"
-        "nchmm_div2_blob_end:\n"
-        ".previous\n");
-
-namespace nchmm {
-// one byte per significand (2^23): 0 = the plain pair, 1..24 = that variant, 255 = the three-operation division
-void expand_div2_table(unsigned char* out)
-{
-    for (size_t i = 0; i < ((size_t)1 << 23); ++i) out[i] = 0;
-    const size_t n = (size_t)(nchmm_div2_blob_end - nchmm_div2_blob) / 4;
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned char* e = nchmm_div2_blob + 4 * i;
-        const unsigned v = (unsigned)e[0] | ((unsigned)e[1] << 8) | ((unsigned)e[2] << 16) | ((unsigned)e[3] << 24);
-        out[(v >> 8) & 0x7FFFFFu] = (unsigned char)(v & 255u);
-    }
-}
-size_t div2_table_entries() { return (size_t)(nchmm_div2_blob_end - nchmm_div2_blob) / 4; }
-}  // namespace nchmm
 
 namespace {
 // src/builtin_models/builtin_model_names.inl:1-13 / builtin_model_strands.inl:1-13 (also in nanocall_amd/data/builtin_models.json;

@@ -41,8 +41,6 @@ struct ViterbiArgs {
     const float* models;       // [kMaxSlots][kModelFloats]
     const float* trans;        // [kMaxSlots][kTransFloats]
     const int32_t* model_fast; // [kMaxSlots] 1 = parameters inside the range the reciprocal division is proven for
-    const uint8_t* div2;       // [2^23] per binary32 significand of a divisor: the variant of the (zh, zl) pair that divides by it in
-                               // two operations for every numerator (0 = plain, 1..24, 255 = none); viterbi_kernel.hip
     unsigned long long* prof;  // optional [4]: forward ticks, traceback ticks, block ticks, blocks (wall_clock64)
     uint8_t* ws;               // back-pointer workspace: one kBpRowBytes row per event of the (sub-)batch
     uint64_t ev_base;          // off[first_read]: event index of the first row of the workspace

@@ -46,9 +46,5 @@ inline void step_params(float p_skip, float p_stay, float& p_step, float& p_skip
     p_skip_1 = static_cast<float>(p_skip / (p_skip + 1.0));
 }
 
-// nchmm_builtin.cpp: the embedded table of the two-operation division, one byte per binary32 significand (8 MiB)
-void expand_div2_table(unsigned char* out);
-size_t div2_table_entries();
-
 }  // namespace nchmm
 #endif

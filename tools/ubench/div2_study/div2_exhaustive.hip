@@ -10,13 +10,17 @@
 //   pass 2  for every divisor that fails, the same count with zl moved by -1, +1, -2, +2 ulps,
 //           then zh one or two floats below / above RN(1/d) with its own zl (0, -1, +1, -2, +2 ulps): the first variant with NO
 //           failing numerator is that divisor's pair.
-// Output: div2_table.bin -- sorted uint32 entries (significand << 8) | code for the divisors whose plain pair does not work,
+//   pass 3  for the divisors no variant rescues: the one numerator significand their PLAIN pair fails on (the kernel uses the plain
+//           pair for them and tests every numerator against it: a handful of operations instead of a third one per division).
+// Output: div2_table.bin.nstar -- uint32 pairs (divisor significand, failing numerator significand), sorted; and
+//         div2_table.bin -- sorted uint32 entries (significand << 8) | code for the divisors whose plain pair does not work,
 // code 1..24 = the variant (variant_pair below) that does, 255 = none does (such a divisor keeps the 3-operation division).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off div2_exhaustive.hip -o div2_exhaustive ; ./div2_exhaustive [out.bin]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -30,12 +34,13 @@ __device__ __forceinline__ float ulps(float v, int k) { return __builtin_bit_cas
 
 __device__ __forceinline__ uint32_t count_fails(float d, float zh, float zl)
 {
+    const float r = 1.0f / d;      // the reference needs the CORRECTLY ROUNDED reciprocal, whatever zh the candidate pair uses
     uint32_t f = 0;
     for (uint32_t nm = 0; nm < (1u << 23); ++nm) {
         const float n = sig(nm);
         const float q2 = __builtin_fmaf(n, zh, n * zl);
-        const float q0 = n * zh;
-        const float q3 = __builtin_fmaf(__builtin_fmaf(-q0, d, n), zh, q0);
+        const float q0 = n * r;
+        const float q3 = __builtin_fmaf(__builtin_fmaf(-q0, d, n), r, q0);
         f += (__builtin_bit_cast(uint32_t, q2) != __builtin_bit_cast(uint32_t, q3));
     }
     return f;
@@ -95,6 +100,24 @@ __global__ __launch_bounds__(64) void pass2(const uint32_t* bad, uint32_t n_bad,
     if (threadIdx.x == 0) code[i] = ok ? (uint8_t)(__builtin_ctzll(ok) + 1) : 255;
 }
 
+// pass 3: the ONE numerator significand on which the plain pair of a pair-less divisor fails (pass 1 counted exactly one)
+__global__ __launch_bounds__(256) void pass3(const uint32_t* none, uint32_t n_none, uint32_t* nstar)
+{
+    // one block per divisor, the numerators split over its 256 threads
+    const uint32_t i = blockIdx.x;
+    if (i >= n_none) return;
+    const float d = sig(none[i]);
+    const float zh = 1.0f / d, r = zh;
+    const float zl = __builtin_fmaf(-zh, d, 1.0f) / d;
+    for (uint32_t nm = threadIdx.x; nm < (1u << 23); nm += 256u) {
+        const float n = sig(nm);
+        const float q2 = __builtin_fmaf(n, zh, n * zl);
+        const float q0 = n * r;
+        const float q3 = __builtin_fmaf(__builtin_fmaf(-q0, d, n), r, q0);
+        if (__builtin_bit_cast(uint32_t, q2) != __builtin_bit_cast(uint32_t, q3)) nstar[i] = nm;
+    }
+}
+
 int main(int argc, char** argv)
 {
     const char* out = argc > 1 ? argv[1] : "div2_table.bin";
@@ -135,5 +158,25 @@ int main(int argc, char** argv)
     if (!f || fwrite(table.data(), 4, table.size(), f) != table.size()) { printf("cannot write %s\n", out); return 1; }
     fclose(f);
     printf("wrote %s: %zu entries (significand << 8 | code), sorted\n", out, table.size());
+    // pass 3 -> <out>.nstar: (divisor significand, failing numerator significand) for the pair-less divisors, sorted by divisor
+    std::vector<uint32_t> none;
+    for (size_t i = 0; i < bad.size(); ++i) if (code[i] == 255) none.push_back(bad[i]);
+    uint32_t *d_none, *d_nstar;
+    CHECK(hipMalloc(&d_none, none.size() * 4 + 4)); CHECK(hipMalloc(&d_nstar, none.size() * 4 + 4));
+    CHECK(hipMemcpy(d_none, none.data(), none.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemset(d_nstar, 0xFF, none.size() * 4));
+    hipLaunchKernelGGL(pass3, dim3((uint32_t)none.size()), dim3(256), 0, 0, d_none, (uint32_t)none.size(), d_nstar);
+    CHECK(hipDeviceSynchronize());
+    std::vector<uint32_t> nstar(none.size());
+    CHECK(hipMemcpy(nstar.data(), d_nstar, nstar.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> pairs;
+    size_t missing = 0;
+    for (size_t i = 0; i < none.size(); ++i) { pairs.push_back(none[i]); pairs.push_back(nstar[i]); missing += nstar[i] == 0xFFFFFFFFu; }
+    const std::string out2 = std::string(out) + ".nstar";
+    FILE* g = fopen(out2.c_str(), "wb");
+    if (!g || fwrite(pairs.data(), 4, pairs.size(), g) != pairs.size()) { printf("cannot write %s\n", out2.c_str()); return 1; }
+    fclose(g);
+    printf("pass 3: wrote %s: %zu pair-less divisors with the numerator significand their plain pair fails on (%zu without one)\n", out2.c_str(), none.size(),
+           missing);
     return 0;
 }
