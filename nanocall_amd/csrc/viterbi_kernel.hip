@@ -182,41 +182,55 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
 
     // ---------------- group scans over the previous column ----------------
     // raw maxima first (strict >, ascending index => first maximum), sums once per group
-    float m4[2]; unsigned x4[2];
+    // (the scans carry the winner as its back-pointer slot code straight away -- 1 + x for a step group, 5 + 4x + y for the skip
+    // group: the constants ride in the selects and in the shift-add that forms the skip code, no separate adds)
+    float m4[2]; unsigned x4[2];              // x4 = 1 + winning member
 #pragma unroll
     for (int g = 0; g < 2; ++g) {            // y = 2g + h, members i = 2x + g
         // starting from member 0 instead of -INF saves one compare-select; the results differ only
         // if member 0 is NaN while another member is not, which needs a NaN emission for some
         // states but not others -- no finite model/event does that (and an all-NaN column is
         // reported as NCHMM_E_NUMERIC at the end)
-        float bv = S.alpha[g]; unsigned bx = 0;
+        float bv = S.alpha[g]; unsigned bx = 1;
 #pragma unroll
         for (int xx = 1; xx < 4; ++xx) {
             const float v = S.alpha[2 * xx + g];
             const mask_t m = ballot(v > bv);
             bv = selm(m, v, bv);
-            bx = selm(m, (unsigned)xx, bx);
+            bx = selm(m, (unsigned)xx + 1u, bx);
         }
         m4[g] = bv; x4[g] = bx;
     }
-    // own half of the skip group: k = 4x + y
-    float m8 = m4[0]; unsigned k8 = 4u * x4[0] + h;
-    merge_lower(m8, k8, m4[1], 4u * x4[1] + 2u + h);
+    // own half of the skip group: k = 4x + y.  Fast form: strict > decides; an exact tie between the halves (the lower index
+    // would win) is rare and goes to the exact rescan below
+    float m8 = m4[0]; unsigned k8 = 4u * x4[0] + (h + 1u);          // 5 + 4x + h with x = x4 - 1
+    mask_t tie_halves = ballot(m4[1] == m8);
+    {
+        const mask_t g = ballot(m4[1] > m8);
+        m8 = selm(g, m4[1], m8);
+        k8 = selm(g, 4u * x4[1] + (h + 3u), k8);                     // 5 + 4x + (2 + h)
+    }
     // partner half
     float m16 = m8; unsigned k16 = k8;
-    merge_lower(m16, k16, swap1(m8), swap1(k8));
+    {
+        const float pm = swap1(m8); const unsigned pk = swap1(k8);
+        tie_halves |= ballot(pm == m16);
+        const mask_t g = ballot(pm > m16);
+        m16 = selm(g, pm, m16);
+        k16 = selm(g, pk, k16);
+    }
 
     float s1[2] = {S.w1[0] + m4[0], S.w1[1] + m4[1]};
     float s2 = S.w2 + m16;
-    unsigned sl1[2] = {1u + x4[0], 1u + x4[1]};
-    unsigned sl2 = 5u + k16;
+    unsigned sl1[2] = {x4[0], x4[1]};
+    unsigned sl2 = k16;
     // Is any smaller alpha rounded to the same sum?  probe the next float below the maximum
     // (exact for negative normal maxima; anything else reports "unsafe").
     {
         const float c = 0x1.8p-24f;   // 0.75 ulp relative: RN(m + m*c) is the next float below a negative m
         const float p0 = __builtin_fmaf(m4[0], c, m4[0]), p1 = __builtin_fmaf(m4[1], c, m4[1]);
         const float p2 = __builtin_fmaf(m16, c, m16);
-        const mask_t unsafe = ballot(S.w1[0] + p0 >= s1[0]) | ballot(S.w1[1] + p1 >= s1[1]) | ballot(S.w2 + p2 >= s2);
+        const mask_t unsafe = ballot(S.w1[0] + p0 >= s1[0]) | ballot(S.w1[1] + p1 >= s1[1]) | ballot(S.w2 + p2 >= s2) | tie_halves;
         if (unsafe != 0) {
             ++S.n_rescan;
             // exact scan on the sums themselves (Viterbi.hpp:79-89 restricted to one class)
