@@ -8,7 +8,7 @@
 // device decodes its shard in batched launches.  Output order is input order.
 //
 // Not provided (fails with a message): --write-fast5 (HDF5 write-back), -s/--trans with a graph other than the
-// stay/step/skip-1 one (the device tables are built from (pr_skip, pr_stay)), gzip-compressed model files.
+// stay/step/skip-1 one (the device tables are built from (pr_skip, pr_stay)).
 // Extra options: --gpus N (devices to use, default all), --chunk-events N (events decoded per batch and device).
 #include <dirent.h>
 #include <fcntl.h>
@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -275,6 +276,21 @@ static std::vector<std::string> list_directory(const std::string& fn)
 // ---------------------------------------------------------------------------------------------------------------
 // init_models / init_transitions / init_files / init_reads  (nanocall.cpp:97-273)
 // ---------------------------------------------------------------------------------------------------------------
+// A text file that may be gzip-compressed (the reference opens its model files and the model fofn through zstr,
+// nanocall.cpp:122,144): zlib's gz layer passes plain files through unchanged.
+static std::string read_text_or_gzip(const std::string& fn, const char* what)
+{
+    gzFile gz = gzopen(fn.c_str(), "rb");
+    if (!gz) { LOG(error) << "cannot open " << what << " [" << fn << "]" << std::endl; std::exit(EXIT_FAILURE); }
+    std::string text;
+    char buf[1 << 16];
+    int n;
+    while ((n = gzread(gz, buf, sizeof(buf))) > 0) text.append(buf, (size_t)n);
+    const int rc = gzclose(gz);
+    if (n < 0 || rc != Z_OK) { LOG(error) << "cannot read " << what << " [" << fn << "]: damaged gzip stream" << std::endl; std::exit(EXIT_FAILURE); }
+    return text;
+}
+
 static void init_models(Pore_Model_Dict_Type& models)
 {
     auto parse_model_name = [](const std::string& s) {
@@ -290,8 +306,7 @@ static void init_models(Pore_Model_Dict_Type& models)
         model_list[p.first].push_back(p.second);
     }
     if (!opts::model_fofn.get().empty()) {
-        std::ifstream ifs(opts::model_fofn.get());
-        if (!ifs) { LOG(error) << "cannot open model fofn [" << opts::model_fofn.get() << "]" << std::endl; std::exit(EXIT_FAILURE); }
+        std::istringstream ifs(read_text_or_gzip(opts::model_fofn.get(), "model fofn"));
         std::string s;
         while (std::getline(ifs, s)) {
             auto p = parse_model_name(s);
@@ -306,9 +321,8 @@ static void init_models(Pore_Model_Dict_Type& models)
         for (unsigned st = 0; st < 3; ++st)
             for (const auto& e : model_list[st]) {
                 Pore_Model_Type pm;
-                std::ifstream ifs(e, std::ios::binary);
-                if (!ifs) { LOG(error) << "cannot open model file [" << e << "]" << std::endl; std::exit(EXIT_FAILURE); }
-                if (ifs.peek() == 0x1f) { LOG(error) << "model file [" << e << "] is gzip-compressed: decompress it first" << std::endl; std::exit(EXIT_FAILURE); }
+                const std::string text = read_text_or_gzip(e, "model file");
+                std::istringstream ifs(text);
                 try { ifs >> pm; } catch (const std::exception& x) { LOG(error) << e << ": " << x.what() << std::endl; std::exit(EXIT_FAILURE); }
                 pm.strand() = st;
                 LOG(info) << "loaded module [" << e << "] for strand [" << st << "] statistics [mean=" << pm.mean() << ", stdv=" << pm.stdv() << "]" << std::endl;

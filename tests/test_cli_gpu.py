@@ -388,6 +388,16 @@ def test_custom_model_files_equal_the_builtin_models(tmp_path):
     fofn.write_text("".join(f"{s}:{tmp_path / f}\n" for f, s in (("a_c_p1.model", 1), ("b_c_p2.model", 1), ("c_t.model", 0))))
     assert run_cli(["--pore", "r73", "--model-fofn", str(fofn)] + base + files).stdout == a
     assert "models were specified only for strand" in run_cli(["-m", f"0:{tmp_path / 'c_t.model'}"] + files, expect_rc=1).stderr
+    # gzip-compressed model files read like plain ones (the reference opens models through zstr, nanocall.cpp:113-120)
+    import gzip
+    gz_args = []
+    for fname, strand in (("a_c_p1.model", 1), ("b_c_p2.model", 1), ("c_t.model", 0)):
+        with open(tmp_path / fname, "rb") as f, gzip.open(tmp_path / (fname + ".gz"), "wb") as g:
+            g.write(f.read())
+        gz_args += ["-m", f"{strand}:{tmp_path / (fname + '.gz')}"]
+    assert run_cli(["--pore", "r73"] + base + gz_args + files).stdout == a
+    (tmp_path / "cut.model.gz").write_bytes((tmp_path / "c_t.model.gz").read_bytes()[:2000])
+    assert "damaged gzip stream" in run_cli(["-m", f"2:{tmp_path / 'cut.model.gz'}"] + files, expect_rc=1).stderr
 
 
 def test_non_default_transition_and_segmentation_options_no_train():
