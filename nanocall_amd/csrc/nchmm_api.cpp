@@ -632,7 +632,7 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
     int rc = ensure(c, &p, &c->last_state_bytes, sizeof(unsigned) * n_reads);
     c->d_last_state = (unsigned*)p;
     if (rc != NCHMM_OK) return rc;
-    // Back-pointer workspace: kBpRowBytes (1.5 KiB) per event.  When the whole batch fits the budget it is one
+    // Back-pointer workspace: kBpRowBytes (4 KiB: one byte per state) per event.  When the whole batch fits the budget it is one
     // forward + one traceback launch; otherwise the batch is cut into contiguous read ranges.
     if (c->ws_budget == 0) {
         size_t free_b = 0, total_b = 0;
