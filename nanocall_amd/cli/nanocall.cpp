@@ -7,8 +7,8 @@
 // reads of a chunk are sharded over the GPUs of the node (one host thread + context per device, nchmm_pool_*) and every
 // device decodes its shard in batched launches.  Output order is input order.
 //
-// Not provided (fails with a message): --write-fast5 (HDF5 write-back), -s/--trans with a graph other than the
-// stay/step/skip-1 one (the device tables are built from (pr_skip, pr_stay)).
+// Not provided (fails with a message): --write-fast5 (HDF5 write-back), -s/--trans (the device tables, and the
+// transition statistics of the EM rounds, are built from (pr_skip, pr_stay)).
 // Extra options: --gpus N (devices to use, default all), --chunk-events N (events decoded per batch and device).
 #include <dirent.h>
 #include <fcntl.h>
