@@ -17,6 +17,19 @@ print("== kernel stats (rocprofv3 --kernel-trace --stats, same command) ==")
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+# the --stats average runs over EVERY launch of the command: warm-up steps (cold clocks) and the host-pointer leg's calls
+# (the kernel after a PCIe gap) as well as the timed steps; the per-call trace separates them
+warm, steps = int(os.environ.get("PROF_WARMUP", 3)), int(os.environ.get("PROF_STEPS", 12))
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    for kern in ("viterbi_kernel", "traceback_kernel"):
+        d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+             for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+        d = [x[1] for x in sorted(d)]
+        if len(d) >= warm + steps:
+            timed, rest = d[warm:warm + steps], d[:warm] + d[warm + steps:]
+            print(f"{kern}: launches {warm + 1}..{warm + steps} (bench.py's timed region) mean {sum(timed) / len(timed):.3f} ms "
+                  f"[{min(timed):.3f}, {max(timed):.3f}]; the other {len(rest)} (warm-up, host-pointer leg) mean "
+                  f"{sum(rest) / max(1, len(rest)):.3f} ms")
 traffic = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
