@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 4) void vit_shape(float* out, u64* planes, int
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
 {
-    float a[8], b = 1.0001f, c = 0.5f;
+    float a[8], b = 1.0001f, c = 0.5f, d2 = 0.25f, t5 = 0.f, z6 = 0.f;
     for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 0.001f + i;
     u64 msk = 0x5555555555555555ull ^ (u64)iters;
     unsigned sv = (unsigned)iters;
@@ -195,10 +195,58 @@ __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
                 if (MODE == 29) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (MODE == 30) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (MODE == 31) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sv) : "v"(a[i]));
+                // round-3 addendum: do the VCC / VOP2 / VOPC encodings of compare and select cost the same as the SGPR-pair ones?
+                if (MODE == 32) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : );
+                if (MODE == 33) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+                if (MODE == 34) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (MODE == 35) asm volatile("v_cmp_gt_f32_e64 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(msk));
+                if (MODE == 37) asm volatile("v_cndmask_b32_e64 %0, 1.0, 2.0, %1" : "=v"(a[i]) : "s"(msk));
+                if (MODE == 38) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 39) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (MODE == 40) asm volatile("v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(a[i]) : "v"(b));
+                // sequences as the Viterbi kernel has them (time per SEQUENCE): one compare feeding two selects (a scan step), and a
+                // 3-way combine cell (max3, three equality compares, tie logic on the scalar unit, two selects)
+                if (MODE == 43) asm volatile("v_cmp_gt_f32_e64 %3, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %3\n\tv_cndmask_b32_e64 %1, %1, %2, %3"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b), "s"(msk));
+                if (MODE == 44) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %1, %1, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                if (MODE == 45) asm volatile("v_max3_f32 %1, %0, %2, %3\n\t"
+                                             "v_cmp_eq_f32_e64 s[20:21], %2, %1\n\tv_cmp_eq_f32_e64 s[22:23], %3, %1\n\tv_cmp_eq_f32_e64 s[24:25], %0, %1\n\t"
+                                             "v_cndmask_b32_e64 %0, %3, %2, s[20:21]\n\tv_cndmask_b32_e64 %0, %0, 0, s[24:25]\n\t"
+                                             "s_and_b64 s[26:27], s[24:25], s[20:21]\n\ts_or_b64 s[24:25], s[24:25], s[20:21]\n\t"
+                                             "s_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk) : : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+                if (MODE == 46) asm volatile("v_max3_f32 %1, %0, %2, %3\n\t"
+                                             "v_cmp_eq_f32_e64 s[22:23], %3, %1\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %2, %1\n\ts_mov_b64 s[20:21], vcc\n\tv_cndmask_b32_e32 %5, %3, %2, vcc\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %5, %6, vcc\n\t"
+                                             "s_and_b64 s[26:27], vcc, s[20:21]\n\ts_or_b64 s[24:25], vcc, s[20:21]\n\t"
+                                             "s_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5) : "v"(z6) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+                if (MODE == 50) asm volatile("v_max3_f32 %1, %0, %2, %3\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %5, %3, %2, vcc\n\ts_mov_b64 s[20:21], vcc\n\t"
+                                             "v_cmp_eq_f32_e64 s[22:23], %3, %1\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %5, %6, vcc\n\t"
+                                             "s_and_b64 s[26:27], vcc, s[20:21]\n\ts_or_b64 s[24:25], vcc, s[20:21]\n\t"
+                                             "s_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5) : "v"(z6) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+                if (MODE == 51) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\ts_nop 0\n\tv_cndmask_b32_e32 %1, %1, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                if (MODE == 52) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %1, %2, %0, vcc"
+                                             : "+v"(a[i]), "=v"(t5) : "v"(b) : "vcc");
+                if (MODE == 53) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %1, %1, %2, vcc\n\tv_cndmask_b32_e32 %0, %0, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                if (MODE == 47) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                if (MODE == 48) asm volatile("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "s"(msk) : "vcc");
+                if (MODE == 49) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_add_f32 %1, %1, %2\n\tv_cndmask_b32_e32 %1, %1, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                if (MODE == 41) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (MODE == 42) asm volatile("v_subb_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
             }
         }
     }
-    float s = (float)sv;
+    float s = (float)sv + c + d2 + t5 + b + (float)(msk & 1);
     for (int i = 0; i < 8; ++i) s += a[i];
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
@@ -234,6 +282,7 @@ template <int STORES, int SELS, int SALU, bool X2> static double run_shape(const
 
 int main()
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);   // a kernel that hangs must not take the lines before it along
     float* d; CHECK(hipMalloc(&d, 64 << 20));
     u64* planes; CHECK(hipMalloc(&planes, 64 << 20));
     CHECK(hipMemset(planes, 0xAB, 64 << 20));
@@ -279,5 +328,14 @@ int main()
     run_rate<11>("v_and_or_b32", d); run_rate<12>("v_min_u32", d); run_rate<29>("v_min3_u32", d);
     run_rate<26>("v_mov_b32_dpp", d); run_rate<16>("v_max_f32_dpp", d);
     run_rate<15>("v_mov_b32 from sgpr", d); run_rate<14>("v_writelane_b32", d); run_rate<31>("v_readlane_b32", d);
+    run_rate<32>("v_cndmask_b32_e32 (vcc)", d); run_rate<33>("v_cmp_gt_f32_e32 -> vcc", d); run_rate<37>("v_cndmask_e64 consts", d);
+    run_rate<34>("cmp_e32 + cndmask_e32 (2 instr)", d); run_rate<35>("cmp_e64 + cndmask_e64 (2 instr)", d);
+    run_rate<38>("v_max_i32", d); run_rate<39>("v_pk_max_f16", d); run_rate<40>("v_cndmask_b32_sdwa", d);
+    run_rate<43>("SEQ cmp_e64 + 2 cndmask_e64", d); run_rate<44>("SEQ cmp_e32 + 2 cndmask_e32", d); run_rate<49>("SEQ cmp_e32 cnd add cnd", d);
+    run_rate<47>("SEQ cmp_e32 + add + cndmask_e32", d); run_rate<48>("SEQ s_mov vcc + cndmask_e32", d);
+    run_rate<51>("SEQ cmp_e32 cnd s_nop cnd", d); run_rate<52>("SEQ cmp_e32 cnd cnd (2nd into a fresh reg)", d); run_rate<53>("SEQ cmp_e32 cnd(shared) cnd(own)", d);
+    run_rate<50>("SEQ combine cell, vcc selects, s_mov after", d);
+    run_rate<45>("SEQ combine cell, e64 masks", d); run_rate<46>("SEQ combine cell, vcc selects", d);
+    run_rate<41>("v_sub_co_u32", d); run_rate<42>("v_subb_co_u32", d);
     return 0;
 }
