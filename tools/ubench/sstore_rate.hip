@@ -154,8 +154,8 @@ __global__ __launch_bounds__(512, 4) void vit_shape(float* out, u64* planes, int
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
 {
-    float a[8], b = 1.0001f, c = 0.5f, d2 = 0.25f, t5 = 0.f, z6 = 0.f;
-    for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 0.001f + i;
+    float a[8], g[8], h[8], k[8], b = 1.0001f, c = 0.5f, d2 = 0.25f, t5 = 0.f, z6 = 0.f, f7 = 1.f, f8 = 2.f;
+    for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 0.001f + i; g[i] = a[i] + 1.f; h[i] = a[i] + 2.f; k[i] = a[i] + 3.f; }
     u64 msk = 0x5555555555555555ull ^ (u64)iters;
     unsigned sv = (unsigned)iters;
     for (int it = 0; it < iters; ++it) {
@@ -236,6 +236,62 @@ __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
                                              : "+v"(a[i]), "=v"(t5) : "v"(b) : "vcc");
                 if (MODE == 53) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %1, %1, %2, vcc\n\tv_cndmask_b32_e32 %0, %0, %2, vcc"
                                              : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                // the combine cell with two independent full-rate ops (as the emission right after it provides) between the selects
+                if (MODE == 54) asm volatile("v_max3_f32 %1, %0, %2, %3\n\t"
+                                             "v_cmp_eq_f32_e64 s[20:21], %2, %1\n\tv_cmp_eq_f32_e64 s[22:23], %3, %1\n\tv_cmp_eq_f32_e64 s[28:29], %0, %1\n\t"
+                                             "v_cndmask_b32_e64 %5, %3, %2, s[20:21]\n\tv_add_f32 %6, %6, %8\n\tv_cndmask_b32_e64 %0, %5, 0, s[28:29]\n\tv_add_f32 %7, %7, %8\n\t"
+                                             "s_and_b64 s[26:27], s[28:29], s[20:21]\n\ts_or_b64 s[24:25], s[28:29], s[20:21]\n\ts_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5), "+v"(f7), "+v"(f8) : "v"(z6) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
+                if (MODE == 55) asm volatile("v_max3_f32 %1, %0, %2, %3\n\t"
+                                             "v_cmp_eq_f32_e64 s[22:23], %3, %1\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %5, %3, %2, vcc\n\tv_add_f32 %6, %6, %8\n\ts_mov_b64 s[20:21], vcc\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %5, %8, vcc\n\tv_add_f32 %7, %7, %8\n\t"
+                                             "s_and_b64 s[26:27], vcc, s[20:21]\n\ts_or_b64 s[24:25], vcc, s[20:21]\n\ts_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5), "+v"(f7), "+v"(f8) : "v"(z6) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+                if (MODE == 56) asm volatile("v_max3_f32 %1, %0, %2, %3\n\t"
+                                             "v_cmp_eq_f32_e64 s[22:23], %3, %1\n\tv_cmp_eq_f32_e64 s[20:21], %2, %1\n\t"
+                                             "v_cmp_eq_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e64 %5, %3, %2, s[20:21]\n\tv_add_f32 %6, %6, %8\n\tv_cndmask_b32_e32 %0, %5, %8, vcc\n\tv_add_f32 %7, %7, %8\n\t"
+                                             "s_and_b64 s[26:27], vcc, s[20:21]\n\ts_or_b64 s[24:25], vcc, s[20:21]\n\ts_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5), "+v"(f7), "+v"(f8) : "v"(z6) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+                if (MODE == 57) asm volatile("v_cmp_gt_f32_e64 %3, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %3\n\tv_add_f32 %4, %4, %2\n\tv_cndmask_b32_e64 %1, %1, %2, %3"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b), "s"(msk), "v"(f7));
+                if (MODE == 58) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_nop\n\tv_cndmask_b32_e32 %1, %1, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
+                if (MODE == 59) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_fma_f32 %3, %3, %2, %2\n\tv_cndmask_b32_e32 %1, %1, %2, vcc"
+                                             : "+v"(a[i]), "+v"(c) : "v"(b), "v"(f7) : "vcc");
+                // half-rate and full-rate ops interleaved, every chain independent (a[i] for the half-rate op, g[i] / h[i] / k[i] for the adds)
+                if (MODE == 60) asm volatile("v_max_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 61) asm volatile("v_max_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %3" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]) : "v"(b));
+                if (MODE == 62) asm volatile("v_max_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
+                if (MODE == 63) asm volatile("v_cndmask_b32_e64 %0, %0, %2, %3\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b), "s"(msk));
+                if (MODE == 64) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b) : "s20", "s21");
+                if (MODE == 65) asm volatile("v_max_f32 %0, %0, %2\n\tv_fma_f32 %1, %1, %2, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 66) asm volatile("v_max_f32 %0, %0, %4\n\tv_max_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
+                if (MODE == 67) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 68) asm volatile("v_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 69) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %4\n\tv_add_f32 %2, %2, %4\n\tv_cndmask_b32_e64 %0, %0, %4, s[20:21]\n\tv_add_f32 %3, %3, %4\n\tv_cndmask_b32_e64 %1, %1, %4, s[20:21]"
+                                             : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b) : "s20", "s21");
+                if (MODE == 70) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %2, s[20:21]"
+                                             : "+v"(a[i]), "+v"(g[i]) : "v"(b) : "s20", "s21");
+                if (MODE == 71) asm volatile("v_max3_f32 %0, %0, %2, %3\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b), "v"(c));
+                if (MODE == 72) asm volatile("v_lshl_or_b32 %0, %0, 8, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 73) asm volatile("v_lshl_add_u32 %0, %0, 2, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 74) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 75) asm volatile("v_cndmask_b32_e64 %0, %0, %2, %3\n\tv_mul_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b), "s"(msk));
+                if (MODE == 76) asm volatile("v_cndmask_b32_e64 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b), "s"(msk));
+                if (MODE == 77) asm volatile("v_add_f32 %1, %1, %2\n\tv_cmp_gt_f32_e64 s[20:21], %0, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b) : "s20", "s21");
+                if (MODE == 78) asm volatile("v_cmp_eq_f32_e64 s[20:21], %0, %2\n\tv_cmp_eq_f32_e64 s[22:23], %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b) : "s20", "s21", "s22", "s23");
+                if (MODE == 79) asm volatile("v_cndmask_b32_e64 %0, %0, %3, %4\n\tv_sub_f32 %1, %1, %3\n\tv_cndmask_b32_e64 %2, %2, %3, %4\n\tv_mul_f32 %5, %5, %3"
+                                             : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]) : "v"(b), "s"(msk), "v"(k[i]));
+                // the combine cell with SIX independent full-rate riders (sub / mul / add), one after each half-rate op
+                if (MODE == 80) asm volatile("v_max3_f32 %1, %0, %2, %3\n\tv_sub_f32 %6, %6, %8\n\t"
+                                             "v_cmp_eq_f32_e64 s[20:21], %2, %1\n\tv_mul_f32 %7, %7, %8\n\t"
+                                             "v_cmp_eq_f32_e64 s[22:23], %3, %1\n\tv_sub_f32 %9, %9, %8\n\t"
+                                             "v_cmp_eq_f32_e64 s[28:29], %0, %1\n\tv_mul_f32 %10, %10, %8\n\t"
+                                             "v_cndmask_b32_e64 %5, %3, %2, s[20:21]\n\tv_add_f32 %6, %6, %8\n\tv_cndmask_b32_e64 %0, %5, 0, s[28:29]\n\tv_add_f32 %7, %7, %8\n\t"
+                                             "s_and_b64 s[26:27], s[28:29], s[20:21]\n\ts_or_b64 s[24:25], s[28:29], s[20:21]\n\ts_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
+                                             : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5), "+v"(g[i]), "+v"(h[i]) : "v"(z6), "v"(k[i]), "v"(f7)
+                                             : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
                 if (MODE == 47) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc"
                                              : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
                 if (MODE == 48) asm volatile("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "s"(msk) : "vcc");
@@ -246,8 +302,52 @@ __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
             }
         }
     }
-    float s = (float)sv + c + d2 + t5 + b + (float)(msk & 1);
-    for (int i = 0; i < 8; ++i) s += a[i];
+    // clustered half-rate / full-rate blocks (8 + 8, the shape the compiler gives the Viterbi column) in step on all waves (83),
+    // or out of phase between the two waves a block has on each SIMD (84): can ANOTHER wave's full-rate op use the idle pass?
+    if (MODE == 83 || MODE == 84) {
+        const bool flip = MODE == 84 && ((threadIdx.x >> 8) & 1u);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!flip) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(g[i]) : "v"(b));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(g[i]) : "v"(b));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                }
+            }
+        }
+    }
+    // the Viterbi column's shape: 56 half-rate ops and 168 full-rate ops per iteration, clustered (85), clustered with a
+    // barrier per iteration (86), or interleaved H F F F (87), interleaved + barrier (88).  Time per 224 instructions.
+    if (MODE >= 85 && MODE <= 88) {
+        for (int it = 0; it < iters / 8; ++it) {
+            if (MODE == 85 || MODE == 86) {
+#pragma unroll
+                for (int r = 0; r < 7; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#pragma unroll
+                for (int r = 0; r < 7; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_add_f32 %0, %0, %3\n\tv_mul_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %3" : "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 7; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        asm volatile("v_max_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
+            }
+            if (MODE == 86 || MODE == 88) __syncthreads();
+        }
+    }
+    float s = (float)sv + c + d2 + t5 + b + f7 + f8 + (float)(msk & 1);
+    for (int i = 0; i < 8; ++i) s += a[i] + g[i] + h[i] + k[i];
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
@@ -269,6 +369,13 @@ template <int MODE> static void run_rate(const char* name, float* d)
     const float ms = time_ms([&] { hipLaunchKernelGGL(rate<MODE>, dim3(grid), dim3(512), 0, 0, d, iters); });
     // 512 blocks x 8 waves over 1024 SIMDs = 4 waves per SIMD, each 32 * iters instructions
     printf("rate  %-22s %8.3f ms  -> %.3f ns per wave-instruction per SIMD (4 waves/SIMD)\n", name, ms, ms * 1e6 / (4.0 * 32.0 * iters));
+}
+
+template <int MODE> static void run_shape224(const char* name, float* d)
+{
+    const int iters = 20000, grid = 512;
+    const float ms = time_ms([&] { hipLaunchKernelGGL(rate<MODE>, dim3(grid), dim3(512), 0, 0, d, iters); });
+    printf("col   %-52s %8.3f ms  -> %.1f ns per 224 instructions per wave and SIMD share (additive: 56 x 1.80 + 168 x 1.07 = 280.6)\n", name, ms, ms * 1e6 / (4.0 * (iters / 8)));
 }
 
 template <int STORES, int SELS, int SALU, bool X2> static double run_shape(const char* name, float* d, u64* planes)
@@ -334,6 +441,16 @@ int main()
     run_rate<43>("SEQ cmp_e64 + 2 cndmask_e64", d); run_rate<44>("SEQ cmp_e32 + 2 cndmask_e32", d); run_rate<49>("SEQ cmp_e32 cnd add cnd", d);
     run_rate<47>("SEQ cmp_e32 + add + cndmask_e32", d); run_rate<48>("SEQ s_mov vcc + cndmask_e32", d);
     run_rate<51>("SEQ cmp_e32 cnd s_nop cnd", d); run_rate<52>("SEQ cmp_e32 cnd cnd (2nd into a fresh reg)", d); run_rate<53>("SEQ cmp_e32 cnd(shared) cnd(own)", d);
+    run_rate<54>("SEQ combine cell + 2 adds, e64 masks", d); run_rate<55>("SEQ combine cell + 2 adds, vcc selects", d); run_rate<56>("SEQ combine cell + 2 adds, e0 only in vcc", d);
+    run_rate<57>("SEQ cmp_e64 cnd add cnd", d); run_rate<58>("SEQ cmp_e32 cnd v_nop cnd", d); run_rate<59>("SEQ cmp_e32 cnd fma cnd", d);
+    run_rate<67>("SEQ add add", d); run_rate<60>("SEQ max add", d); run_rate<61>("SEQ max add add", d); run_rate<62>("SEQ max add add add", d); run_rate<66>("SEQ max max add add", d);
+    run_rate<71>("SEQ max3 add", d); run_rate<72>("SEQ lshl_or add", d); run_rate<73>("SEQ lshl_add add", d); run_rate<74>("SEQ mov_dpp add", d);
+    run_rate<75>("SEQ cndmask mul", d); run_rate<76>("SEQ cndmask fma", d); run_rate<77>("SEQ add cmp", d); run_rate<78>("SEQ cmp cmp", d); run_rate<79>("SEQ cnd sub cnd mul", d);
+    run_rate<80>("SEQ combine cell + 6 riders", d);
+    run_rate<83>("SEQ 8 max then 8 add, x2 (per 32 instr)", d); run_rate<84>("SEQ same, waves out of phase", d);
+    run_shape224<85>("224-instr column shape, clustered 56 H then 168 F", d); run_shape224<86>("  same + barrier per iteration", d);
+    run_shape224<87>("224-instr column shape, interleaved H F F F", d); run_shape224<88>("  same + barrier per iteration", d);
+    run_rate<65>("SEQ max fma", d); run_rate<68>("SEQ max max", d); run_rate<70>("SEQ cmp cnd cnd (own regs)", d); run_rate<69>("SEQ cmp add cnd add cnd (own regs)", d); run_rate<63>("SEQ cndmask_e64 add", d); run_rate<64>("SEQ cmp_e64 add", d);
     run_rate<50>("SEQ combine cell, vcc selects, s_mov after", d);
     run_rate<45>("SEQ combine cell, e64 masks", d); run_rate<46>("SEQ combine cell, vcc selects", d);
     run_rate<41>("v_sub_co_u32", d); run_rate<42>("v_subb_co_u32", d);
