@@ -383,6 +383,15 @@ def test_product_before_torch_shares_one_hip_runtime(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "order_child.py"
     script.write_text(_ORDER_CHILD)
-    p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
+    # A fresh interpreter's first `import torch` pages in ~2 GB on a new box; once in ~30 runs the child was seen to sit
+    # there past any reasonable limit.  A TIMEOUT is therefore retried once (a wrong answer or a crash never is).
+    p = None
+    for attempt in range(2):
+        try:
+            p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=240)
+            break
+        except subprocess.TimeoutExpired as e:
+            if attempt == 1:
+                raise AssertionError(f"child timed out twice: {(e.stderr or b'')[-2000:]!r}")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.strip().startswith("ok"), p.stdout
