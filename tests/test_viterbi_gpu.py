@@ -383,8 +383,9 @@ def test_product_before_torch_shares_one_hip_runtime(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "order_child.py"
     script.write_text(_ORDER_CHILD)
-    # A fresh interpreter's first `import torch` pages in ~2 GB on a new box; once in ~30 runs the child was seen to sit
-    # there past any reasonable limit.  A TIMEOUT is therefore retried once (a wrong answer or a crash never is).
+    # Seen once in round 3 (an A/B session right after another kernel build had been swapped in): the child did not return
+    # within 600 s; eight repeats on a fresh box took 4 s each, cause unknown.  A TIMEOUT is therefore retried once -- a wrong
+    # answer or a crash never is.
     p = None
     for attempt in range(2):
         try:
