@@ -124,14 +124,20 @@ __device__ __forceinline__ float uniform(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-// swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+// swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2].  Written out with its own two wait states: a DPP read of
+// a VGPR needs them after the VALU write, and the values swapped here come out of asm statements (selm), which the compiler's
+// hazard recogniser does not look into -- the distance must not depend on what it happens to schedule in between.
 __device__ __forceinline__ float swap1(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    float r;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+    return r;
 }
 __device__ __forceinline__ unsigned swap1(unsigned v)
 {
-    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    unsigned r;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+    return r;
 }
 
 // byte of state j inside its 16-byte group: k = j >> 8 = 4x + y  ->  ((y&1)<<3) | (x<<1) | (y>>1)
