@@ -292,6 +292,12 @@ __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
                                              "s_and_b64 s[26:27], s[28:29], s[20:21]\n\ts_or_b64 s[24:25], s[28:29], s[20:21]\n\ts_and_b64 s[24:25], s[24:25], s[22:23]\n\ts_or_b64 s[26:27], s[26:27], s[24:25]\n\ts_or_b64 %4, %4, s[26:27]"
                                              : "+v"(a[i]), "+v"(c), "+v"(b), "+v"(d2), "+s"(msk), "=&v"(t5), "+v"(g[i]), "+v"(h[i]) : "v"(z6), "v"(k[i]), "v"(f7)
                                              : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
+                // transcendental + riders
+                if (MODE == 90) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                if (MODE == 91) asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %2" : "+v"(a[i]), "+v"(g[i]) : "v"(b));
+                if (MODE == 92) asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %3" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]) : "v"(b));
+                if (MODE == 93) asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
+                if (MODE == 94) asm volatile("v_exp_f32 %0, %0\n\tv_max_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %3" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]) : "v"(b));
                 if (MODE == 47) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc"
                                              : "+v"(a[i]), "+v"(c) : "v"(b) : "vcc");
                 if (MODE == 48) asm volatile("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "s"(msk) : "vcc");
@@ -344,6 +350,18 @@ __global__ __launch_bounds__(512, 4) void rate(float* out, int iters)
                         asm volatile("v_max_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4" : "+v"(a[i]), "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
             }
             if (MODE == 86 || MODE == 88) __syncthreads();
+        }
+    }
+    // eight transcendentals then twenty-four adds, clustered (95) -- against MODE 93's exp add add add, same instruction mix
+    if (MODE == 95) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %3" : "+v"(g[i]), "+v"(h[i]), "+v"(k[i]) : "v"(b));
+            }
         }
     }
     float s = (float)sv + c + d2 + t5 + b + f7 + f8 + (float)(msk & 1);
@@ -450,6 +468,7 @@ int main()
     run_rate<83>("SEQ 8 max then 8 add, x2 (per 32 instr)", d); run_rate<84>("SEQ same, waves out of phase", d);
     run_shape224<85>("224-instr column shape, clustered 56 H then 168 F", d); run_shape224<86>("  same + barrier per iteration", d);
     run_shape224<87>("224-instr column shape, interleaved H F F F", d); run_shape224<88>("  same + barrier per iteration", d);
+    run_rate<90>("v_exp_f32", d); run_rate<91>("SEQ exp add", d); run_rate<92>("SEQ exp add add", d); run_rate<93>("SEQ exp add add add", d); run_rate<94>("SEQ exp max add", d); run_rate<95>("SEQ 8 exp then 24 add (per exp+3 add)", d);
     run_rate<65>("SEQ max fma", d); run_rate<68>("SEQ max max", d); run_rate<70>("SEQ cmp cnd cnd (own regs)", d); run_rate<69>("SEQ cmp add cnd add cnd (own regs)", d); run_rate<63>("SEQ cndmask_e64 add", d); run_rate<64>("SEQ cmp_e64 add", d);
     run_rate<50>("SEQ combine cell, vcc selects, s_mov after", d);
     run_rate<45>("SEQ combine cell, e64 masks", d); run_rate<46>("SEQ combine cell, vcc selects", d);
