@@ -232,7 +232,7 @@ int nchmm_put_transitions_fast(nchmm_ctx* ctx, int first_slot, size_t n, const f
  * Reads with zero events get out_path_logp = NaN and status 0.
  * ---------------------------------------------------------------------------------------- */
 
-/* host-pointer form: copies in, runs, copies out, synchronises. */
+/* host-pointer form: copies in, runs, copies out, synchronises (pipelined over read ranges, see nchmm_viterbi_begin). */
 int nchmm_viterbi(nchmm_ctx* ctx, size_t n_reads, const uint64_t* off, const float* corrected_mean,
                   const float* stdv, const float* log_stdv, const int32_t* model_slot,
                   const int32_t* trans_slot, uint16_t* out_state, float* out_path_logp,
@@ -261,6 +261,30 @@ int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t 
 int nchmm_viterbi_raw(nchmm_ctx* ctx, size_t n_raw_events, const float* mean, const float* stdv, const float* start,
                       size_t n_cand, const uint64_t* src, const uint32_t* len, const float* drift, const int32_t* model_slot,
                       const int32_t* trans_slot, uint16_t* out_state, float* out_path_logp, int32_t* out_status);
+
+/* The two host-pointer forms above, split for callers that stream batches (the reference hides the latency of a strand
+ * behind its pfor worker threads, nanocall.cpp:611-621; here the unit is a batch and the latencies are the PCIe copies and
+ * the traceback launch).  A batch is cut into read ranges: range k+1 is copied in while range k computes, on a copy-in
+ * stream, two compute lanes and a copy-out stream -- the one-call forms are begin followed by end.
+ *   begin  validates, stages and enqueues copy-in + kernels of a batch, and returns (it holds the thread for the
+ *          duration of the H2D copies only).  At most TWO batches may be in flight per context (NCHMM_E_INVALID beyond).
+ *   end    completes the OLDEST batch in flight: copies its states out range by range as they finish, waits, fills
+ *          out_path_logp / out_status, returns 0 or NCHMM_E_NUMERIC as the one-call form does.
+ * Every array passed to begin -- inputs and outputs -- must stay valid and untouched until the matching end has
+ * returned, and the model / transition slots the batch names must not be rewritten before that.  While a batch is in
+ * flight nchmm_viterbi, nchmm_viterbi_raw and nchmm_viterbi_dev return NCHMM_E_INVALID.
+ * begin(0); begin(1); end(0); begin(2); end(1); ... keeps the GPU busy: batch k+1 goes up and starts while batch k
+ * computes, batch k comes down under the kernels of batch k+1. */
+int nchmm_viterbi_begin(nchmm_ctx* ctx, size_t n_reads, const uint64_t* off, const float* corrected_mean,
+                        const float* stdv, const float* log_stdv, const int32_t* model_slot,
+                        const int32_t* trans_slot, uint16_t* out_state, float* out_path_logp, int32_t* out_status);
+int nchmm_viterbi_raw_begin(nchmm_ctx* ctx, size_t n_raw_events, const float* mean, const float* stdv, const float* start,
+                            size_t n_cand, const uint64_t* src, const uint32_t* len, const float* drift,
+                            const int32_t* model_slot, const int32_t* trans_slot, uint16_t* out_state,
+                            float* out_path_logp, int32_t* out_status);
+int nchmm_viterbi_end(nchmm_ctx* ctx);
+/* batches begun and not yet ended (0, 1 or 2) */
+int nchmm_viterbi_in_flight(const nchmm_ctx* ctx);
 
 /* logf on the device, bit-identical to glibc 2.35 logf as x86-64 CPUs with FMA run it: out[i] = log(in[i]), host
  * buffers, any n (chunked).  Exists so that the claim above can be checked exhaustively. */

@@ -7,6 +7,7 @@ Python here is only the test/bench binding over that ABI:
   nanocall_amd.synth   the seeded synthetic event generator of SURVEY.md section 8d
 """
 from . import _lib  # noqa: F401
+from ._lib import NchmmError  # noqa: F401
 from .api import (Context, model_load, model_scale, model_pack6, transitions_fast, events_prepare,  # noqa: F401
                   base_seq, write_fasta, st_train_kmers, scaled_model_table, train_pm_finish, train_st_finish,
                   device_count, device_mem_info)

@@ -65,6 +65,10 @@ SIGNATURES = {
     "nchmm_viterbi": (C.c_int, [vp, C.c_size_t] + [vp] * 9),
     "nchmm_viterbi_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
     "nchmm_viterbi_raw": (C.c_int, [vp, C.c_size_t, vp, vp, vp, C.c_size_t] + [vp] * 8),
+    "nchmm_viterbi_begin": (C.c_int, [vp, C.c_size_t] + [vp] * 9),
+    "nchmm_viterbi_raw_begin": (C.c_int, [vp, C.c_size_t, vp, vp, vp, C.c_size_t] + [vp] * 8),
+    "nchmm_viterbi_end": (C.c_int, [vp]),
+    "nchmm_viterbi_in_flight": (C.c_int, [vp]),
     "nchmm_logf": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "nchmm_fwbw": (C.c_int, [vp, C.c_size_t] + [vp] * 13),
     "nchmm_fwbw_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 13),

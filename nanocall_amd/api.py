@@ -326,6 +326,35 @@ class Context:
             check(rc, "nchmm_viterbi")
         return states, logp, status
 
+    def viterbi_begin(self, off, cmean, stdv, log_stdv, model_slot=None, trans_slot=None, out=None):
+        """nchmm_viterbi_begin: enqueue one batch (copy-in + kernels) and return a ticket; at most two may be in flight.
+        `out` = (states, logp, status) arrays to reuse (a streaming caller recycles them: fresh pages cost a fault each).
+        The ticket keeps every array alive until viterbi_end."""
+        off = np.ascontiguousarray(off, np.uint64)
+        n = off.shape[0] - 1
+        total = int(off[-1]) if n > 0 else 0
+        cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
+        assert cm.shape[0] >= total and sd.shape[0] >= total and ls.shape[0] >= total
+        ms = None if model_slot is None else np.ascontiguousarray(model_slot, np.int32)
+        ts = None if trans_slot is None else np.ascontiguousarray(trans_slot, np.int32)
+        if out is None:
+            out = (np.empty(total, np.uint16), np.empty(max(n, 0), np.float32), np.zeros(max(n, 0), np.int32))
+        states, logp, status = out
+        assert states.dtype == np.uint16 and states.shape[0] >= total and logp.shape[0] >= n and status.shape[0] >= n
+        check(lib().nchmm_viterbi_begin(self._h, n, _p(off), _p(cm), _p(sd), _p(ls), _p(ms), _p(ts), _p(states), _p(logp), _p(status)),
+              "nchmm_viterbi_begin")
+        return {"keep": (off, cm, sd, ls, ms, ts), "out": (states, logp, status)}
+
+    def viterbi_end(self, ticket, raise_on_numeric=True):
+        """nchmm_viterbi_end: complete the OLDEST batch in flight (tickets end in the order they began)."""
+        rc = lib().nchmm_viterbi_end(self._h)
+        if rc != 0 and not (rc == -6 and not raise_on_numeric):
+            check(rc, "nchmm_viterbi_end")
+        return ticket["out"]
+
+    def viterbi_in_flight(self):
+        return int(lib().nchmm_viterbi_in_flight(self._h))
+
     def viterbi_raw(self, mean, stdv, start, src, length, drift, model_slot=None, trans_slot=None, raise_on_numeric=True):
         """nchmm_viterbi_raw: candidates over raw events, host prep on the device.
         Returns (states u16[sum(length)] packed by candidate, path_logp f32[n_cand], status i32[n_cand])."""

@@ -1,6 +1,7 @@
 // nchmm_api.cpp -- C-ABI device layer: context, model/transition upload, batched launches.
 // Compiled with hipcc; see include/nanocall_hip.h for the contract of every entry point.
 #include "nanocall_hip.h"
+#include "nchmm_ctx.hpp"
 #include "nchmm_device.h"
 #include "nchmm_internal.hpp"
 #include "nchmm_kmer.hpp"
@@ -17,87 +18,7 @@
 
 using namespace nchmm;
 
-struct nchmm_ctx {
-    int device = -1;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    bool external_stream = false;   // stream was set by the caller (0 is then the legacy default stream)
-    int last_hip = 0;
-    int n_cu = 0;
-    int vit_slots = 0;
-    int fb_slots = 0;
-    float* d_models = nullptr;      // [kMaxSlots][kModelFloats]
-    float* d_trans = nullptr;       // [kMaxSlots][kTransFloats]   log-space w0|w1|w2
-    float* d_trans_fb = nullptr;    // [kMaxSlots][kFbTransFloats] per-state forward/backward weights for FB
-    uint8_t* d_train_mask = nullptr; // [512] transition-training k-mers, one bit per state
-    unsigned* d_queue = nullptr;    // [2] work-queue heads (viterbi, fwbw)
-    int32_t* d_model_fast = nullptr; // [kMaxSlots]
-    unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
-    bool profile = false;
-    int tb_margin = 128;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path); profiles/r03_tb_margin.txt:
-                                    // 0 of 86 016 speculative segments un-merged at 64, 384 at 32 -- and a miss only costs a re-walk
-    uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace (4 KiB per event of a batch)
-    size_t ws_bytes = 0;
-    size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
-    size_t fb_budget = 0;           // same for the forward-backward alpha rows (16 KiB per event)
-    unsigned* d_last_state = nullptr; // per read: arg-max state of the last column
-    size_t last_state_bytes = 0;
-    float* d_fb_ws = nullptr;       // FB alpha workspace
-    size_t fb_ws_floats = 0;
-    void* d_fb_aux = nullptr;       // FB per-call scratch: lpd2 | last-row totals | redo list | redo flags | row exponents
-    size_t fb_aux_bytes = 0;
-    unsigned long long* d_fb_total = nullptr;   // windows redone in log space, running total
-    void* d_em_events = nullptr;    // resident raw events of an EM run: mean | stdv | start | log_stdv (nchmm_em_load_events)
-    size_t em_events_bytes = 0, em_n_events = 0;
-    bool fb_force_log = false;      // NCHMM_FB_FORCE_LOG: never take the rescaled linear-space kernels
-    // staging buffers of the host-pointer entry points
-    void* d_stage = nullptr;
-    size_t stage_bytes = 0;
-    uint8_t* d_masks = nullptr;     // overlap-mask ids of the stay / step-group / skip-group arcs (5376 bytes)
-    void* d_tab_stage = nullptr;    // device staging of the loaded (not yet scaled) tables + per-slot parameters
-    size_t tab_stage_bytes = 0;
-    void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
-    size_t h_pin_bytes = 0;
-    hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_vit2 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
-    bool vit_timed = false, fb_timed = false;
-    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int n_slots = 0;                // capacity of the model / transition slot tables (grows on demand)
-    std::vector<char> model_set, trans_set;
-};
-
 namespace {
-
-#define HIP_TRY(ctx, expr)                                  \
-    do {                                                    \
-        hipError_t e_ = (expr);                             \
-        if (e_ != hipSuccess) {                             \
-            (ctx)->last_hip = (int)e_;                      \
-            return e_ == hipErrorOutOfMemory ? NCHMM_E_NOMEM : NCHMM_E_HIP; \
-        }                                                   \
-    } while (0)
-
-int dev_alloc(nchmm_ctx* c, void** p, size_t bytes)
-{
-    HIP_TRY(c, hipMalloc(p, bytes));
-    c->counters[6] += bytes;
-    return NCHMM_OK;
-}
-
-int ensure(nchmm_ctx* c, void** p, size_t* have, size_t need)
-{
-    if (*have >= need) return NCHMM_OK;
-    if (*p) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipFree(*p));
-        c->counters[6] -= *have;
-        *p = nullptr; *have = 0;
-    }
-    need = need + need / 8;  // head-room so slowly growing batches do not reallocate every call
-    int rc = dev_alloc(c, p, need);
-    if (rc != NCHMM_OK) return rc;
-    *have = need;
-    return NCHMM_OK;
-}
 
 // Split the from_v CSR of compute_transitions_fast into w0[j] (stay), w1[r] (step group r = low 10
 // bits of the predecessor) and w2[q] (skip group q = low 8 bits of the predecessor).
@@ -315,20 +236,6 @@ int reserve_slots(nchmm_ctx* c, int n)
     return NCHMM_OK;
 }
 
-int check_offsets(size_t n, const uint64_t* off, size_t* max_events, size_t* total)
-{
-    size_t mx = 0;
-    if (n && !off) return NCHMM_E_INVALID;
-    for (size_t r = 0; r < n; ++r) {
-        if (off[r + 1] < off[r]) return NCHMM_E_INVALID;
-        mx = std::max<size_t>(mx, off[r + 1] - off[r]);
-    }
-    *max_events = mx;
-    *total = n ? (size_t)(off[n] - off[0]) : 0;
-    if (n && off[0] != 0) return NCHMM_E_INVALID;
-    return NCHMM_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -369,7 +276,9 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         for (uint32_t i = 0; i < nk; ++i) mask[km[i] >> 3] |= (uint8_t)(1u << (km[i] & 7));
         if (hipMemcpy(c->d_train_mask, mask.data(), 512, hipMemcpyHostToDevice) != hipSuccess) return fail(NCHMM_E_HIP);
     }
-    if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * (16 + 4096)))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_queue, sizeof(unsigned) * 16))) return fail(rc);
+    if ((rc = dev_alloc(c, (void**)&c->d_vq, sizeof(unsigned) * kQueueWords))) return fail(rc);
+    if (hipMemset(c->d_vq, 0, sizeof(unsigned) * kQueueWords) != hipSuccess) return fail(NCHMM_E_HIP);
     if ((rc = dev_alloc(c, (void**)&c->d_prof, sizeof(unsigned long long) * 6200))) return fail(rc);
     if (hipMemset(c->d_prof, 0, sizeof(unsigned long long) * 6200) != hipSuccess) return fail(NCHMM_E_HIP);
     if ((rc = dev_alloc(c, (void**)&c->d_fb_total, sizeof(unsigned long long)))) return fail(rc);
@@ -408,6 +317,9 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_trans_fb) (void)hipFree(c->d_trans_fb);
     if (c->d_train_mask) (void)hipFree(c->d_train_mask);
     if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_vq) (void)hipFree(c->d_vq);
+    if (c->s_in) { (void)hipStreamSynchronize(c->s_in); (void)hipStreamDestroy(c->s_in); }
+    pipe_destroy(c);
     if (c->d_model_fast) (void)hipFree(c->d_model_fast);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->d_ws) (void)hipFree(c->d_ws);
@@ -581,42 +493,59 @@ int nchmm_put_transitions(nchmm_ctx* c, int slot, const uint32_t* row_ptr, const
 
 }  // extern "C" (reopened below)
 
-namespace {
+namespace nchmm {
 
 // Launch forward + traceback for reads [first, first + count) whose events start at ev_base and
-// number ev_count.  d_order (may be null) is a permutation of exactly these reads.
-int launch_batch(nchmm_ctx* c, size_t first, size_t count, uint64_t ev_base, uint64_t ev_count, const uint64_t* d_off,
-                 const float* d_cmean, const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot,
-                 const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp,
-                 int32_t* d_out_status)
+// number ev_count, on L.stream, through the context's back-pointer workspace and work queue (so launches of one context
+// must execute one after the other: the callers order their streams with events).  d_order (may be null) is a
+// permutation of exactly these reads.
+int launch_viterbi_range(nchmm_ctx* c, const VitLane& L, size_t first, size_t count, uint64_t ev_base, uint64_t ev_count,
+                         const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                         const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
+                         float* d_out_logp, int32_t* d_out_status)
 {
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
     a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
     a.prof = c->profile ? c->d_prof : nullptr;
-    a.ws = c->d_ws; a.ev_base = ev_base; a.first_read = (unsigned)first; a.last_state = c->d_last_state;
+    a.ws = c->d_ws; a.ev_base = ev_base; a.first_read = (unsigned)first; a.last_state = L.last_state;
     a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
-    a.queue = c->d_queue; a.cu_progress = c->d_queue + 16; a.n_reads = (unsigned)count;
+    a.queue = c->d_vq; a.cu_progress = c->d_vq + 16; a.n_reads = (unsigned)count;
     a.tb_margin = c->tb_margin;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     const int grid = (int)std::min<size_t>((size_t)c->vit_slots, count);
-    HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (16 + 4096), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_vit0, c->stream));
-    launch_viterbi(a, grid, c->stream);
+    a.queue_base = c->vq_base;
+    c->vq_base += (unsigned)count + (unsigned)grid;   // every read takes a ticket, every block one more to find the queue empty
+    HIP_TRY(c, hipEventRecord(c->ev_vit0, L.stream));
+    launch_viterbi(a, grid, L.stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_vit1, c->stream));
-    launch_traceback(a, c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev_vit1, L.stream));
+    launch_traceback(a, L.stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_vit2, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_vit2, L.stream));
     c->vit_timed = true;
     c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kBpRowBytes;
     c->counters[3] += 2;
     return NCHMM_OK;
 }
 
-}  // namespace
+// Largest back-pointer workspace the context is willing to hold: NCHMM_WS_BUDGET_MB, else 60 % of what is free at first use
+int viterbi_ws_budget(nchmm_ctx* c, size_t* out)
+{
+    if (c->ws_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        const char* e = std::getenv("NCHMM_WS_BUDGET_MB");
+        c->ws_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : (free_b / 10) * 6;
+        if (c->ws_budget < ((size_t)16 << 20)) c->ws_budget = (size_t)16 << 20;
+    }
+    *out = c->ws_budget;
+    return NCHMM_OK;
+}
+
+}  // namespace nchmm
 
 extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
                       const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
@@ -627,6 +556,7 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
     if (n_reads == 0) return NCHMM_OK;
     if (!d_off || !d_out_logp || n_reads > 0xFFFFFFF0ull || max_events > 0x7FFFFFF0ull) return NCHMM_E_INVALID;
     if (total_events && (!d_cmean || !d_stdv || !d_lstdv || !d_out_state)) return NCHMM_E_INVALID;
+    if (pipe_in_flight(c)) return NCHMM_E_INVALID;   // the workspace and the queue words are in use (nchmm_viterbi_begin)
     HIP_TRY(c, hipSetDevice(c->device));
     void* p = c->d_last_state;
     int rc = ensure(c, &p, &c->last_state_bytes, sizeof(unsigned) * n_reads);
@@ -634,12 +564,9 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
     if (rc != NCHMM_OK) return rc;
     // Back-pointer workspace: kBpRowBytes (4 KiB: one byte per state) per event.  When the whole batch fits the budget it is one
     // forward + one traceback launch; otherwise the batch is cut into contiguous read ranges.
-    if (c->ws_budget == 0) {
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
-        const char* e = std::getenv("NCHMM_WS_BUDGET_MB");
-        c->ws_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : (free_b / 10) * 6;
-        if (c->ws_budget < ((size_t)16 << 20)) c->ws_budget = (size_t)16 << 20;
+    {
+        size_t budget = 0;
+        if ((rc = viterbi_ws_budget(c, &budget))) return rc;
     }
     const size_t need_all = std::max<size_t>(total_events, 1) * (size_t)kBpRowBytes;
     c->counters[0] += n_reads;
@@ -649,7 +576,7 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
         rc = ensure(c, &p, &c->ws_bytes, need_all);
         c->d_ws = (uint8_t*)p;
         if (rc != NCHMM_OK) return rc;
-        return launch_batch(c, 0, n_reads, 0, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
+        return launch_viterbi_range(c, VitLane{c->stream, c->d_last_state}, 0, n_reads, 0, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
                             d_order, d_out_state, d_out_logp, d_out_status);
     }
     // split: needs the offsets on the host (small copy), reads are taken in input order
@@ -675,7 +602,7 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
             const size_t trimmed = (last - first) / slots * slots;
             if (4 * ((last - first) - trimmed) < (last - first)) last = first + trimmed;
         }
-        rc = launch_batch(c, first, last - first, off[first], off[last] - off[first], d_off, d_cmean, d_stdv, d_lstdv,
+        rc = launch_viterbi_range(c, VitLane{c->stream, c->d_last_state}, first, last - first, off[first], off[last] - off[first], d_off, d_cmean, d_stdv, d_lstdv,
                           d_model_slot, d_trans_slot, nullptr, d_out_state, d_out_logp, d_out_status);
         if (rc != NCHMM_OK) return rc;
         first = last;
@@ -684,68 +611,6 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
 }
 
 extern "C" {
-
-int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float* cmean, const float* stdv,
-                  const float* lstdv, const int32_t* model_slot, const int32_t* trans_slot,
-                  uint16_t* out_state, float* out_logp, int32_t* out_status)
-{
-    if (!c) return NCHMM_E_INVALID;
-    if (n_reads == 0) return NCHMM_OK;
-    size_t max_events = 0, total = 0;
-    int rc = check_offsets(n_reads, off, &max_events, &total);
-    if (rc != NCHMM_OK) return rc;
-    if (!out_logp || (total && (!cmean || !stdv || !lstdv || !out_state))) return NCHMM_E_INVALID;
-    for (size_t r = 0; r < n_reads; ++r) {
-        const int ms = model_slot ? model_slot[r] : 0, ts = trans_slot ? trans_slot[r] : 0;
-        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts])
-            return NCHMM_E_INVALID;
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
-    // longest-first processing order (LPT) for the device work queue
-    std::vector<uint32_t> order(n_reads);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return off[a + 1] - off[a] > off[b + 1] - off[b];
-    });
-    // one staging allocation: [off | cmean | stdv | lstdv | mslot | tslot | order | state | logp | status]
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o_off = 0, o_cm = o_off + al(8 * (n_reads + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total);
-    size_t o_ms = o_ls + al(4 * total), o_ts = o_ms + al(4 * n_reads), o_or = o_ts + al(4 * n_reads);
-    size_t o_st = o_or + al(4 * n_reads), o_lp = o_st + al(2 * total), o_ss = o_lp + al(4 * n_reads);
-    size_t need = o_ss + al(4 * n_reads);
-    rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
-    if (rc != NCHMM_OK) return rc;
-    char* d = (char*)c->d_stage;
-    hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(d + o_off, off, 8 * (n_reads + 1), hipMemcpyHostToDevice, s));
-    if (total) {
-        // pageable memory is fine here: the runtime pins it in place and the copies run at PCIe rate (55 GB/s measured,
-        // tools/ubench/pcie_rate.py) -- 1.1 ms of a 17 ms call; staging through our own pinned buffer measured slower
-        HIP_TRY(c, hipMemcpyAsync(d + o_cm, cmean, 4 * total, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(d + o_sd, stdv, 4 * total, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(d + o_ls, lstdv, 4 * total, hipMemcpyHostToDevice, s));
-    }
-    if (model_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ms, model_slot, 4 * n_reads, hipMemcpyHostToDevice, s));
-    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_reads, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d + o_or, order.data(), 4 * n_reads, hipMemcpyHostToDevice, s));
-    rc = nchmm_viterbi_dev(c, n_reads, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm),
-                           (const float*)(d + o_sd), (const float*)(d + o_ls),
-                           model_slot ? (const int32_t*)(d + o_ms) : nullptr,
-                           trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or),
-                           (uint16_t*)(d + o_st), (float*)(d + o_lp), (int32_t*)(d + o_ss));
-    if (rc != NCHMM_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out_logp, d + o_lp, 4 * n_reads, hipMemcpyDeviceToHost, s));
-    std::vector<int32_t> status(n_reads);
-    HIP_TRY(c, hipMemcpyAsync(status.data(), d + o_ss, 4 * n_reads, hipMemcpyDeviceToHost, s));
-    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    int worst = NCHMM_OK;
-    for (size_t r = 0; r < n_reads; ++r) {
-        if (out_status) out_status[r] = status[r];
-        if (status[r] != 0) worst = NCHMM_E_NUMERIC;
-    }
-    return worst;
-}
 
 int nchmm_logf(nchmm_ctx* c, size_t n, const float* in, float* out)
 {
@@ -765,73 +630,6 @@ int nchmm_logf(nchmm_ctx* c, size_t n, const float* in, float* out)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return NCHMM_OK;
-}
-
-int nchmm_viterbi_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, const float* start, size_t n_cand,
-                      const uint64_t* src, const uint32_t* len, const float* drift, const int32_t* model_slot,
-                      const int32_t* trans_slot, uint16_t* out_state, float* out_logp, int32_t* out_status)
-{
-    if (!c) return NCHMM_E_INVALID;
-    if (n_cand == 0) return NCHMM_OK;
-    if (!src || !len || !drift || !out_logp || (n_raw && (!mean || !stdv || !start))) return NCHMM_E_INVALID;
-    std::vector<uint64_t> off(n_cand + 1, 0);
-    size_t max_events = 0;
-    for (size_t v = 0; v < n_cand; ++v) {
-        if (src[v] + len[v] > n_raw) return NCHMM_E_INVALID;
-        off[v + 1] = off[v] + len[v];
-        max_events = std::max<size_t>(max_events, len[v]);
-        const int ms = model_slot ? model_slot[v] : 0, ts = trans_slot ? trans_slot[v] : 0;
-        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts]) return NCHMM_E_INVALID;
-    }
-    const size_t total = (size_t)off[n_cand];
-    if (total && !out_state) return NCHMM_E_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<uint32_t> order(n_cand);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    // [raw mean | stdv | start | src | drift | off | cm | sd | ls | mslot | tslot | order | state | logp | status]
-    size_t o_rm = 0, o_rs = o_rm + al(4 * n_raw), o_rt = o_rs + al(4 * n_raw), o_src = o_rt + al(4 * n_raw), o_dr = o_src + al(8 * n_cand);
-    size_t o_off = o_dr + al(4 * n_cand), o_cm = o_off + al(8 * (n_cand + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total);
-    size_t o_ms = o_ls + al(4 * total), o_ts = o_ms + al(4 * n_cand), o_or = o_ts + al(4 * n_cand), o_st = o_or + al(4 * n_cand);
-    size_t o_lp = o_st + al(2 * total), o_ss = o_lp + al(4 * n_cand), need = o_ss + al(4 * n_cand);
-    int rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
-    if (rc != NCHMM_OK) return rc;
-    char* d = (char*)c->d_stage;
-    hipStream_t s = c->stream;
-    if (n_raw) {
-        HIP_TRY(c, hipMemcpyAsync(d + o_rm, mean, 4 * n_raw, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(d + o_rs, stdv, 4 * n_raw, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemcpyAsync(d + o_rt, start, 4 * n_raw, hipMemcpyHostToDevice, s));
-    }
-    HIP_TRY(c, hipMemcpyAsync(d + o_src, src, 8 * n_cand, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d + o_dr, drift, 4 * n_cand, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d + o_off, off.data(), 8 * (n_cand + 1), hipMemcpyHostToDevice, s));
-    if (model_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ms, model_slot, 4 * n_cand, hipMemcpyHostToDevice, s));
-    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_cand, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d + o_or, order.data(), 4 * n_cand, hipMemcpyHostToDevice, s));
-    EmGatherArgs g;
-    g.mean = (const float*)(d + o_rm); g.stdv = (const float*)(d + o_rs); g.start = (const float*)(d + o_rt); g.lstdv = nullptr;
-    g.win_src = (const uint64_t*)(d + o_src); g.off = (const uint64_t*)(d + o_off); g.win_drift = (const float*)(d + o_dr);
-    g.cmean = (float*)(d + o_cm); g.out_stdv = (float*)(d + o_sd); g.out_lstdv = (float*)(d + o_ls);
-    launch_em_gather(g, (unsigned)n_cand, s, (unsigned)max_events);
-    HIP_TRY(c, hipGetLastError());
-    rc = nchmm_viterbi_dev(c, n_cand, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
-                           (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
-                           trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or), (uint16_t*)(d + o_st),
-                           (float*)(d + o_lp), (int32_t*)(d + o_ss));
-    if (rc != NCHMM_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out_logp, d + o_lp, 4 * n_cand, hipMemcpyDeviceToHost, s));
-    std::vector<int32_t> status(n_cand);
-    HIP_TRY(c, hipMemcpyAsync(status.data(), d + o_ss, 4 * n_cand, hipMemcpyDeviceToHost, s));
-    if (total) HIP_TRY(c, hipMemcpyAsync(out_state, d + o_st, 2 * total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    int worst = NCHMM_OK;
-    for (size_t v = 0; v < n_cand; ++v) {
-        if (out_status) out_status[v] = status[v];
-        if (status[v] != 0) worst = NCHMM_E_NUMERIC;
-    }
-    return worst;
 }
 
 int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_events, const uint64_t* d_off,

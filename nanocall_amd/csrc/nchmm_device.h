@@ -45,12 +45,13 @@ struct ViterbiArgs {
     uint8_t* ws;               // back-pointer workspace: one kBpRowBytes row per event of the (sub-)batch
     uint64_t ev_base;          // off[first_read]: event index of the first row of the workspace
     unsigned first_read;       // reads [first_read, first_read + n_reads) form this (sub-)batch
-    unsigned* cu_progress;     // [4096] per (CU, block slot) events done in this launch; zeroed before launch
+    unsigned* cu_progress;     // [4096] per (CU, block slot) events done in this launch; every block zeroes its word on exit
     unsigned* last_state;      // [n_reads_total] arg-max state of the last column (forward -> traceback)
     uint16_t* out_state;
     float* out_logp;
     int32_t* out_status;
-    unsigned* queue;           // work-queue head, zeroed before launch
+    unsigned* queue;           // work-queue head: never reset -- this launch's tickets start at queue_base
+    unsigned queue_base;       // value of *queue when the launch starts (host-tracked: every launch adds n_reads + grid)
     unsigned n_reads;
     int tb_margin;             // events a speculative traceback segment runs before its first owned event
     float log_n_states;        // std::log(4096.f) from the host libm (Viterbi.hpp:51)

@@ -1,0 +1,467 @@
+// nchmm_pipeline.cpp -- the host-pointer Viterbi entry points (nchmm_viterbi, nchmm_viterbi_raw, and their
+// begin / end halves): copy-in on one stream, kernels on another, two batches in flight.
+//
+// The reference's caller hands over one strand at a time and hides every latency behind pfor worker threads
+// (nanocall.cpp:611-621, 645-690).  Here a call carries a batch of reads and the latencies to hide are the PCIe copies
+// either side of the kernels (12 B per event in, 2 B out, against ~3 ns of kernel time per event), and -- less
+// obviously -- the GPU's own clock management: after an idle gap of 2 ms the next 15 ms forward sweep runs 9 % slower,
+// after 20 ms 17 % slower (profiles/r04_hostpath_gap.json).  A caller that wants the device-resident rate from host
+// arrays must therefore keep kernels back to back, which one synchronous call per batch cannot do.
+//
+// What the timeline of the first attempt showed (profiles/r04_pipeline_timeline.md) and what follows from it:
+//   * The forward sweep is resident with every VGPR of every SIMD taken.  Anything the runtime implements as a shader
+//     kernel -- memsets, copies under 16 KiB, every device-to-host copy -- then waits for a free wave slot, i.e. for the
+//     whole sweep, and so does the traceback kernel of the previous range.  Only SDMA copies (host-to-device of >= 16 KiB)
+//     run beside a sweep.
+//       - no memset in front of a launch: queue tickets count up across launches (ViterbiArgs::queue_base)
+//       - the small inputs travel as ONE padded block from pinned memory (SDMA), on the copy-in stream
+//       - streaming outputs are not copied at all: the kernels write states / log-probs / status straight into a pinned
+//         host block (2 B per event over PCIe, posted writes); `end` moves them into the caller's arrays on the CPU
+//       - two compute lanes bought nothing (the traceback of range k starved until range k+1 had drained): one compute
+//         stream, and ranges as large as the workspace allows -- each costs one traceback latency (~0.45 ms)
+//   * HIP streams share a handful of hardware queues; a copy stream that lands on the compute stream's queue waits
+//     behind its kernels.  The pipeline therefore owns exactly one extra stream (copy-in) and computes on the context's
+//     own stream.
+//
+//   begin(k+1) queues the H2D copies of batch k+1 (they run under the kernels of batch k) and its kernels behind them;
+//   end(k) waits for batch k range by range and hands its results over while batch k+1 computes.
+#include "nanocall_hip.h"
+#include "nchmm_ctx.hpp"
+#include "nchmm_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+using namespace nchmm;
+
+namespace nchmm {
+
+struct PipeRange {
+    size_t r0, r1;       // reads [r0, r1)
+    uint64_t e0, e1;     // their events [e0, e1) of the packed arrays
+    uint64_t raw_hi;     // raw form: raw events [0, raw_hi) must be on the device before this range is gathered
+    size_t max_events;
+};
+
+// One batch in flight.
+struct PipeCall {
+    bool direct = false;              // one-call form: outputs in device memory, copied straight into the caller's arrays
+    size_t n = 0, total = 0;
+    std::vector<PipeRange> ranges;
+    std::vector<hipEvent_t> done;     // per range: kernels finished
+    std::vector<hipEvent_t> ev;       // this slot's events (created once, reused by every batch that takes the slot)
+    size_t ev_used = 0;
+    std::vector<uint64_t> h_off;
+    std::vector<uint32_t> h_order;
+    char* d = nullptr;                // this slot's device staging
+    char* h = nullptr;                // this slot's pinned host block: [small inputs | logp | status | states]
+    size_t h_bytes = 0;
+    size_t o_state = 0, o_logp = 0, o_status = 0;     // device staging offsets (direct form)
+    size_t ho_logp = 0, ho_status = 0, ho_state = 0;  // pinned block offsets (streaming form)
+    uint16_t* out_state = nullptr;
+    float* out_logp = nullptr;
+    int32_t* out_status = nullptr;
+    std::vector<int32_t> status;
+};
+
+struct PipeState {
+    PipeCall call[2];
+    void* d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    unsigned next_begin = 0, next_end = 0, in_flight = 0;
+};
+
+void pipe_destroy(nchmm_ctx* c)
+{
+    if (!c->pipe) return;
+    for (int s = 0; s < 2; ++s) {
+        if (c->pipe->d_stage[s]) (void)hipFree(c->pipe->d_stage[s]);
+        if (c->pipe->call[s].h) (void)hipHostFree(c->pipe->call[s].h);
+        for (hipEvent_t e : c->pipe->call[s].ev) (void)hipEventDestroy(e);
+    }
+    delete c->pipe;
+    c->pipe = nullptr;
+}
+
+int pipe_in_flight(const nchmm_ctx* c) { return c->pipe ? (int)c->pipe->in_flight : 0; }
+
+}  // namespace nchmm
+
+namespace {
+
+constexpr size_t kMinCopy = 64 << 10;      // copies below 16 KiB become shader kernels; stay well clear of the threshold
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int pipe_init(nchmm_ctx* c)
+{
+    if (!c->pipe) {
+        c->pipe = new (std::nothrow) PipeState();
+        if (!c->pipe) return NCHMM_E_NOMEM;
+    }
+    if (!c->s_in) HIP_TRY(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    return NCHMM_OK;
+}
+
+int pipe_event(nchmm_ctx* c, PipeCall& K, hipEvent_t* out)
+{
+    if (K.ev_used == K.ev.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        K.ev.push_back(e);
+    }
+    *out = K.ev[K.ev_used++];
+    return NCHMM_OK;
+}
+
+// Contiguous read ranges, as few as the workspace allows: every range costs one traceback latency during which the GPU
+// idles, and buys the overlap of its successor's copy-in.  A batch that fits is one range (its copy-in then overlaps the
+// previous BATCH, which is what a streaming caller gets); a large one is cut into >= 4 M-event ranges of >= 2 grid-fulls
+// of reads.  NCHMM_PIPE_READS (test hook) forces ranges of that many reads.
+int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events, std::vector<PipeRange>* out)
+{
+    uint64_t want_events = std::max<uint64_t>(cap_events / 2, (uint64_t)4 << 20);
+    size_t want_reads = std::max<size_t>(2 * slots, 1);
+    if (const char* e = std::getenv("NCHMM_PIPE_READS")) {
+        const long v = std::atol(e);
+        if (v > 0) { want_reads = (size_t)v; want_events = 0; }
+    }
+    out->clear();
+    if (n && off[n] - off[0] <= cap_events && want_events) {     // the whole batch fits
+        size_t mx = 0;
+        for (size_t r = 0; r < n; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
+        out->push_back(PipeRange{0, n, off[0], off[n], 0, mx});
+        return NCHMM_OK;
+    }
+    for (size_t r0 = 0; r0 < n;) {
+        size_t r1 = r0;
+        size_t mx = 0;
+        while (r1 < n) {
+            const uint64_t len = off[r1 + 1] - off[r1];
+            if (off[r1 + 1] - off[r0] > cap_events) break;
+            if (r1 - r0 >= want_reads && off[r1] - off[r0] >= want_events) break;
+            mx = std::max<size_t>(mx, (size_t)len);
+            ++r1;
+        }
+        if (r1 == r0) return NCHMM_E_NOMEM;   // (cannot happen: cap_events >= the longest read)
+        // a range that is not the last one drains evenly when it is a whole number of grid-fulls (see nchmm_viterbi_dev)
+        if (r1 < n && slots && r1 - r0 > slots && want_events) {
+            const size_t trimmed = (r1 - r0) / slots * slots;
+            if (4 * ((r1 - r0) - trimmed) < (r1 - r0)) {
+                r1 = r0 + trimmed;
+                mx = 0;
+                for (size_t r = r0; r < r1; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
+            }
+        }
+        out->push_back(PipeRange{r0, r1, off[r0], off[r1], 0, mx});
+        r0 = r1;
+    }
+    return NCHMM_OK;
+}
+
+struct PreparedIn { const float* cmean; const float* stdv; const float* lstdv; };
+struct RawIn { size_t n_raw; const float* mean; const float* stdv; const float* start; const uint64_t* src; const float* drift; };
+
+// Enqueue one batch.  off = n + 1 packed offsets (host).  direct: the one-call form (nothing else in flight).
+int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const int32_t* model_slot, const int32_t* trans_slot,
+               const PreparedIn* prep, const RawIn* raw, uint16_t* out_state, float* out_logp, int32_t* out_status, bool direct)
+{
+    int rc = pipe_init(c);
+    if (rc != NCHMM_OK) return rc;
+    PipeState* P = c->pipe;
+    if (P->in_flight >= 2) return NCHMM_E_INVALID;
+    const unsigned slot = P->next_begin;
+    PipeCall& K = P->call[slot];
+    K.ev_used = 0;
+    hipStream_t si = c->s_in, sr = c->own_stream;
+
+    size_t budget = 0;
+    if ((rc = viterbi_ws_budget(c, &budget))) return rc;
+    uint64_t longest = 1;
+    for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
+    const uint64_t cap_events = std::max<uint64_t>(budget / kBpRowBytes, longest);   // a read longer than the budget still runs, alone
+    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, cap_events, &K.ranges))) return rc;
+    const size_t n_ranges = K.ranges.size();
+    uint64_t ws_events = 1;
+    for (const PipeRange& g : K.ranges) ws_events = std::max<uint64_t>(ws_events, g.e1 - g.e0);
+
+    // longest-first processing order inside each range (the device work queue hands reads out in this order)
+    K.h_off.assign(off, off + n + 1);
+    off = K.h_off.data();
+    std::vector<uint32_t>& order = K.h_order;
+    order.resize(n);
+    std::iota(order.begin(), order.end(), 0u);
+    for (const PipeRange& g : K.ranges)
+        std::stable_sort(order.begin() + g.r0, order.begin() + g.r1,
+                         [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    if (raw) {
+        uint64_t hi = 0;
+        for (PipeRange& g : K.ranges) {
+            for (size_t v = g.r0; v < g.r1; ++v) hi = std::max<uint64_t>(hi, raw->src[v] + (off[v + 1] - off[v]));
+            g.raw_hi = hi;
+        }
+    }
+
+    // Device staging of this slot:
+    //   [ small: off | mslot | tslot | order | src | drift ]    one copy from the pinned block
+    //   [ last_state | cm | sd | ls | raw mean | stdv | start ]
+    //   [ logp | status | state ]                               direct form only
+    // Pinned host block:  [ small (as above) | logp | status | state ]   (the outputs: streaming form only)
+    const size_t n_raw = raw ? raw->n_raw : 0;
+    size_t o_off = 0, o_ms = o_off + al256(8 * (n + 1)), o_ts = o_ms + al256(4 * n), o_or = o_ts + al256(4 * n);
+    size_t o_src = o_or + al256(4 * n), o_dr = o_src + (raw ? al256(8 * n) : 0);
+    const size_t small_bytes = std::max<size_t>(o_dr + (raw ? al256(4 * n) : 0), kMinCopy);
+    size_t o_last = small_bytes, o_cm = o_last + al256(4 * n), o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total);
+    size_t o_rm = o_ls + al256(4 * total), o_rs = o_rm + al256(4 * n_raw), o_rt = o_rs + al256(4 * n_raw);
+    size_t o_lp = o_rt + al256(4 * n_raw), o_ss = o_lp + al256(4 * n), o_st = o_ss + al256(4 * n);
+    const size_t need = direct ? o_st + al256(2 * total) : o_lp;
+    const size_t ho_lp = small_bytes, ho_ss = ho_lp + al256(4 * n), ho_st = ho_ss + al256(4 * n);
+    const size_t h_need = direct ? small_bytes : ho_st + al256(2 * total);
+    // (this slot's buffers: nothing in flight uses them)
+    if ((rc = ensure(c, &P->d_stage[slot], &P->stage_bytes[slot], need))) return rc;
+    if (K.h_bytes < h_need) {
+        if (K.h) { HIP_TRY(c, hipHostFree(K.h)); K.h = nullptr; K.h_bytes = 0; }
+        void* hp = nullptr;
+        HIP_TRY(c, hipHostMalloc(&hp, h_need + h_need / 8, hipHostMallocDefault));
+        K.h = (char*)hp; K.h_bytes = h_need + h_need / 8;
+    }
+    if (c->ws_bytes < (size_t)ws_events * kBpRowBytes) {
+        if (P->in_flight) HIP_TRY(c, hipStreamSynchronize(sr));       // the batch in flight is using the workspace
+        void* p = c->d_ws;
+        rc = ensure(c, &p, &c->ws_bytes, (size_t)ws_events * kBpRowBytes);
+        c->d_ws = (uint8_t*)p;
+        if (rc != NCHMM_OK) return rc;
+    }
+    char* const d = (char*)P->d_stage[slot];
+    K.direct = direct; K.n = n; K.total = total; K.d = d;
+    K.o_state = o_st; K.o_logp = o_lp; K.o_status = o_ss;
+    K.ho_logp = ho_lp; K.ho_status = ho_ss; K.ho_state = ho_st;
+    K.out_state = out_state; K.out_logp = out_logp; K.out_status = out_status;
+    K.done.assign(n_ranges, nullptr);
+    // where the kernels write: device staging (direct) or the pinned block (hipHostMalloc memory is device-visible at its
+    // host address)
+    uint16_t* const k_state = direct ? (uint16_t*)(d + o_st) : (uint16_t*)(K.h + ho_st);
+    float* const k_logp = direct ? (float*)(d + o_lp) : (float*)(K.h + ho_lp);
+    int32_t* const k_status = direct ? (int32_t*)(d + o_ss) : (int32_t*)(K.h + ho_ss);
+
+    // the batch starts after whatever the caller queued on the context's stream (table uploads, device-pointer calls)
+    if (c->stream != sr) {
+        hipEvent_t ev_entry;
+        if ((rc = pipe_event(c, K, &ev_entry))) return rc;
+        HIP_TRY(c, hipEventRecord(ev_entry, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(sr, ev_entry, 0));
+    }
+
+    std::memcpy(K.h + o_off, off, 8 * (n + 1));
+    if (model_slot) std::memcpy(K.h + o_ms, model_slot, 4 * n);
+    if (trans_slot) std::memcpy(K.h + o_ts, trans_slot, 4 * n);
+    std::memcpy(K.h + o_or, order.data(), 4 * n);
+    if (raw) {
+        std::memcpy(K.h + o_src, raw->src, 8 * n);
+        std::memcpy(K.h + o_dr, raw->drift, 4 * n);
+    }
+    HIP_TRY(c, hipMemcpyAsync(d, K.h, small_bytes, hipMemcpyHostToDevice, si));
+    uint64_t raw_up = 0;
+    for (size_t k = 0; k < n_ranges; ++k) {
+        const PipeRange& g = K.ranges[k];
+        const size_t ne = (size_t)(g.e1 - g.e0);
+        // pageable sources: the runtime pins the pages in place and the SDMA engines read them at PCIe rate; the call
+        // returns when the copy is done, so the launches below are queued range by range right behind their data
+        if (raw) {
+            if (g.raw_hi > raw_up) {
+                const size_t m = (size_t)(g.raw_hi - raw_up);
+                HIP_TRY(c, hipMemcpyAsync(d + o_rm + 4 * raw_up, raw->mean + raw_up, 4 * m, hipMemcpyHostToDevice, si));
+                HIP_TRY(c, hipMemcpyAsync(d + o_rs + 4 * raw_up, raw->stdv + raw_up, 4 * m, hipMemcpyHostToDevice, si));
+                HIP_TRY(c, hipMemcpyAsync(d + o_rt + 4 * raw_up, raw->start + raw_up, 4 * m, hipMemcpyHostToDevice, si));
+                raw_up = g.raw_hi;
+            }
+        } else if (ne) {
+            HIP_TRY(c, hipMemcpyAsync(d + o_cm + 4 * g.e0, prep->cmean + g.e0, 4 * ne, hipMemcpyHostToDevice, si));
+            HIP_TRY(c, hipMemcpyAsync(d + o_sd + 4 * g.e0, prep->stdv + g.e0, 4 * ne, hipMemcpyHostToDevice, si));
+            HIP_TRY(c, hipMemcpyAsync(d + o_ls + 4 * g.e0, prep->lstdv + g.e0, 4 * ne, hipMemcpyHostToDevice, si));
+        }
+        hipEvent_t ev_in;
+        if ((rc = pipe_event(c, K, &ev_in))) return rc;
+        HIP_TRY(c, hipEventRecord(ev_in, si));
+        HIP_TRY(c, hipStreamWaitEvent(sr, ev_in, 0));
+        if (raw) {
+            EmGatherArgs ga;
+            ga.mean = (const float*)(d + o_rm); ga.stdv = (const float*)(d + o_rs); ga.start = (const float*)(d + o_rt); ga.lstdv = nullptr;
+            ga.win_src = (const uint64_t*)(d + o_src) + g.r0; ga.off = (const uint64_t*)(d + o_off) + g.r0;
+            ga.win_drift = (const float*)(d + o_dr) + g.r0;
+            ga.cmean = (float*)(d + o_cm); ga.out_stdv = (float*)(d + o_sd); ga.out_lstdv = (float*)(d + o_ls);
+            launch_em_gather(ga, (unsigned)(g.r1 - g.r0), sr, (unsigned)g.max_events);
+            HIP_TRY(c, hipGetLastError());
+        }
+        rc = launch_viterbi_range(c, VitLane{sr, (unsigned*)(d + o_last)}, g.r0, g.r1 - g.r0, g.e0, g.e1 - g.e0,
+                                  (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
+                                  (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
+                                  trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or) + g.r0, k_state, k_logp,
+                                  k_status);
+        if (rc != NCHMM_OK) return rc;
+        if ((rc = pipe_event(c, K, &K.done[k]))) return rc;
+        HIP_TRY(c, hipEventRecord(K.done[k], sr));
+    }
+    c->counters[0] += n;
+    c->counters[1] += total;
+    P->next_begin ^= 1u;
+    P->in_flight += 1;
+    return NCHMM_OK;
+}
+
+// Hand over the oldest batch in flight.
+int pipe_end(nchmm_ctx* c)
+{
+    PipeState* P = c->pipe;
+    if (!P || P->in_flight == 0) return NCHMM_E_INVALID;
+    PipeCall& K = P->call[P->next_end];
+    hipStream_t sr = c->own_stream;
+    auto body = [&]() -> int {
+        K.status.resize(K.n);
+        if (K.direct) {
+            // nothing is queued behind a lone batch, so the runtime's shader copies into the caller's pageable arrays start
+            // at once (they hold this thread until they are done)
+            HIP_TRY(c, hipMemcpyAsync(K.out_logp, K.d + K.o_logp, 4 * K.n, hipMemcpyDeviceToHost, sr));
+            HIP_TRY(c, hipMemcpyAsync(K.status.data(), K.d + K.o_status, 4 * K.n, hipMemcpyDeviceToHost, sr));
+            if (K.total) HIP_TRY(c, hipMemcpyAsync(K.out_state, K.d + K.o_state, 2 * K.total, hipMemcpyDeviceToHost, sr));
+            HIP_TRY(c, hipStreamSynchronize(sr));
+            return NCHMM_OK;
+        }
+        // range by range as each finishes: pinned block -> the caller's arrays on this thread, under the kernels of the
+        // ranges and the batch behind it
+        for (size_t k = 0; k < K.ranges.size(); ++k) {
+            const PipeRange& g = K.ranges[k];
+            HIP_TRY(c, hipEventSynchronize(K.done[k]));
+            if (g.e1 > g.e0) std::memcpy(K.out_state + g.e0, K.h + K.ho_state + 2 * g.e0, 2 * (size_t)(g.e1 - g.e0));
+            std::memcpy(K.out_logp + g.r0, K.h + K.ho_logp + 4 * g.r0, 4 * (g.r1 - g.r0));
+            std::memcpy(K.status.data() + g.r0, K.h + K.ho_status + 4 * g.r0, 4 * (g.r1 - g.r0));
+        }
+        return NCHMM_OK;
+    };
+    const int rc = body();
+    if (rc != NCHMM_OK) {
+        // leave nothing of this batch running behind the caller's back
+        (void)hipStreamSynchronize(c->s_in);
+        (void)hipStreamSynchronize(sr);
+    }
+    P->next_end ^= 1u;
+    P->in_flight -= 1;
+    if (rc != NCHMM_OK) return rc;
+    int worst = NCHMM_OK;
+    for (size_t r = 0; r < K.n; ++r) {
+        if (K.out_status) K.out_status[r] = K.status[r];
+        if (K.status[r] != 0) worst = NCHMM_E_NUMERIC;
+    }
+    return worst;
+}
+
+int check_slots(const nchmm_ctx* c, size_t n, const int32_t* model_slot, const int32_t* trans_slot)
+{
+    for (size_t r = 0; r < n; ++r) {
+        const int ms = model_slot ? model_slot[r] : 0, ts = trans_slot ? trans_slot[r] : 0;
+        if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts]) return NCHMM_E_INVALID;
+    }
+    return NCHMM_OK;
+}
+
+// a begin that failed half-way may have queued work: drain it so the slot's buffers can be reused
+int fail_drain(nchmm_ctx* c, int rc)
+{
+    if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+    (void)hipStreamSynchronize(c->own_stream);
+    return rc;
+}
+
+int begin_prepared(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float* cmean, const float* stdv, const float* lstdv,
+                   const int32_t* model_slot, const int32_t* trans_slot, uint16_t* out_state, float* out_logp, int32_t* out_status,
+                   bool direct)
+{
+    if (!c || n_reads == 0 || n_reads > 0xFFFFFFF0ull) return NCHMM_E_INVALID;
+    size_t max_events = 0, total = 0;
+    int rc = check_offsets(n_reads, off, &max_events, &total);
+    if (rc != NCHMM_OK) return rc;
+    if (max_events > 0x7FFFFFF0ull) return NCHMM_E_INVALID;
+    if (!out_logp || (total && (!cmean || !stdv || !lstdv || !out_state))) return NCHMM_E_INVALID;
+    if ((rc = check_slots(c, n_reads, model_slot, trans_slot))) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const PreparedIn in{cmean, stdv, lstdv};
+    rc = pipe_begin(c, n_reads, off, total, model_slot, trans_slot, &in, nullptr, out_state, out_logp, out_status, direct);
+    return rc == NCHMM_OK ? rc : fail_drain(c, rc);
+}
+
+int begin_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, const float* start, size_t n_cand, const uint64_t* src,
+              const uint32_t* len, const float* drift, const int32_t* model_slot, const int32_t* trans_slot, uint16_t* out_state,
+              float* out_logp, int32_t* out_status, bool direct)
+{
+    if (!c || n_cand == 0 || n_cand > 0xFFFFFFF0ull) return NCHMM_E_INVALID;
+    if (!src || !len || !drift || !out_logp || (n_raw && (!mean || !stdv || !start))) return NCHMM_E_INVALID;
+    std::vector<uint64_t> off(n_cand + 1, 0);
+    for (size_t v = 0; v < n_cand; ++v) {
+        if (src[v] + len[v] > n_raw) return NCHMM_E_INVALID;
+        off[v + 1] = off[v] + len[v];
+    }
+    const size_t total = (size_t)off[n_cand];
+    if (total && !out_state) return NCHMM_E_INVALID;
+    int rc = check_slots(c, n_cand, model_slot, trans_slot);
+    if (rc != NCHMM_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const RawIn in{n_raw, mean, stdv, start, src, drift};
+    rc = pipe_begin(c, n_cand, off.data(), total, model_slot, trans_slot, nullptr, &in, out_state, out_logp, out_status, direct);
+    return rc == NCHMM_OK ? rc : fail_drain(c, rc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nchmm_viterbi_begin(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float* cmean, const float* stdv,
+                        const float* lstdv, const int32_t* model_slot, const int32_t* trans_slot, uint16_t* out_state,
+                        float* out_logp, int32_t* out_status)
+{
+    return begin_prepared(c, n_reads, off, cmean, stdv, lstdv, model_slot, trans_slot, out_state, out_logp, out_status, false);
+}
+
+int nchmm_viterbi_raw_begin(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, const float* start, size_t n_cand,
+                            const uint64_t* src, const uint32_t* len, const float* drift, const int32_t* model_slot,
+                            const int32_t* trans_slot, uint16_t* out_state, float* out_logp, int32_t* out_status)
+{
+    return begin_raw(c, n_raw, mean, stdv, start, n_cand, src, len, drift, model_slot, trans_slot, out_state, out_logp, out_status, false);
+}
+
+int nchmm_viterbi_end(nchmm_ctx* c)
+{
+    if (!c) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return pipe_end(c);
+}
+
+int nchmm_viterbi_in_flight(const nchmm_ctx* c) { return c ? pipe_in_flight(c) : 0; }
+
+int nchmm_viterbi(nchmm_ctx* c, size_t n_reads, const uint64_t* off, const float* cmean, const float* stdv,
+                  const float* lstdv, const int32_t* model_slot, const int32_t* trans_slot,
+                  uint16_t* out_state, float* out_logp, int32_t* out_status)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_reads == 0) return NCHMM_OK;
+    if (pipe_in_flight(c)) return NCHMM_E_INVALID;   // the one-call form returns THIS batch's results
+    const int rc = begin_prepared(c, n_reads, off, cmean, stdv, lstdv, model_slot, trans_slot, out_state, out_logp, out_status, true);
+    return rc == NCHMM_OK ? nchmm_viterbi_end(c) : rc;
+}
+
+int nchmm_viterbi_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, const float* start, size_t n_cand,
+                      const uint64_t* src, const uint32_t* len, const float* drift, const int32_t* model_slot,
+                      const int32_t* trans_slot, uint16_t* out_state, float* out_logp, int32_t* out_status)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (n_cand == 0) return NCHMM_OK;
+    if (pipe_in_flight(c)) return NCHMM_E_INVALID;
+    const int rc = begin_raw(c, n_raw, mean, stdv, start, n_cand, src, len, drift, model_slot, trans_slot, out_state, out_logp,
+                             out_status, true);
+    return rc == NCHMM_OK ? nchmm_viterbi_end(c) : rc;
+}
+
+}  // extern "C"

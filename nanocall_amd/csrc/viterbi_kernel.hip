@@ -438,7 +438,9 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         // `if (tau == 0)` apart from this one (back to back across the loop edge LLVM may thread the two tests
         // together and send every other lane straight to the barrier below -- see fwbw_scaled_kernel.hip)
         __syncthreads();
-        if (tau == 0) sWork = atomicAdd(P.queue, 1u);
+        // tickets count up across launches (no memset in front of the kernel: a fill kernel queued behind a resident
+        // forward sweep waits for a free wave slot, i.e. for the whole sweep -- profiles/r04_pipeline_timeline.md)
+        if (tau == 0) sWork = atomicAdd(P.queue, 1u) - P.queue_base;
         __syncthreads();
         const unsigned widx = sWork;
         if (widx >= P.n_reads) break;
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         }
         // the other waves wait for the traceback at the top-of-loop barrier; the workspace is reused
     }
+    if ((tau & 63u) == 0) __hip_atomic_store(my_progress, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the slot's word as found
     if (P.prof && tau == 0) {
         atomicAdd(&P.prof[0], t_fwd);
         atomicAdd(&P.prof[1], t_tb);

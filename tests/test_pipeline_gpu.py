@@ -1,0 +1,80 @@
+"""The host-pointer pipeline (nchmm_pipeline.cpp): a batch cut into read ranges over a copy-in stream, two compute lanes and
+a copy-out stream must decode exactly what one launch decodes -- i.e. what the oracle decodes (Viterbi.hpp:44-142)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import nanocall_amd as na
+from helpers import IDENT, ragged_batch, oracle_viterbi_batch, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["NC_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NC_ROOT"], "tests")); sys.path.insert(0, os.path.join(os.environ["NC_ROOT"], "oracle"))
+import nanocall_amd as na
+from helpers import IDENT, ragged_batch, oracle_viterbi_batch
+t = na.builtin_model("r73.t")
+lens = [300, 17, 0, 256, 1, 511, 90, 700, 33, 257, 64, 5, 400, 128]
+off, mean, stdv, start, cm, sd, ls = ragged_batch(t, lens, first_read=21)
+with na.Context(0) as ctx:
+    ctx.put_model(0, na.scaled_model_table(t, IDENT)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    st, lp, status = ctx.viterbi(off, cm, sd, ls)
+    launches = int(ctx.counters()[3]) // 2
+    src = off[:-1].astype(np.uint64); ln = np.diff(off.astype(np.int64)).astype(np.uint32)
+    st2, lp2, status2 = ctx.viterbi_raw(mean, stdv, start, src, ln, np.zeros(len(lens), np.float32))
+ost, olp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+nz = np.diff(off.astype(np.int64)) > 0
+print(json.dumps({"launches": launches, "states_equal": bool(np.array_equal(st, ost)), "logp_equal": bool(lp[nz].tobytes() == olp[nz].tobytes()),
+                  "status_ok": bool((status == 0).all()), "raw_equal": bool(np.array_equal(st2, ost) and lp2[nz].tobytes() == olp[nz].tobytes()),
+                  "empty_nan": bool(np.isnan(lp[~nz]).all())}))
+"""
+
+
+@pytest.mark.parametrize("reads_per_range", [1, 3, 5])
+def test_forced_ranges_match_the_oracle(reads_per_range):
+    """NCHMM_PIPE_READS (test hook) cuts 14 ragged reads -- one of them empty -- into 14 / 5 / 3 ranges: every range
+    boundary, both lanes, the per-range LPT order, the prepared AND the raw (device gather) form, against the oracle."""
+    env = dict(os.environ, NCHMM_PIPE_READS=str(reads_per_range), NC_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-c", _CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["launches"] >= 3, out
+    assert out["states_equal"] and out["logp_equal"] and out["status_ok"] and out["raw_equal"] and out["empty_nan"], out
+
+
+def test_two_batches_in_flight_equal_one_call_each(gpu_ctx, r73t):
+    """begin(0); begin(1); end(0); begin(2); end(1); end(2) -- a streaming caller -- returns for every batch what the
+    one-call form returns, which is what the oracle returns."""
+    gpu_ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+    gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    batches = [ragged_batch(r73t, lens, first_read=fr) for lens, fr in (([200, 31, 400], 1), ([64, 0, 129, 500, 7], 9), ([350], 30))]
+    t0 = gpu_ctx.viterbi_begin(batches[0][0], *batches[0][4:])
+    t1 = gpu_ctx.viterbi_begin(batches[1][0], *batches[1][4:])
+    assert gpu_ctx.viterbi_in_flight() == 2
+    with pytest.raises(na.NchmmError):       # a third one has no slot
+        gpu_ctx.viterbi_begin(batches[2][0], *batches[2][4:])
+    with pytest.raises(na.NchmmError):       # and the one-call form would have to jump the queue
+        gpu_ctx.viterbi(batches[2][0], *batches[2][4:])
+    r0 = gpu_ctx.viterbi_end(t0)
+    t2 = gpu_ctx.viterbi_begin(batches[2][0], *batches[2][4:])
+    r1 = gpu_ctx.viterbi_end(t1)
+    r2 = gpu_ctx.viterbi_end(t2)
+    assert gpu_ctx.viterbi_in_flight() == 0
+    for (off, mean, stdv, start, cm, sd, ls), (st, lp, status) in zip(batches, (r0, r1, r2)):
+        ost, olp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        nz = np.diff(off.astype(np.int64)) > 0
+        assert np.array_equal(st, ost)
+        assert_bits_equal(lp[nz], olp[nz], "path probability")
+        assert (status == 0).all()
+    with pytest.raises(na.NchmmError):       # nothing left to end
+        gpu_ctx.viterbi_end(t2)
+    # and the context still serves the one-call form
+    st, lp, status = gpu_ctx.viterbi(batches[0][0], *batches[0][4:])
+    assert np.array_equal(st, r0[0])
