@@ -466,17 +466,23 @@ class Context:
         return dict(pm=pm, st=st, fit=fit, rounds=rounds, preferred=pref)
 
     def basecall_reads(self, opts, model_states, strand_off, mean, stdv, start, job_read, job_m0, job_m1, job_pm, job_st,
-                       preferred=None):
-        """nchmm_basecall_reads -> dict(states u16[total], best_job i32[n_reads,2], best_logp f32[n_reads,2])."""
+                       preferred=None, out=None):
+        """nchmm_basecall_reads -> dict(states u16[total], best_job i32[n_reads,2], best_logp f32[n_reads,2]).
+        `out` = a previous result to write into (a caller that decodes chunk after chunk reuses its arrays, as the command
+        line does; fresh zero pages cost a fault each when the winners are copied in)."""
         st10 = _f32(model_states).reshape(-1, S, 10)
         so = np.ascontiguousarray(strand_off, np.uint64)
         n_reads = (so.shape[0] - 1) // 2
         jr, j0, j1 = (np.ascontiguousarray(a, np.int32) for a in (job_read, job_m0, job_m1))
         pm, st = _f32(job_pm).reshape(-1, 6), _f32(job_st).reshape(-1, 4)
         pref = None if preferred is None else np.ascontiguousarray(preferred, np.int32).reshape(n_reads, 3)
-        states = np.zeros(int(so[-1]), np.uint16)
-        bj = np.empty((n_reads, 2), np.int32)
-        bl = np.empty((n_reads, 2), np.float32)
+        if out is not None:
+            states, bj, bl = out["states"], out["best_job"], out["best_logp"]
+            assert states.shape[0] >= int(so[-1]) and bj.shape == (n_reads, 2) and bl.shape == (n_reads, 2)
+        else:
+            states = np.zeros(int(so[-1]), np.uint16)
+            bj = np.empty((n_reads, 2), np.int32)
+            bl = np.empty((n_reads, 2), np.float32)
         rc = lib().nchmm_basecall_reads(self._h, C.byref(opts), st10.shape[0], _p(st10), n_reads, _p(so), _p(_f32(mean)),
                                         _p(_f32(stdv)), _p(_f32(start)), jr.shape[0], _p(jr), _p(j0), _p(j1), _p(pm), _p(st),
                                         _p(pref), _p(states), _p(bj), _p(bl))

@@ -185,15 +185,20 @@ const MaskTables& mask_tables()
     return T;
 }
 
+}  // namespace
+
 // log weight of every overlap mask that occurs, for compute_transitions_fast(p_skip, p_stay)
-void mask_weights(float p_skip, float p_stay, float wm[64])
+void nchmm::mask_weights(float p_skip, float p_stay, float wm[64])
 {
     const MaskTables& T = mask_tables();
     float p_step, p_skip_1;
     step_params(p_skip, p_stay, p_step, p_skip_1);
+    const TransPow pw(p_skip_1);
     for (unsigned m = 0; m < 64; ++m)
-        wm[m] = T.used[m] ? std::log(trans_prob(T.rep_i[m], T.rep_j[m], p_stay, p_step, p_skip_1)) : 0.0f;
+        wm[m] = T.used[m] ? std::log(trans_prob(T.rep_i[m], T.rep_j[m], p_stay, p_step, pw)) : 0.0f;
 }
+
+namespace {
 
 int pinned(nchmm_ctx* c, size_t bytes, void** out)
 {

@@ -85,6 +85,7 @@ int launch_viterbi_range(nchmm_ctx* c, const VitLane& L, size_t first, size_t co
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
                          float* d_out_logp, int32_t* d_out_status);
 int viterbi_ws_budget(nchmm_ctx* c, size_t* out);
+void mask_weights(float p_skip, float p_stay, float wm[64]);   // nchmm_api.cpp
 
 #define HIP_TRY(ctx, expr)                                  \
     do {                                                    \

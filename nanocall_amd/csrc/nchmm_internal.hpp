@@ -6,23 +6,34 @@
 #include <algorithm>
 #include <cmath>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "nchmm_kmer.hpp"
 
 namespace nchmm {
 
+// Host worker pool (nchmm_host.cpp): created on first use -- after the command line has forked its reader processes --
+// and kept: a parallel_for used to spawn and join up to 32 std::threads per call (~1-2 ms), which was most of the host
+// share of an EM round and of the decode prologue.  Size = the CPUs this process may run on (sched_getaffinity), at most 32;
+// NCHMM_HOST_THREADS overrides.  run_chunks calls fn(arg, i) for i in [0, n_chunks), chunk 0 on the calling thread; if
+// another thread is using the pool the caller runs every chunk itself.
+unsigned host_threads();
+void run_chunks(unsigned n_chunks, void (*fn)(void*, unsigned), void* arg);
+
 // f(begin, end) over [0, n) on the host cores (the work items are independent)
 template <typename F>
 void parallel_for(size_t n, F&& f)
 {
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt ? std::min<unsigned>(nt, 32) : 4;
+    unsigned nt = host_threads();
     if (n < 4 || nt < 2) { f(0, n); return; }
     nt = (unsigned)std::min<size_t>(nt, n);
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nt; ++i) th.emplace_back([&, i] { f(n * i / nt, n * (i + 1) / nt); });
-    for (auto& t : th) t.join();
+    using Fn = typename std::remove_reference<F>::type;
+    struct Job { Fn* f; size_t n; unsigned nt; } job{&f, n, nt};
+    run_chunks(nt, [](void* a, unsigned i) {
+        Job* j = static_cast<Job*>(a);
+        (*j->f)(j->n * i / j->nt, j->n * (i + 1) / j->nt);
+    }, &job);
 }
 
 
@@ -36,6 +47,31 @@ inline float trans_prob(unsigned i, unsigned j, float p_stay, float p_step, floa
         if (Kmer6::suffix(i, 6 - l) == Kmer6::prefix(j, 6 - l))
             p += std::pow(static_cast<double>(p_skip_1), static_cast<double>(l - 1)) / (1u << (2 * l));
     p += (std::pow(static_cast<double>(p_skip_1), 5.0) / (1.0f - p_skip_1)) / 4096u;
+    return p;
+}
+
+// The same sum with the pow() terms of one p_skip_1 taken from a table: pw[l] = pow(p_skip_1, l) for l = 1..4 (double),
+// tail = (pow(p_skip_1, 5.0) / (1.0f - p_skip_1)) / 4096u.  pow is a pure function, so every addend -- and the order they
+// are added in -- is the one trans_prob forms; evaluating a transition table's 18 distinct overlap masks costs 5 pow calls
+// instead of ~60.
+struct TransPow {
+    double pw[5];
+    double tail;
+    explicit TransPow(float p_skip_1)
+    {
+        pw[0] = 1.0;
+        for (unsigned l = 1; l < 5; ++l) pw[l] = std::pow(static_cast<double>(p_skip_1), static_cast<double>(l));
+        tail = (std::pow(static_cast<double>(p_skip_1), 5.0) / (1.0f - p_skip_1)) / 4096u;
+    }
+};
+inline float trans_prob(unsigned i, unsigned j, float p_stay, float p_step, const TransPow& T)
+{
+    float p = 0;
+    if (i == j) p += p_stay;
+    if (Kmer6::suffix(i, 5) == Kmer6::prefix(j, 5)) p += p_step / 4;
+    for (unsigned l = 2; l < 6; ++l)
+        if (Kmer6::suffix(i, 6 - l) == Kmer6::prefix(j, 6 - l)) p += T.pw[l - 1] / (1u << (2 * l));
+    p += T.tail;
     return p;
 }
 

@@ -28,6 +28,8 @@
 #include "nanocall_hip.h"
 #include "nchmm_ctx.hpp"
 #include "nchmm_device.h"
+#include "nchmm_internal.hpp"
+#include "nchmm_pipe.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -118,47 +120,52 @@ int pipe_event(nchmm_ctx* c, PipeCall& K, hipEvent_t* out)
     return NCHMM_OK;
 }
 
-// Contiguous read ranges, as few as the workspace allows: every range costs one traceback latency during which the GPU
-// idles, and buys the overlap of its successor's copy-in.  A batch that fits is one range (its copy-in then overlaps the
-// previous BATCH, which is what a streaming caller gets); a large one is cut into >= 4 M-event ranges of >= 2 grid-fulls
-// of reads.  NCHMM_PIPE_READS (test hook) forces ranges of that many reads.
+// Contiguous read ranges.  Every range costs one traceback latency (~0.45 ms during which the GPU is nearly idle) and
+// buys the overlap of its successor's copy-in with its own kernels; the FIRST range's copy-in is overlapped with nothing.
+//   * up to two grid-fulls of reads (the 1024-read batches a streaming caller sends): one range -- its copy-in overlaps the
+//     previous BATCH instead
+//   * larger: one grid-full first (short head), then ranges that double, capped by the back-pointer workspace; a short
+//     remainder joins its predecessor.  Inner ranges are whole grid-fulls (they drain evenly, see nchmm_viterbi_dev).
+// NCHMM_PIPE_READS (test hook) forces ranges of that many reads.
 int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events, std::vector<PipeRange>* out)
 {
-    uint64_t want_events = std::max<uint64_t>(cap_events / 2, (uint64_t)4 << 20);
-    size_t want_reads = std::max<size_t>(2 * slots, 1);
+    slots = std::max<size_t>(slots, 1);
+    size_t forced = 0;
     if (const char* e = std::getenv("NCHMM_PIPE_READS")) {
         const long v = std::atol(e);
-        if (v > 0) { want_reads = (size_t)v; want_events = 0; }
+        if (v > 0) forced = (size_t)v;
     }
-    out->clear();
-    if (n && off[n] - off[0] <= cap_events && want_events) {     // the whole batch fits
+    auto range_of = [&](size_t r0, size_t r1) {
         size_t mx = 0;
-        for (size_t r = 0; r < n; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
-        out->push_back(PipeRange{0, n, off[0], off[n], 0, mx});
+        for (size_t r = r0; r < r1; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
+        return PipeRange{r0, r1, off[r0], off[r1], 0, mx};
+    };
+    out->clear();
+    if (!forced && n <= 2 * slots && off[n] - off[0] <= cap_events) {
+        out->push_back(range_of(0, n));
         return NCHMM_OK;
     }
+    size_t want_reads = forced ? forced : slots;
+    uint64_t want_events = forced ? 0 : (uint64_t)1 << 20;
     for (size_t r0 = 0; r0 < n;) {
         size_t r1 = r0;
-        size_t mx = 0;
         while (r1 < n) {
-            const uint64_t len = off[r1 + 1] - off[r1];
             if (off[r1 + 1] - off[r0] > cap_events) break;
             if (r1 - r0 >= want_reads && off[r1] - off[r0] >= want_events) break;
-            mx = std::max<size_t>(mx, (size_t)len);
             ++r1;
         }
         if (r1 == r0) return NCHMM_E_NOMEM;   // (cannot happen: cap_events >= the longest read)
-        // a range that is not the last one drains evenly when it is a whole number of grid-fulls (see nchmm_viterbi_dev)
-        if (r1 < n && slots && r1 - r0 > slots && want_events) {
-            const size_t trimmed = (r1 - r0) / slots * slots;
-            if (4 * ((r1 - r0) - trimmed) < (r1 - r0)) {
-                r1 = r0 + trimmed;
-                mx = 0;
-                for (size_t r = r0; r < r1; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
-            }
-        }
-        out->push_back(PipeRange{r0, r1, off[r0], off[r1], 0, mx});
+        if (!forced && r1 < n && r1 - r0 > slots) r1 = r0 + (r1 - r0) / slots * slots;
+        out->push_back(range_of(r0, r1));
         r0 = r1;
+        if (!forced) { want_reads *= 2; want_events *= 2; }
+    }
+    if (!forced && out->size() >= 2) {
+        const PipeRange a = (*out)[out->size() - 2], b = out->back();
+        if (2 * (b.e1 - b.e0) < a.e1 - a.e0 && b.e1 - a.e0 <= cap_events) {
+            out->pop_back();
+            out->back() = range_of(a.r0, b.r1);
+        }
     }
     return NCHMM_OK;
 }
@@ -168,12 +175,13 @@ struct RawIn { size_t n_raw; const float* mean; const float* stdv; const float* 
 
 // Enqueue one batch.  off = n + 1 packed offsets (host).  direct: the one-call form (nothing else in flight).
 int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const int32_t* model_slot, const int32_t* trans_slot,
-               const PreparedIn* prep, const RawIn* raw, uint16_t* out_state, float* out_logp, int32_t* out_status, bool direct)
+               const PreparedIn* prep, const RawIn* raw, uint16_t* out_state, float* out_logp, int32_t* out_status, bool direct,
+               const PipeTables* tab = nullptr)
 {
     int rc = pipe_init(c);
     if (rc != NCHMM_OK) return rc;
     PipeState* P = c->pipe;
-    if (P->in_flight >= 2) return NCHMM_E_INVALID;
+    if (P->in_flight >= 2 || (tab && P->in_flight)) return NCHMM_E_INVALID;   // (a batch with tables rewrites slots 0 .. n-1)
     const unsigned slot = P->next_begin;
     PipeCall& K = P->call[slot];
     K.ev_used = 0;
@@ -218,9 +226,21 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     size_t o_last = small_bytes, o_cm = o_last + al256(4 * n), o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total);
     size_t o_rm = o_ls + al256(4 * total), o_rs = o_rm + al256(4 * n_raw), o_rt = o_rs + al256(4 * n_raw);
     size_t o_lp = o_rt + al256(4 * n_raw), o_ss = o_lp + al256(4 * n), o_st = o_ss + al256(4 * n);
-    const size_t need = direct ? o_st + al256(2 * total) : o_lp;
+    const size_t out_end = direct ? o_st + al256(2 * total) : o_lp;
     const size_t ho_lp = small_bytes, ho_ss = ho_lp + al256(4 * n), ho_st = ho_ss + al256(4 * n);
-    const size_t h_need = direct ? small_bytes : ho_st + al256(2 * total);
+    const size_t h_out_end = direct ? small_bytes : ho_st + al256(2 * total);
+    // tables (when the batch builds its own): the loaded models once, then per range one block [idx | par | wm] of its candidates
+    std::vector<size_t> tb_off(n_ranges + 1, 0);
+    size_t tb_states = 0;
+    if (tab) {
+        tb_states = al256(sizeof(float) * tab->n_tables * kStates * 10);
+        for (size_t k = 0; k < n_ranges; ++k) {
+            const size_t m = K.ranges[k].r1 - K.ranges[k].r0;
+            tb_off[k + 1] = tb_off[k] + std::max<size_t>(al256(4 * m) + al256(32 * m) + al256(256 * m), kMinCopy);
+        }
+    }
+    const size_t o_tst = out_end, o_tb = o_tst + tb_states, need = o_tb + tb_off[n_ranges];
+    const size_t ho_tb = h_out_end, h_need = ho_tb + tb_off[n_ranges];
     // (this slot's buffers: nothing in flight uses them)
     if ((rc = ensure(c, &P->d_stage[slot], &P->stage_bytes[slot], need))) return rc;
     if (K.h_bytes < h_need) {
@@ -257,6 +277,12 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     }
 
     std::memcpy(K.h + o_off, off, 8 * (n + 1));
+    std::vector<int32_t> ident;
+    if (tab) {
+        ident.resize(n);
+        std::iota(ident.begin(), ident.end(), 0);
+        model_slot = trans_slot = ident.data();
+    }
     if (model_slot) std::memcpy(K.h + o_ms, model_slot, 4 * n);
     if (trans_slot) std::memcpy(K.h + o_ts, trans_slot, 4 * n);
     std::memcpy(K.h + o_or, order.data(), 4 * n);
@@ -265,18 +291,49 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         std::memcpy(K.h + o_dr, raw->drift, 4 * n);
     }
     HIP_TRY(c, hipMemcpyAsync(d, K.h, small_bytes, hipMemcpyHostToDevice, si));
+    if (tab) {
+        // model / transition slot v belongs to candidate v
+        if ((rc = nchmm_reserve_slots(c, (int)n))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(d + o_tst, tab->states_Sx10, sizeof(float) * tab->n_tables * kStates * 10, hipMemcpyHostToDevice, si));
+        for (size_t v = 0; v < n; ++v) { c->model_set[v] = 1; c->trans_set[v] = 1; }
+    }
     uint64_t raw_up = 0;
     for (size_t k = 0; k < n_ranges; ++k) {
         const PipeRange& g = K.ranges[k];
         const size_t ne = (size_t)(g.e1 - g.e0);
+        const size_t m = g.r1 - g.r0;
+        if (tab) {
+            // Pore_Model::scale parameters (Pore_Model.hpp:190-201) and the 64 mask weights of compute_transitions_fast
+            // (State_Transitions.hpp:198-224) of this range's candidates: host libm here, expansion on the device
+            char* hb = K.h + ho_tb + tb_off[k];
+            int32_t* h_idx = (int32_t*)hb;
+            float* h_par = (float*)(hb + al256(4 * m));
+            float* h_wm = (float*)(hb + al256(4 * m) + al256(32 * m));
+            auto fill = [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    const size_t v = g.r0 + i;
+                    h_idx[i] = tab->table_idx[v];
+                    const float* pp = tab->params_nx6 + 6 * v;
+                    std::memcpy(h_par + 8 * i, pp, 6 * sizeof(float));
+                    h_par[8 * i + 6] = std::log(pp[3]);   // log_params.var, Pore_Model.hpp:193
+                    h_par[8 * i + 7] = std::log(pp[5]);   // log_params.var_sd :195
+                    if (i > lo && tab->p_skip[v] == tab->p_skip[v - 1] && tab->p_stay[v] == tab->p_stay[v - 1])
+                        std::memcpy(h_wm + 64 * i, h_wm + 64 * (i - 1), 64 * sizeof(float));
+                    else
+                        mask_weights(tab->p_skip[v], tab->p_stay[v], h_wm + 64 * i);
+                }
+            };
+            if (m >= 256) parallel_for(m, fill); else fill(0, m);
+            HIP_TRY(c, hipMemcpyAsync(d + o_tb + tb_off[k], hb, tb_off[k + 1] - tb_off[k], hipMemcpyHostToDevice, si));
+        }
         // pageable sources: the runtime pins the pages in place and the SDMA engines read them at PCIe rate; the call
         // returns when the copy is done, so the launches below are queued range by range right behind their data
         if (raw) {
             if (g.raw_hi > raw_up) {
-                const size_t m = (size_t)(g.raw_hi - raw_up);
-                HIP_TRY(c, hipMemcpyAsync(d + o_rm + 4 * raw_up, raw->mean + raw_up, 4 * m, hipMemcpyHostToDevice, si));
-                HIP_TRY(c, hipMemcpyAsync(d + o_rs + 4 * raw_up, raw->stdv + raw_up, 4 * m, hipMemcpyHostToDevice, si));
-                HIP_TRY(c, hipMemcpyAsync(d + o_rt + 4 * raw_up, raw->start + raw_up, 4 * m, hipMemcpyHostToDevice, si));
+                const size_t mr = (size_t)(g.raw_hi - raw_up);
+                HIP_TRY(c, hipMemcpyAsync(d + o_rm + 4 * raw_up, raw->mean + raw_up, 4 * mr, hipMemcpyHostToDevice, si));
+                HIP_TRY(c, hipMemcpyAsync(d + o_rs + 4 * raw_up, raw->stdv + raw_up, 4 * mr, hipMemcpyHostToDevice, si));
+                HIP_TRY(c, hipMemcpyAsync(d + o_rt + 4 * raw_up, raw->start + raw_up, 4 * mr, hipMemcpyHostToDevice, si));
                 raw_up = g.raw_hi;
             }
         } else if (ne) {
@@ -288,6 +345,15 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         if ((rc = pipe_event(c, K, &ev_in))) return rc;
         HIP_TRY(c, hipEventRecord(ev_in, si));
         HIP_TRY(c, hipStreamWaitEvent(sr, ev_in, 0));
+        if (tab) {
+            const char* db = d + o_tb + tb_off[k];
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_model_fast + g.r0), 1, m, sr));   // the scale kernel clears it for an out-of-range model
+            launch_scale_models((const float*)(d + o_tst), (const int32_t*)db, (const float*)(db + al256(4 * m)), c->d_models, c->d_model_fast,
+                                (int)g.r0, m, static_cast<float>(std::log(2.0 * M_PI)), sr);
+            HIP_TRY(c, hipGetLastError());
+            launch_expand_transitions((const float*)(db + al256(4 * m) + al256(32 * m)), c->d_masks, c->d_trans, c->d_trans_fb, (int)g.r0, m, sr);
+            HIP_TRY(c, hipGetLastError());
+        }
         if (raw) {
             EmGatherArgs ga;
             ga.mean = (const float*)(d + o_rm); ga.stdv = (const float*)(d + o_rs); ga.start = (const float*)(d + o_rt); ga.lstdv = nullptr;
@@ -312,6 +378,53 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     P->in_flight += 1;
     return NCHMM_OK;
 }
+
+}  // namespace
+
+namespace nchmm {
+
+size_t pipe_n_ranges(const nchmm_ctx* c)
+{
+    const PipeState* P = c->pipe;
+    return P && P->in_flight ? P->call[P->next_end].ranges.size() : 0;
+}
+
+int pipe_wait_range(nchmm_ctx* c, size_t k, size_t* r0, size_t* r1)
+{
+    PipeState* P = c->pipe;
+    if (!P || P->in_flight == 0) return NCHMM_E_INVALID;
+    PipeCall& K = P->call[P->next_end];
+    if (k >= K.ranges.size() || K.direct) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(K.done[k]));
+    *r0 = K.ranges[k].r0; *r1 = K.ranges[k].r1;
+    return NCHMM_OK;
+}
+
+void pipe_results(const nchmm_ctx* c, const uint16_t** states, const float** logp, const int32_t** status)
+{
+    const PipeCall& K = c->pipe->call[c->pipe->next_end];
+    *states = (const uint16_t*)(K.h + K.ho_state);
+    *logp = (const float*)(K.h + K.ho_logp);
+    *status = (const int32_t*)(K.h + K.ho_status);
+}
+
+int pipe_release(nchmm_ctx* c)
+{
+    PipeState* P = c->pipe;
+    if (!P || P->in_flight == 0) return NCHMM_E_INVALID;
+    PipeCall& K = P->call[P->next_end];
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = K.done.empty() ? hipSuccess : hipEventSynchronize(K.done.back());
+    P->next_end ^= 1u;
+    P->in_flight -= 1;
+    HIP_TRY(c, e);
+    return NCHMM_OK;
+}
+
+}  // namespace nchmm
+
+namespace {
 
 // Hand over the oldest batch in flight.
 int pipe_end(nchmm_ctx* c)
@@ -415,6 +528,23 @@ int begin_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, 
 }
 
 }  // namespace
+
+int nchmm::pipe_raw_tables_begin(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, const float* start, size_t n_cand,
+                                 const uint64_t* src, const uint32_t* len, const float* drift, const PipeTables& tab)
+{
+    if (!c || n_cand == 0 || n_cand > 0x7FFFFFF0ull) return NCHMM_E_INVALID;
+    if (!src || !len || !drift || (n_raw && (!mean || !stdv || !start))) return NCHMM_E_INVALID;
+    if (!tab.states_Sx10 || !tab.table_idx || !tab.params_nx6 || !tab.p_skip || !tab.p_stay || tab.n_tables == 0) return NCHMM_E_INVALID;
+    std::vector<uint64_t> off(n_cand + 1, 0);
+    for (size_t v = 0; v < n_cand; ++v) {
+        if (src[v] + len[v] > n_raw || tab.table_idx[v] < 0 || (size_t)tab.table_idx[v] >= tab.n_tables) return NCHMM_E_INVALID;
+        off[v + 1] = off[v] + len[v];
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const RawIn in{n_raw, mean, stdv, start, src, drift};
+    const int rc = pipe_begin(c, n_cand, off.data(), (size_t)off[n_cand], nullptr, nullptr, nullptr, &in, nullptr, nullptr, nullptr, false, &tab);
+    return rc == NCHMM_OK ? rc : fail_drain(c, rc);
+}
 
 extern "C" {
 

@@ -9,6 +9,7 @@
 // Pure host C++ over the C ABI (no HIP here).
 #include "nanocall_hip.h"
 #include "nchmm_internal.hpp"
+#include "nchmm_pipe.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -312,6 +313,7 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
     if (!ctx || !o || !model_states_Sx10 || !strand_off || !mean || !stdv || !start || !job_read || !job_m0 || !job_m1
         || !job_pm || !job_st || !out_state || !out_best_job || !out_best_logp)
         return NCHMM_E_INVALID;
+    const auto t_fn = std::chrono::steady_clock::now();
     // candidate list (nanocall.cpp:696-709 / :790-806): the preferred job if one was selected, else every job
     struct Cand { size_t job; int strand; size_t vread; };
     std::vector<Cand> cands;
@@ -342,67 +344,45 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
             slot_t.push_back((int32_t)v);
         }
     }
-    // every candidate's events are drift-corrected with ITS parameters and get their log_stdv ON THE DEVICE
-    // (nchmm_viterbi_raw: one upload of the raw events, a gather kernel per batch); only the candidate table is built here
+    // Every candidate's events are drift-corrected with ITS parameters and get their log_stdv ON THE DEVICE, and its scaled
+    // model / transitions are built there too, range by range in front of each range's kernels (nchmm_pipeline.cpp): the raw
+    // events go up once, range k+1's share while range k computes; only the candidate table is built here.
     const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     const size_t tot = (size_t)off.back();
-    std::vector<uint64_t> c_src(cands.size());
-    std::vector<uint32_t> c_len(cands.size());
-    std::vector<float> c_drift(cands.size());
-    for (size_t v = 0; v < cands.size(); ++v) {
+    const size_t nc = cands.size();
+    std::vector<uint64_t> c_src(nc);
+    std::vector<uint32_t> c_len(nc);
+    std::vector<float> c_drift(nc);
+    std::vector<long> last_cand(2 * n_reads, -1);        // per (read, strand-or-pair key): its last candidate
+    for (size_t v = 0; v < nc; ++v) {
         const size_t k = cands[v].job;
         const int r = job_read[k];
         c_src[v] = strand_off[2 * r + cands[v].strand];
         c_len[v] = (uint32_t)(off[v + 1] - off[v]);
         c_drift[v] = job_pm[6 * k + 2];   // corrected_events.apply_drift_correction(pm_params.drift), nanocall.cpp:685-686
-    }
-    // host buffer for the decoded states of all candidates: lives with the calling thread and only grows
-    struct Staging { std::unique_ptr<uint16_t[]> states; size_t cap = 0; };
-    static thread_local Staging stg;
-    if (stg.cap < tot + 1) {
-        stg.cap = tot + 1 + tot / 8;
-        stg.states.reset();
-        stg.states.reset(new uint16_t[stg.cap]);
+        last_cand[2 * r] = last_cand[2 * r + 1] = (long)v;   // (a read's candidates decide together: both keys wait for the last)
     }
     for (size_t i = 0; i < 2 * n_reads; ++i) { out_best_job[i] = -1; out_best_logp[i] = std::numeric_limits<float>::quiet_NaN(); }
     if (cands.empty()) return NCHMM_OK;
-    int rc;
-    if ((rc = nchmm_put_models_scaled(ctx, 0, cands.size(), model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
-    if ((rc = nchmm_put_transitions_fast(ctx, 0, cands.size(), t_skip.data(), t_stay.data()))) return rc;
-    uint16_t* const states = stg.states.get();
-    std::vector<float> logp(cands.size());
-    std::vector<int32_t> status(cands.size());
+    (void)slot_m; (void)slot_t;
+    const nchmm::PipeTables tab{model_states_Sx10, n_models, m_idx.data(), m_par.data(), t_skip.data(), t_stay.data()};
+    int rc = nchmm::pipe_raw_tables_begin(ctx, (size_t)strand_off[2 * n_reads], mean, stdv, start, nc, c_src.data(), c_len.data(),
+                                          c_drift.data(), tab);
+    if (rc != NCHMM_OK) return rc;
     const auto t_1 = std::chrono::steady_clock::now();
-    rc = nchmm_viterbi_raw(ctx, (size_t)strand_off[2 * n_reads], mean, stdv, start, cands.size(), c_src.data(), c_len.data(), c_drift.data(),
-                           slot_m.data(), slot_t.data(), states, logp.data(), status.data());
-    if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) return rc;
-    const auto t_2 = std::chrono::steady_clock::now();
+    const uint16_t* states = nullptr; const float* logp = nullptr; const int32_t* status = nullptr;
+    nchmm::pipe_results(ctx, &states, &logp, &status);
     // choose per read: 2D jobs by the float sum of both strands (:725-739), 1D jobs per strand (:807-825);
     // `sort ... back()` = the highest value, the later candidate among exact ties
     std::vector<float> best_total(2 * n_reads, -std::numeric_limits<float>::infinity());
     std::vector<long> best_c0(2 * n_reads, -1), best_c1(2 * n_reads, -1);
-    for (size_t v = 0; v < cands.size();) {
-        const size_t k = cands[v].job;
-        const int r = job_read[k];
-        const bool two_d = job_m0[k] >= 0 && job_m1[k] >= 0;
-        // A candidate that failed to decode (status != 0, NaN log-probability) must not shadow a later valid one: the
-        // reference's `sort` has no defined order with a NaN key, here a NaN ranks below everything (-INF) and is kept
-        // only while nothing else has been seen.
-        auto key = [](float x) { return std::isnan(x) ? -std::numeric_limits<float>::infinity() : x; };
-        if (two_d && v + 1 < cands.size() && cands[v + 1].job == k) {
-            const float tot = key(logp[v] + logp[v + 1]);
-            if (tot >= best_total[2 * r] || best_c0[2 * r] < 0) { best_total[2 * r] = tot; best_c0[2 * r] = (long)v; best_c1[2 * r] = (long)v + 1; }
-            v += 2;
-        } else {
-            const int s = cands[v].strand;
-            if (!two_d && (key(logp[v]) >= best_total[2 * r + s] || best_c0[2 * r + s] < 0)) {
-                // a 1D job on a read that also has a 2D winner is a different mode; the caller passes one mode per read
-                best_total[2 * r + s] = key(logp[v]); best_c0[2 * r + s] = (long)v; best_c1[2 * r + s] = -1;
-            }
-            v += 1;
-        }
-    }
+    // reads in the order in which their last candidate completes
+    std::vector<uint32_t> by_last;
+    for (size_t r = 0; r < n_reads; ++r) if (last_cand[2 * r] >= 0) by_last.push_back((uint32_t)r);
+    std::stable_sort(by_last.begin(), by_last.end(), [&](uint32_t a, uint32_t b) { return last_cand[2 * a] < last_cand[2 * b]; });
+    size_t scan = 0, emit_pos = 0;
+    bool any_numeric = false;
     auto emit = [&](long v) {
         const Cand& c = cands[(size_t)v];
         const int r = job_read[c.job];
@@ -411,18 +391,62 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_mod
         out_best_job[2 * r + c.strand] = (int32_t)c.job;
         out_best_logp[2 * r + c.strand] = logp[(size_t)v];
     };
-    parallel_for(n_reads, [&](size_t lo, size_t hi) {     // (per read, in the serial order: its slices belong to no other read)
-        for (size_t i = 2 * lo; i < 2 * hi; ++i) {
-            if (best_c0[i] >= 0) emit(best_c0[i]);
-            if (best_c1[i] >= 0) emit(best_c1[i]);
+    double ms_wait = 0, ms_host = 0;
+    const size_t n_ranges = nchmm::pipe_n_ranges(ctx);
+    for (size_t g = 0; g < n_ranges; ++g) {
+        size_t r0 = 0, r1 = 0;
+        const auto t_a = std::chrono::steady_clock::now();
+        if ((rc = nchmm::pipe_wait_range(ctx, g, &r0, &r1)) != NCHMM_OK) { (void)nchmm::pipe_release(ctx); return rc; }
+        const auto t_b = std::chrono::steady_clock::now();
+        // the candidates that have landed: [scan, r1), except a 2D pair whose second strand is in the next range
+        while (scan < r1) {
+            const size_t v = scan;
+            const size_t k = cands[v].job;
+            const int r = job_read[k];
+            const bool two_d = job_m0[k] >= 0 && job_m1[k] >= 0;
+            // A candidate that failed to decode (status != 0, NaN log-probability) must not shadow a later valid one: the
+            // reference's `sort` has no defined order with a NaN key, here a NaN ranks below everything (-INF) and is kept
+            // only while nothing else has been seen.
+            auto key = [](float x) { return std::isnan(x) ? -std::numeric_limits<float>::infinity() : x; };
+            if (two_d && v + 1 < nc && cands[v + 1].job == k) {
+                if (v + 1 >= r1) break;
+                const float tot2 = key(logp[v] + logp[v + 1]);
+                if (tot2 >= best_total[2 * r] || best_c0[2 * r] < 0) { best_total[2 * r] = tot2; best_c0[2 * r] = (long)v; best_c1[2 * r] = (long)v + 1; }
+                any_numeric |= status[v] != 0 || status[v + 1] != 0;
+                scan += 2;
+            } else {
+                const int s = cands[v].strand;
+                if (!two_d && (key(logp[v]) >= best_total[2 * r + s] || best_c0[2 * r + s] < 0)) {
+                    // a 1D job on a read that also has a 2D winner is a different mode; the caller passes one mode per read
+                    best_total[2 * r + s] = key(logp[v]); best_c0[2 * r + s] = (long)v; best_c1[2 * r + s] = -1;
+                }
+                any_numeric |= status[v] != 0;
+                scan += 1;
+            }
         }
-    });
+        // the reads all of whose candidates have been seen: winners' states -> the caller's array, under the next range's kernels
+        const size_t e0 = emit_pos;
+        while (emit_pos < by_last.size() && (size_t)last_cand[2 * by_last[emit_pos]] < scan) ++emit_pos;
+        parallel_for(emit_pos - e0, [&](size_t lo, size_t hi) {     // (per read: its slices belong to no other read)
+            for (size_t q = e0 + lo; q < e0 + hi; ++q)
+                for (size_t i = 2 * (size_t)by_last[q]; i < 2 * (size_t)by_last[q] + 2; ++i) {
+                    if (best_c0[i] >= 0) emit(best_c0[i]);
+                    if (best_c1[i] >= 0) emit(best_c1[i]);
+                }
+        });
+        const auto t_c = std::chrono::steady_clock::now();
+        ms_wait += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+        ms_host += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+    }
+    rc = nchmm::pipe_release(ctx);
+    if (rc != NCHMM_OK) return rc;
     if (dbg_time) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "[nchmm_basecall_reads] %zu candidates, %zu events: tables %.2f ms, upload+gather+viterbi %.2f ms, choose+copy %.2f ms\n",
-                     cands.size(), tot, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, std::chrono::steady_clock::now()));
+        std::fprintf(stderr, "[nchmm_basecall_reads] %zu candidates, %zu events, %zu ranges: candidate table %.2f ms, begin (tables + copy-in + launches) %.2f ms, "
+                             "waiting for ranges %.2f ms, choose+copy %.2f ms\n",
+                     nc, tot, n_ranges, ms(t_fn, t_0), ms(t_0, t_1), ms_wait, ms_host);
     }
-    return rc;
+    return any_numeric ? NCHMM_E_NUMERIC : NCHMM_OK;
 }
 
 }  // extern "C"
