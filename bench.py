@@ -186,27 +186,57 @@ def generate_shard(table, read_ids, n_events, threads):
 
 
 def end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, reps):
-    """SURVEY 8d's second figure: the same batch through the HOST-pointer entry point (nchmm_viterbi: pageable host arrays in,
-    H2D of 12 B/event, forward + traceback kernels, D2H of 2 B/event + 4 B/read, host arrays out), wall clock around the
-    call.  Never the headline `value`; output compared with the device-resident run of the timed region."""
+    """SURVEY 8d's second figure: the same batch from pageable HOST arrays to host arrays (12 B/event up, 2 B/event + 8 B/read
+    down over PCIe).  Never the headline `value`; every output compared with the device-resident run of the timed region.
+      value     a caller that streams batches (nchmm_viterbi_begin / _end, two in flight: batch k+1 is copied in and queued
+                while batch k computes, batch k is handed over under the kernels of batch k+1) -- what the library's own
+                chunk loops do.  Wall per batch over `reps` batches after 6 warm-up batches (the shader clock needs ~50 ms of
+                uninterrupted load to come back up after the gaps of the one-call loop before it).
+      one_call  nchmm_viterbi, one synchronous call per batch: the copies are exposed AND every launch starts after an idle
+                gap, which costs the sweep itself 6-9 % (profiles/r04_hostpath_gap.md)."""
     import torch
     n_reads = off.shape[0] - 1
     total = int(off[-1])
-    ctx.viterbi(off, cm, sd, ls)                 # first call sizes the library's staging buffers
-    wall = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        states, logp, status = ctx.viterbi(off, cm, sd, ls)
-        wall.append(time.perf_counter() - t0)
-    torch.cuda.synchronize()
-    assert (status == 0).all()
-    assert np.array_equal(states, d_state.cpu().numpy().view(np.uint16)), "host-pointer path decodes differently"
-    assert logp.tobytes() == d_logp.cpu().numpy().tobytes()
-    ms = float(np.median(wall)) * 1e3
+    want_states = d_state.cpu().numpy().view(np.uint16)
+    want_logp = d_logp.cpu().numpy()
+    ctx.use_own_stream()
+    try:
+        ctx.viterbi(off, cm, sd, ls)                 # first call sizes the library's staging buffers
+        wall = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            states, logp, status = ctx.viterbi(off, cm, sd, ls)
+            wall.append(time.perf_counter() - t0)
+        assert (status == 0).all()
+        assert np.array_equal(states, want_states), "host-pointer path decodes differently"
+        assert logp.tobytes() == want_logp.tobytes()
+        one_ms = float(np.median(wall)) * 1e3
+        outs = [(np.empty(total, np.uint16), np.empty(n_reads, np.float32), np.zeros(n_reads, np.int32)) for _ in range(2)]
+        warm = 6
+        tk = ctx.viterbi_begin(off, cm, sd, ls, out=outs[0])
+        per, same = [], True
+        for i in range(1, warm + reps + 1):
+            t0 = time.perf_counter()
+            nxt = ctx.viterbi_begin(off, cm, sd, ls, out=outs[i & 1])
+            st, lp, status = ctx.viterbi_end(tk)
+            tk = nxt
+            per.append(time.perf_counter() - t0)
+            if i in (1, warm + reps):            # (the comparison is host work between batches: keep it out of most iterations)
+                same = same and np.array_equal(st[:total], want_states) and lp[:n_reads].tobytes() == want_logp.tobytes() and (status == 0).all()
+        st, lp, status = ctx.viterbi_end(tk)
+        same = same and np.array_equal(st[:total], want_states) and lp[:n_reads].tobytes() == want_logp.tobytes()
+        assert same, "streamed batches decode differently"
+        ms = float(np.mean(per[warm:warm + reps - 1])) * 1e3     # (the last timed iteration carries the comparison)
+    finally:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     return {"metric": "Mevents/s Viterbi, host pointers in and out (PCIe inclusive)", "value": round(total / ms / 1e3, 3), "unit": "Mevents/s",
-            "ms_per_call": round(ms, 3), "calls": reps,
-            "path": "nchmm_viterbi: pageable host SoA events -> H2D -> viterbi_kernel + traceback_kernel -> D2H -> host states / log-probs",
-            "pcie_bytes_per_call": int(12 * total + 8 * (n_reads + 1) + 2 * total + 8 * n_reads),
+            "ms_per_batch": round(ms, 3), "batches": reps - 1, "warm_up_batches": warm,
+            "path": "nchmm_viterbi_begin / nchmm_viterbi_end, two batches in flight: pageable host SoA events -> H2D on the copy-in stream "
+                    "under the previous batch's kernels -> viterbi_kernel + traceback_kernel writing states / log-probs into pinned host "
+                    "memory -> memcpy into the caller's arrays under the next batch's kernels",
+            "one_call": {"value": round(total / one_ms / 1e3, 3), "unit": "Mevents/s", "ms_per_call": round(one_ms, 3), "calls": reps,
+                         "path": "nchmm_viterbi: H2D -> viterbi_kernel + traceback_kernel -> D2H, one synchronous call per batch"},
+            "pcie_bytes_per_batch": int(12 * total + 8 * (n_reads + 1) + 2 * total + 8 * n_reads),
             "identical_to_device_resident_run": True}
 
 
@@ -501,7 +531,7 @@ def main():
                                   "last_launch_kernel_ms": round(k_ms, 3)}
         if world == 1 and not args.no_end_to_end and total <= 64 * 1024 * 1024:
             try:
-                result["end_to_end"] = end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, max(3, min(args.steps, 10)))
+                result["end_to_end"] = end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, max(6, min(args.steps, 16)))
             except Exception as e:      # a secondary leg must not cost the run its headline line
                 sys.stderr.write(f"bench.py: end-to-end leg failed: {e}\n")
                 result["end_to_end"] = {"error": str(e)}
