@@ -193,7 +193,7 @@ def end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, reps):
                 chunk loops do.  Wall per batch over `reps` batches after 6 warm-up batches (the shader clock needs ~50 ms of
                 uninterrupted load to come back up after the gaps of the one-call loop before it).
       one_call  nchmm_viterbi, one synchronous call per batch: the copies are exposed AND every launch starts after an idle
-                gap, which costs the sweep itself 6-9 % (profiles/r04_hostpath_gap.md)."""
+                gap, which costs the sweep itself 6-9 % (profiles/r04_pipeline_timeline.md)."""
     import torch
     n_reads = off.shape[0] - 1
     total = int(off[-1])

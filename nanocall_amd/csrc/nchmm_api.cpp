@@ -304,10 +304,6 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         return fail(NCHMM_E_HIP);
     c->vit_slots = c->n_cu * viterbi_blocks_per_cu();
     c->fb_slots = c->n_cu * fwbw_blocks_per_cu();
-    if (const char* e = std::getenv("NCHMM_EXP_FB_BLOCKS_PER_CU")) {      // experiment only: occupancy vs per-event latency
-        const int b = std::atoi(e);
-        if (b >= 1 && b <= fwbw_blocks_per_cu()) c->fb_slots = c->n_cu * b;
-    }
     *out = c;
     return NCHMM_OK;
 }

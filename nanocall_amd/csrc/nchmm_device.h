@@ -15,14 +15,8 @@ constexpr int kTransFloats = kStates + 1024 + 256;      // w0[4096] | w1[1024] |
 constexpr int kMaxSlots = 64;
 constexpr unsigned kNoState = 0xFFFFu;
 
-// Back-pointer row of one event: one byte per state (viterbi_kernel.hip).  The bit-plane experiment of round 3
-// (tools/ubench/viterbi_bitplane_kernel.hip.txt) builds with -DNCHMM_BP_ROW_BYTES=1536.
-#ifdef NCHMM_BP_ROW_BYTES
-constexpr unsigned kBpRowBytes = NCHMM_BP_ROW_BYTES;
-#else
+// Back-pointer row of one event: one byte per state (viterbi_kernel.hip)
 constexpr unsigned kBpRowBytes = kStates;
-#endif
-constexpr unsigned kBpGroupOff = 1024;   // (bit-plane experiment only)
 
 // device image of a pore model: field-major so thread t reads field f of state t+256k at [f][t+256k]
 enum ModelField {

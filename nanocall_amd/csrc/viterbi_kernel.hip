@@ -700,7 +700,7 @@ __device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsig
 
 // Viterbi::fill_state_seq, Viterbi.hpp:134-141.  The chase is a dependent pointer walk bound by
 // HBM latency (~1 us per three events), so a read is cut into up to 8 segments walked by 8 waves
-// at once.  Only the top segment knows its start state; the others start tb_margin (256) events above
+// at once.  Only the top segment knows its start state; the others start tb_margin (128 by default) events above
 // their segment from an arbitrary state and rely on Viterbi survivor paths coalescing: if the
 // speculative walk is in the same state as the true path at the first event it owns, everything
 // below is the true path (back-pointers are a function of (event, state)).  Wave 0 checks each
