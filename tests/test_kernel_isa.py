@@ -19,13 +19,35 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
 
 
+def _hipflags():
+    """the device-code flags of csrc/Makefile (one source of truth: `make print-hipflags`)"""
+    p = subprocess.run(["make", "-s", "-C", CSRC, "print-hipflags"], check=True, capture_output=True, text=True)
+    return [f.replace("-I../../include", "-I" + os.path.join(ROOT, "include")).replace("-I.", "-I" + CSRC) if f in ("-I../../include", "-I.") else f
+            for f in p.stdout.split()]
+
+
+KERNEL_FILES = ("viterbi_kernel", "fwbw_scaled_kernel", "fwbw_kernel", "em_kernel")
+
+
 @pytest.fixture(scope="module")
-def fast_loop(tmp_path_factory):
-    out = tmp_path_factory.mktemp("isa") / "viterbi_kernel.s"
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-fno-slp-vectorize", "-S", "--cuda-device-only"]   # = csrc/Makefile
-    subprocess.run([HIPCC] + flags + ["-o", str(out), os.path.join(CSRC, "viterbi_kernel.hip")], check=True, capture_output=True, timeout=600)
-    lines = open(out).read().split("\n")
+def asm(tmp_path_factory):
+    """gfx950 assembly of every kernel file, compiled as the library compiles them"""
+    from concurrent.futures import ThreadPoolExecutor
+    d = tmp_path_factory.mktemp("isa")
+    flags = _hipflags() + ["-S", "--cuda-device-only"]
+
+    def build(name):
+        out = d / (name + ".s")
+        subprocess.run([HIPCC] + flags + ["-o", str(out), os.path.join(CSRC, name + ".hip")], check=True, capture_output=True, timeout=900)
+        return name, open(out).read()
+
+    with ThreadPoolExecutor(4) as ex:
+        return dict(ex.map(build, KERNEL_FILES))
+
+
+@pytest.fixture(scope="module")
+def fast_loop(asm):
+    lines = asm["viterbi_kernel"].split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^\S*viterbi_kernel\S*:", l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
@@ -72,3 +94,74 @@ def test_tie_paths_are_out_of_line(fast_loop):
     assert sum(x.startswith("v_max3_f32") for x in fast_loop) == 8
     assert len(fast_loop) < 560, len(fast_loop)                      # 470 today; 740 with the tie paths inline
     assert sum(x.startswith("s_barrier") for x in fast_loop) == 1
+
+
+# ---- data hazards the compiler cannot see (tools/isa_lint.py) ----
+import sys
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_lint  # noqa: E402
+
+
+def test_no_data_hazards_in_any_kernel(asm):
+    """Every VALU-write -> DPP / v_permlane*_swap / v_readlane read, every transcendental -> dependent op, every EXEC write -> DPP
+    in the final assembly of all four kernel files keeps its wait states -- including the ones whose two ends sit in different
+    inline-asm statements, which LLVM's hazard recogniser does not connect (viterbi_kernel.hip swap1, fwbw_common.hpp)."""
+    seen_lane_readers = 0
+    for name, text in asm.items():
+        bad, stats = isa_lint.lint(text)
+        assert not bad, f"{name}: " + "; ".join(f"{b[1]} line {b[2]}: `{b[3]}` -> `{b[4]}` at {b[5]} wait states, needs {b[6]}" for b in bad[:5])
+        seen_lane_readers += sum(s["lane_readers"] for s in stats.values())
+    assert seen_lane_readers >= 100, seen_lane_readers      # the scan found the DPP / permlane / readlane sites (244 today)
+
+
+def test_the_lint_catches_a_lane_swap_that_lost_its_wait_states(asm):
+    """Commit 4e99858 wrote `s_nop 1` into the lane-swap asm because the distance between the asm select that produces its input
+    and the DPP read had been kept only by what the compiler happened to schedule in between (the kernel BEFORE that commit also
+    lints clean: the luck had held).  Take the wait states out of today's assembly -- the compiler scheduling nothing there --
+    and the lint must object; likewise for the permlane swaps of the forward-backward reductions."""
+    vit = re.sub(r"\ts_nop 1\n(\tv_mov_b32_dpp [^\n]*quad_perm)", r"\1", asm["viterbi_kernel"])
+    assert vit != asm["viterbi_kernel"]
+    bad, _ = isa_lint.lint(vit)
+    assert any(b[1] == "R1" and "quad_perm" in b[4] for b in bad), "removing the s_nop in front of the lane swap went unnoticed"
+    fb = asm["fwbw_scaled_kernel"]
+    m = re.search(r"\t(v_\w+ (v\d+), [^\n]*)\n((?:\t[^\n]*\n){0,6}?)\t(v_permlane(?:16|32)_swap_b32 [^\n]*)", fb)
+    assert m, "no v_permlane*_swap in the forward-backward kernels?"
+    # a VALU write of a swapped register moved directly in front of the swap
+    swap = m.group(4)
+    reg = re.search(r"v\d+", swap).group(0)
+    poisoned = fb.replace("\t" + swap, f"\tv_add_f32_e32 {reg}, {reg}, {reg}\n\t" + swap, 1)
+    bad, _ = isa_lint.lint(poisoned)
+    assert any(b[1] == "R1" and "permlane" in b[4] for b in bad)
+
+
+def test_the_lint_rules_on_hand_written_snippets():
+    def run(body):
+        return isa_lint.lint("_Z1kv:\n" + "".join("\t" + l + "\n" for l in body) + "\ts_endpgm\n")[0]
+    # R1: two wait states between a VALU write and a DPP read; s_nop 1 supplies both
+    assert run(["v_add_f32_e32 v1, v2, v3", "v_mov_b32_dpp v4, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"])
+    assert run(["v_add_f32_e32 v1, v2, v3", "s_nop 0", "v_mov_b32_dpp v4, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"])
+    assert not run(["v_add_f32_e32 v1, v2, v3", "s_nop 1", "v_mov_b32_dpp v4, v1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"])
+    assert not run(["v_add_f32_e32 v1, v2, v3", "s_mov_b32 s0, 0", "v_mul_f32_e32 v9, v8, v8", "v_add_f32_dpp v4, v1, v1 row_shr:1 row_mask:0xf bank_mask:0xf"])
+    # ... a register pair written by a 64-bit op, read by a swap
+    assert run(["v_lshlrev_b64 v[2:3], 1, v[4:5]", "v_permlane32_swap_b32 v3, v7"])
+    # R2: a transcendental result needs one wait state before an ordinary VALU op reads it (another transcendental may follow at once)
+    assert run(["v_exp_f32_e32 v1, v2", "v_add_f32_e32 v3, v1, v1"])
+    assert not run(["v_exp_f32_e32 v1, v2", "v_mov_b32_e32 v9, v8", "v_add_f32_e32 v3, v1, v1"])
+    assert not run(["v_rsq_f32_e32 v1, v2", "v_rcp_f32_e32 v3, v1"])
+    # R3: five wait states between a VALU write of EXEC and a DPP op
+    assert run(["v_cmpx_gt_f32_e32 v1, v2", "s_nop 3", "v_mov_b32_dpp v4, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"])
+    assert not run(["v_cmpx_gt_f32_e32 v1, v2", "s_nop 4", "v_mov_b32_dpp v4, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"])
+
+
+def test_no_scratch_traffic_in_the_forward_backward_event_loops(asm):
+    """The rescaled sweeps spill (39 VGPRs in the forward kernel's prologue); none of it may sit in the per-event loop -- the loop
+    with the block barrier -- of either sweep."""
+    for pat in ("fwbw_forward_scaled_kernel", "fwbw_backward_scaled_kernel"):
+        loops = isa_lint.event_loops(asm["fwbw_scaled_kernel"], pat)
+        assert loops, pat
+        # the event loop proper: the innermost loop around the barrier (an enclosing window loop contains it and the prologue)
+        big = [t for t in loops if len(t[2]) > 150 and any(x.startswith("v_permlane") or "_dpp" in x for x in t[2])]
+        assert big, (pat, [(t[1], len(t[2])) for t in loops])
+        kernel, label, seg = min(big, key=lambda t: len(t[2]))
+        spills = [x for x in seg if x.startswith("scratch_") or "accvgpr" in x]
+        assert not spills, f"{pat} {label}: {spills[:4]}"
