@@ -398,6 +398,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
     total = n_reads * n_events
 
+    mem_free_before, mem_total = na.device_mem_info(local_rank_dev)
     ctx = na.Context(local_rank_dev)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # launches are ordered with torch's work on this stream
     ctx.put_model(0, na.scaled_model_table(table))
@@ -444,6 +445,9 @@ def main():
     launches_per_step = (int(local_counters[3]) - launches0) // (2 * max(1, args.steps))
     counters = shard.gather_counters(local_counters, red_dev)
 
+    # device memory at the high-water mark (the workspace and staging buffers are kept between calls, so "now" is the peak)
+    lib_now, lib_peak = ctx.mem_stats()
+    mem_free_after, _ = na.device_mem_info(local_rank_dev)
     if os.environ.get("NCHMM_PROFILE") == "1" and rank == 0:
         profile_report(ctx)
     status = d_status.cpu().numpy()
@@ -491,7 +495,14 @@ def main():
                        "grid_slots": ctx.grid_slots(), "forward_launches_per_step": launches_per_step,
                        "host_generation_s": round(t_gen, 1)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
-            "device": {"shader_clock_mhz_under_load": (round(sclk_mhz, 0) if sclk_mhz == sclk_mhz else None), "peak_shader_clock_mhz": round(SCLK_GHZ * 1e3, 0),
+            "output_sha256_16": hashlib.sha256(d_state.cpu().numpy().tobytes() + d_logp.cpu().numpy().tobytes()).hexdigest()[:16],
+            "device": {"peak_mem_bytes": int(mem_free_before - mem_free_after), "library_peak_bytes": int(lib_peak),
+                       "workspace_budget_mb": (int(os.environ["NCHMM_WS_BUDGET_MB"]) if os.environ.get("NCHMM_WS_BUDGET_MB") else None),
+                       "total_mem_bytes": int(mem_total),
+                       "mem_note": "peak_mem_bytes = device memory taken by this process between context creation and the end of the timed "
+                                   "region (inputs + outputs of the batch, the library's tables, staging and back-pointer workspace); "
+                                   "library_peak_bytes = the library's own share at its high-water mark (nchmm_mem_stats)",
+                       "shader_clock_mhz_under_load": (round(sclk_mhz, 0) if sclk_mhz == sclk_mhz else None), "peak_shader_clock_mhz": round(SCLK_GHZ * 1e3, 0),
                        "note": "rank 0, ~3 ms full-chip VALU probe right after the timed region (nchmm_shader_clock_mhz)"},
         }
         if events_per_launch:

@@ -431,6 +431,11 @@ int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);
 /* number of resident thread-block slots (persistent grid size) the Viterbi kernel launches */
 int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
 
+/* Device memory the context holds now (out[0]) and at its high-water mark (out[1]), in bytes: tables, staging and the
+ * back-pointer workspace (4 KiB per event of the largest launch; the reference's Viterbi matrix is 32 KiB per event of ONE read,
+ * Viterbi.hpp:50).  NCHMM_WS_BUDGET_MB bounds the workspace: a batch that needs more runs as several launches. */
+int nchmm_mem_stats(const nchmm_ctx* ctx, uint64_t out[2]);
+
 /* ------------------------------------------------------------------------------------------
  * Device pool -- the reference's read-parallel pfor loops (src/nanocall/nanocall.cpp:282-579, :611-866; `-t`
  * worker threads, one read each) become: one context + one host thread per GPU of the node, reads assigned to

@@ -518,6 +518,12 @@ class Context:
         check(lib().nchmm_profile_blocks(self._h, _p(out)), "nchmm_profile_blocks")
         return out
 
+    def mem_stats(self):
+        """(device bytes the context holds now, at its high-water mark)"""
+        out = np.zeros(2, np.uint64)
+        check(lib().nchmm_mem_stats(self._h, _p(out)), "nchmm_mem_stats")
+        return int(out[0]), int(out[1])
+
     def grid_slots(self):
         v = C.c_int(0)
         check(lib().nchmm_grid_slots(self._h, C.byref(v)), "nchmm_grid_slots")

@@ -585,28 +585,34 @@ extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events
     HIP_TRY(c, hipMemcpyAsync(off.data(), d_off, sizeof(uint64_t) * (n_reads + 1), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint64_t budget_events = std::max<uint64_t>(c->ws_budget / kBpRowBytes, max_events);
+    // Every launch ends with a tail in which the persistent blocks run dry one by one.  With reads of similar length a range of
+    // k * (resident blocks) reads drains evenly; 1560 reads on 512 blocks take four rounds for three rounds' worth of work
+    // (measured: 249 instead of 318 Mevents/s), and 1024 long reads cut 806 + 218 by the budget alone ran at 242 instead of
+    // 330.  So: the fewest launches the budget allows, the reads spread evenly over them in whole grid-fulls.
+    const size_t slots = std::max<size_t>((size_t)c->vit_slots, 1);
+    const size_t n_launch = (size_t)((total_events + budget_events - 1) / budget_events);
+    size_t per = (n_reads + n_launch - 1) / n_launch;
+    per = (per + slots - 1) / slots * slots;
+    std::vector<size_t> cut{0};
+    uint64_t ws_events = 1;
+    for (size_t first = 0; first < n_reads;) {
+        size_t last = first;
+        while (last < n_reads && last - first < per && off[last + 1] - off[first] <= budget_events) ++last;
+        if (last == first) return NCHMM_E_NOMEM;   // a single read larger than the workspace
+        if (last < n_reads && last - first < per && (last - first) > slots) last = first + (last - first) / slots * slots;   // cut short by the budget
+        cut.push_back(last);
+        ws_events = std::max<uint64_t>(ws_events, off[last] - off[first]);
+        first = last;
+    }
     p = c->d_ws;
-    rc = ensure(c, &p, &c->ws_bytes, (size_t)budget_events * kBpRowBytes);
+    rc = ensure(c, &p, &c->ws_bytes, (size_t)ws_events * kBpRowBytes);
     c->d_ws = (uint8_t*)p;
     if (rc != NCHMM_OK) return rc;
-    size_t first = 0;
-    while (first < n_reads) {
-        size_t last = first;
-        while (last < n_reads && off[last + 1] - off[first] <= budget_events) ++last;
-        if (last == first) return NCHMM_E_NOMEM;   // a single read larger than the workspace
-        // Every launch ends with a tail in which the persistent blocks run dry one by one.  With reads of similar length a
-        // range of k * (resident blocks) reads drains evenly; 1560 reads on 512 blocks take four rounds for three rounds'
-        // worth of work (measured: 249 instead of 318 Mevents/s).  So a range that is not the last one is trimmed to a
-        // multiple of the grid when that costs less than a quarter of it.
-        const size_t slots = (size_t)c->vit_slots;
-        if (last < n_reads && slots && (last - first) > slots) {
-            const size_t trimmed = (last - first) / slots * slots;
-            if (4 * ((last - first) - trimmed) < (last - first)) last = first + trimmed;
-        }
+    for (size_t k = 0; k + 1 < cut.size(); ++k) {
+        const size_t first = cut[k], last = cut[k + 1];
         rc = launch_viterbi_range(c, VitLane{c->stream, c->d_last_state}, first, last - first, off[first], off[last] - off[first], d_off, d_cmean, d_stdv, d_lstdv,
                           d_model_slot, d_trans_slot, nullptr, d_out_state, d_out_logp, d_out_status);
         if (rc != NCHMM_OK) return rc;
-        first = last;
     }
     return NCHMM_OK;
 }
@@ -1007,6 +1013,14 @@ int nchmm_profile_ticks(nchmm_ctx* c, uint64_t out[8], int reset)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out, c->d_prof, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(c, hipMemset(c->d_prof, 0, sizeof(uint64_t) * 8));
+    return NCHMM_OK;
+}
+
+int nchmm_mem_stats(const nchmm_ctx* c, uint64_t out[2])
+{
+    if (!c || !out) return NCHMM_E_INVALID;
+    out[0] = c->counters[6];
+    out[1] = c->peak_bytes;
     return NCHMM_OK;
 }
 

@@ -61,6 +61,53 @@ def test_config5_r9_50k_event_read_against_oracle(gpu_ctx, r9t):
     assert 45000 < len(seq) < 60000
 
 
+def test_config5_long_reads_decode_identically_under_a_small_workspace_budget(r9t):
+    """BASELINE config 5 with bounded memory (SURVEY 8d hard part 7; the reference needs 1.57 GB per 50 k-event read,
+    Viterbi.hpp:50): four 50 000-event R9 reads need 800 MB of back-pointers at once; under NCHMM_WS_BUDGET_MB=256 every read
+    is its own forward + traceback launch (>= 4 sub-batches) through a 205 MB workspace, and decodes to the same bits --
+    through the host-pointer form and through the device-pointer form.  One read is re-scored along its decoded path with the
+    reference's float operations."""
+    import os
+    import torch
+    n_reads, n_events = 4, 50000
+    ev = synth.generate(r9t, n_reads, n_events, first_read=500)
+    off, mean, stdv, start = synth.flat_batch(ev)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+
+    def run(budget_mb):
+        if budget_mb:
+            os.environ["NCHMM_WS_BUDGET_MB"] = str(budget_mb)
+        try:
+            ctx = na.Context(0)
+            ctx.put_model(0, na.scaled_model_table(r9t, IDENT))
+            ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+            states, logp, status = ctx.viterbi(off, cm, sd, ls)                     # host pointers (pipeline ranges)
+            launches_host = int(ctx.counters()[3]) // 2
+            dev = torch.device("cuda", 0)
+            d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (off.astype(np.int64), cm, sd, ls)]
+            d_state = torch.empty(n_reads * n_events, dtype=torch.int16, device=dev)
+            d_logp = torch.empty(n_reads, dtype=torch.float32, device=dev)
+            d_status = torch.empty(n_reads, dtype=torch.int32, device=dev)
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.viterbi_dev(n_reads, n_events, n_reads * n_events, *d, d_state, d_logp, d_status)  # device pointers (sub-batches)
+            torch.cuda.synchronize()
+            launches_dev = int(ctx.counters()[3]) // 2 - launches_host
+            peak = ctx.mem_stats()[1]
+            assert np.array_equal(d_state.cpu().numpy().view(np.uint16), states) and d_logp.cpu().numpy().tobytes() == logp.tobytes()
+            ctx.close()
+        finally:
+            os.environ.pop("NCHMM_WS_BUDGET_MB", None)
+        return states, logp, status, launches_host, launches_dev, peak
+
+    s0, lp0, st0, lh0, ld0, peak0 = run(0)
+    s1, lp1, st1, lh1, ld1, peak1 = run(256)
+    assert lh0 == 1 and ld0 == 1 and lh1 >= 4 and ld1 >= 4, (lh0, ld0, lh1, ld1)
+    assert np.array_equal(s0, s1) and lp0.tobytes() == lp1.tobytes() and (st0 == 0).all() and (st1 == 0).all()
+    assert peak1 < peak0 / 2 and peak1 < (400 << 20), (peak0, peak1)      # 4 reads' rows at once against one read's
+    score, ok = rescore_path(r9t, IDENT, 0.3, 0.1, cm[:n_events], sd[:n_events], ls[:n_events], s1[:n_events])
+    assert ok and np.float32(score).tobytes() == lp1[0].tobytes()
+
+
 def test_config4_shard_12500_reads_sub_batched(r73t):
     """The per-GPU shard of BASELINE config 4 (100 000 reads x 5 000 events over 8 GPUs = 12 500 reads, 62.5 M events):
     its 256 GB of back-pointers exceed the workspace budget, so one call is several forward + traceback launches over
