@@ -52,6 +52,12 @@ __device__ __forceinline__ float xs(float x, float ysry, float sry, float mu, fl
     return __builtin_fmaf(dx * dx, r2, dyp * dyp * lq);
 }
 
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void store_row(float* p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt" :: "v"(p), "v"(v), "n"(BYTE_OFFSET) : "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ T uniform_load(const T* p)
 {
@@ -202,8 +208,15 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                         ah[q] = E * __builtin_fmaf(W1[q], in1[q], __builtin_fmaf(T0[q], ah[q], in2[q])) * sc;
                     }
                 }
+                // The row is read again only by the backward sweep, a launch and 6.9 GB later: written through (sc1) and marked
+                // streaming (nt) it does not wait behind L2 write-back -- 3.41 -> 3.24 ms for the two sweeps, any of nt / sc1 /
+                // sc0 sc1 gets most of it (profiles/r04_fb_isa_budget.md).  Cells 2p and 2p + 1 of a thread are 512 states apart:
+                // one 64-bit address and an immediate offset per pair, as the compiler had it.
 #pragma unroll
-                for (int q = 0; q < 8; ++q) rowp[jj[q]] = ah[q];
+                for (int p = 0; p < 4; ++p) {
+                    store_row<0>(&rowp[jj[2 * p]], ah[2 * p]);
+                    store_row<2048>(&rowp[jj[2 * p]], ah[2 * p + 1]);
+                }
                 rowp += kStates;
                 if (tau == 0) P.ws_exp[e0 + i] = Ia;
                 ref_sum += (double)(kmax - ev.w);

@@ -678,6 +678,7 @@ int nchmm_fwbw_dev(nchmm_ctx* c, size_t n_win, size_t max_events, size_t total_e
     a.ws_exp = (int32_t*)(aux + o_exp); a.fb_count = c->d_queue + 5; a.fb_total = c->d_fb_total; a.win_list = nullptr; a.n_list = nullptr;
     a.out_log_pr_data = d_out_lpd; a.out_pm_sums = d_out_pm; a.out_st_sums = d_out_st;
     a.out_beta = d_out_beta; a.queue = c->d_queue + 1; a.n_win = (unsigned)n_win;
+    a.prof = c->profile ? c->d_prof : nullptr;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Forward_Backward.hpp:53
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     const int grid = (int)std::min<size_t>((size_t)c->fb_slots, n_win);

@@ -88,6 +88,7 @@ struct FwbwArgs {
     float* out_st_sums;
     float* out_beta;
     unsigned* queue;            // [2] work-queue heads: forward kernel, backward kernel
+    unsigned long long* prof;   // [8] NCHMM_PROFILE=1 only; the shipped kernels do not touch it (tools/ubench/fb_phases.py builds a copy that does)
     unsigned n_win;
     float log_n_states;
     float log_2pi;

@@ -5,6 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export STEPS=${STEPS:-20}     # the --stats average runs over every launch: enough warm ones to outweigh the first two
 BENCH="python3 $ROOT/tools/bench_fwbw.py"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o fb -- $BENCH > $OUT/stats.log 2>&1

@@ -390,12 +390,7 @@ __device__ __forceinline__ void column(State& S, const float (*sTab)[kStates], V
         }
     }
     const unsigned w_lo = bpw[0], w_hi = bpw[1];
-    {
-        // streaming store: the row is read once, by the traceback, 21 GB of other rows later -- keeping it out of L2's write-back
-        // path takes 0.6 % off the sweep and 11 % off the traceback that follows (profiles/r04_vit_nt_ab.txt)
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store(u2v{w_lo, w_hi}, reinterpret_cast<u2v*>(bp_row + tau * 8u));
-    }
+    asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" :: "v"(bp_row + tau * 8u), "v"(make_uint2(w_lo, w_hi)) : "memory");
 }
 
 __device__ __forceinline__ bool event_in_fast_range(float x, float y)
