@@ -155,7 +155,7 @@ def test_the_lint_rules_on_hand_written_snippets():
 
 def test_no_scratch_traffic_in_the_forward_backward_event_loops(asm):
     """The rescaled sweeps spill (39 VGPRs in the forward kernel's prologue); none of it may sit in the per-event loop -- the loop
-    with the block barrier -- of either sweep (DESIGN.md section 4.2)."""
+    with the block barrier -- of either sweep (DESIGN.md section 4.3)."""
     for pat in ("fwbw_forward_scaled_kernel", "fwbw_backward_scaled_kernel"):
         loops = isa_lint.event_loops(asm["fwbw_scaled_kernel"], pat)
         assert loops, pat

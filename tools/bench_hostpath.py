@@ -1,5 +1,5 @@
 """Wall time of the host-pointer entry points (nchmm_viterbi, nchmm_viterbi_raw) for 1024 reads x 5000 events: kernels
-plus the copies between the caller's pageable memory and the device, with the shader clock of the box (DESIGN.md section 6)."""
+plus the copies between the caller's pageable memory and the device, with the shader clock of the box (DESIGN.md section 5)."""
 import hashlib, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
