@@ -2,7 +2,10 @@
 //
 // The reference spreads its host work over `-t` pfor threads that live for the whole run (nanocall.cpp:282,611).  The
 // library's host loops (event prep, per-job EM finish, per-slot transition weights, winner copies) are short -- tens of
-// microseconds to a millisecond -- so the workers must already exist when a loop starts.
+// microseconds to a millisecond -- so the workers must already exist when a loop starts; and on an 8-GPU node eight device
+// threads (nchmm_pool.cpp) run such loops at the same time, so the pool serves several loops at once: a loop is a JOB in one
+// of a few slots, workers take chunks from whichever jobs are open, the thread that posted a job works on it too and waits
+// only for its own chunks.
 #include "nchmm_internal.hpp"
 
 #include <atomic>
@@ -18,16 +21,24 @@ namespace nchmm {
 
 namespace {
 
-struct Pool {
-    std::mutex submit;                 // one parallel loop at a time; a second caller runs its loop itself
-    std::mutex m;
-    std::condition_variable cv_work, cv_done;
+constexpr unsigned kJobSlots = 16;
+
+struct Job {
     void (*fn)(void*, unsigned) = nullptr;
     void* arg = nullptr;
     unsigned n_chunks = 0;
-    std::atomic<unsigned> next{0};
-    unsigned busy = 0;                 // workers that have not yet finished the current generation
-    unsigned long long gen = 0;
+    std::atomic<unsigned> next{0};     // next chunk to hand out
+    std::atomic<unsigned> done{0};     // chunks finished
+    std::atomic<bool> open{false};     // chunks may still be taken
+    std::atomic<unsigned> inside{0};   // workers currently looking at this slot (it is not reused while any is)
+};
+
+struct Pool {
+    std::mutex m;                      // guards slot allocation and the sleep / wake-up of workers
+    std::condition_variable cv_work;
+    Job job[kJobSlots];
+    bool used[kJobSlots] = {};
+    unsigned long long posted = 0;     // bumped under m whenever a job opens
     unsigned n_workers = 0;
     pid_t owner = 0;
 };
@@ -35,20 +46,41 @@ struct Pool {
 Pool* g_pool = nullptr;
 std::once_flag g_once;
 
+// take chunks of job J until none are left; returns how many this thread ran
+unsigned drain(Job& J)
+{
+    unsigned ran = 0;
+    const unsigned n = J.n_chunks;
+    for (unsigned i; (i = J.next.fetch_add(1, std::memory_order_acq_rel)) < n;) {
+        J.fn(J.arg, i);
+        J.done.fetch_add(1, std::memory_order_acq_rel);
+        ++ran;
+    }
+    return ran;
+}
+
 void worker(Pool* P)
 {
     unsigned long long seen = 0;
     for (;;) {
-        std::unique_lock<std::mutex> lk(P->m);
-        P->cv_work.wait(lk, [&] { return P->gen != seen; });
-        seen = P->gen;
-        void (*fn)(void*, unsigned) = P->fn;
-        void* arg = P->arg;
-        const unsigned n = P->n_chunks;
-        lk.unlock();
-        for (unsigned i; (i = P->next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(arg, i);
-        lk.lock();
-        if (--P->busy == 0) P->cv_done.notify_one();
+        {
+            std::unique_lock<std::mutex> lk(P->m);
+            P->cv_work.wait(lk, [&] { return P->posted != seen; });
+            seen = P->posted;
+        }
+        // serve every open job; re-scan while any is open (a job may be posted while this thread is busy)
+        for (bool any = true; any;) {
+            any = false;
+            for (unsigned s = 0; s < kJobSlots; ++s) {
+                Job& J = P->job[s];
+                if (!J.open.load()) continue;
+                // announce, THEN look again: the poster closes the job and then waits for `inside` to drop to zero, so either
+                // this thread sees the job closed or the poster sees this thread (both sequentially consistent)
+                J.inside.fetch_add(1);
+                if (J.open.load() && J.next.load(std::memory_order_relaxed) < J.n_chunks) any = drain(J) != 0 || any;
+                J.inside.fetch_sub(1);
+            }
+        }
     }
 }
 
@@ -95,25 +127,35 @@ void run_chunks(unsigned n_chunks, void (*fn)(void*, unsigned), void* arg)
         g_pool = P;
     });
     Pool* P = g_pool;
-    // a forked child has no workers; a second concurrent loop (one host thread per device) does not queue behind the first
-    if (P->owner != getpid() || !P->submit.try_lock()) {
+    int slot = -1;
+    if (P->owner == getpid()) {         // (a forked child has no workers)
+        std::lock_guard<std::mutex> lk(P->m);
+        for (unsigned s = 0; s < kJobSlots; ++s)
+            if (!P->used[s]) { slot = (int)s; P->used[s] = true; break; }
+        if (slot >= 0) {
+            Job& J = P->job[slot];
+            J.fn = fn; J.arg = arg; J.n_chunks = n_chunks;
+            J.next.store(0, std::memory_order_relaxed);
+            J.done.store(0, std::memory_order_relaxed);
+            J.open.store(true);
+            ++P->posted;
+        }
+    }
+    if (slot < 0) {                     // every slot taken (or a forked child): run the loop here
         for (unsigned i = 0; i < n_chunks; ++i) fn(arg, i);
         return;
     }
+    P->cv_work.notify_all();
+    Job& J = P->job[slot];
+    drain(J);
+    // chunks handed to workers are short: spin politely until the last one has finished
+    while (J.done.load(std::memory_order_acquire) < n_chunks) std::this_thread::yield();
+    J.open.store(false);
+    while (J.inside.load() != 0) std::this_thread::yield();     // nobody may still hold the old n_chunks when the slot is reused
     {
         std::lock_guard<std::mutex> lk(P->m);
-        P->fn = fn; P->arg = arg; P->n_chunks = n_chunks;
-        P->next.store(0, std::memory_order_relaxed);
-        P->busy = P->n_workers;
-        ++P->gen;
+        P->used[slot] = false;
     }
-    P->cv_work.notify_all();
-    for (unsigned i; (i = P->next.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) fn(arg, i);
-    {
-        std::unique_lock<std::mutex> lk(P->m);
-        P->cv_done.wait(lk, [&] { return P->busy == 0; });
-    }
-    P->submit.unlock();
 }
 
 }  // namespace nchmm

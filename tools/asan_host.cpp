@@ -5,7 +5,10 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
+#include "nchmm_internal.hpp"
 #include <random>
 #include "nanocall_hip.h"
 int main(){
@@ -49,4 +52,18 @@ int main(){
     if (nchmm_initial_scaling(1, r0, r1, m0, m1, &sc, &sh)) return 26; if (nchmm_initial_scaling(0, r0, nullptr, m0, nullptr, &sc, &sh)) return 27;
     (void)nchmm_initial_scaling(0, z, nullptr, z, nullptr, &sc, &sh);   // degenerate: must not trap
     float mean, stdv; if (nchmm_mean_stdv(0, nullptr, &mean, &stdv)) return 28; if (nchmm_mean_stdv(1, r0, &mean, &stdv)) return 29; }
+  { // the host worker pool with several callers at once (one host thread per device runs such loops, nchmm_pool.cpp):
+    // every index of every loop is visited exactly once, slots are reused thousands of times
+    std::atomic<long> bad{0};
+    std::vector<std::thread> callers;
+    for (int id = 0; id < 6; ++id)
+      callers.emplace_back([&bad, id] {
+        for (int rep = 0; rep < 400; ++rep) {
+          const size_t n = 5 + (size_t)((rep * 7 + id * 13) % 600);
+          std::vector<int> hit(n, 0);
+          nchmm::parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) hit[i] += 1; });
+          for (size_t i = 0; i < n; ++i) if (hit[i] != 1) bad++;
+        } });
+    for (auto& t : callers) t.join();
+    if (bad.load()) return 30; }
   puts("host ABI under ASan/UBSan: ok"); return 0; }
