@@ -232,10 +232,10 @@ def end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, reps):
     return {"metric": "Mevents/s Viterbi, host pointers in and out (PCIe inclusive)", "value": round(total / ms / 1e3, 3), "unit": "Mevents/s",
             "ms_per_batch": round(ms, 3), "batches": reps - 1, "warm_up_batches": warm,
             "path": "nchmm_viterbi_begin / nchmm_viterbi_end, two batches in flight: pageable host SoA events -> H2D on the copy-in stream "
-                    "under the previous batch's kernels -> viterbi_kernel + traceback_kernel writing states / log-probs into pinned host "
-                    "memory -> memcpy into the caller's arrays under the next batch's kernels",
+                    "under the previous batch's kernel -> viterbi_kernel (sweep + in-block traceback) writing states / log-probs into pinned "
+                    "host memory -> memcpy into the caller's arrays under the next batch's kernel",
             "one_call": {"value": round(total / one_ms / 1e3, 3), "unit": "Mevents/s", "ms_per_call": round(one_ms, 3), "calls": reps,
-                         "path": "nchmm_viterbi: H2D -> viterbi_kernel + traceback_kernel -> D2H, one synchronous call per batch"},
+                         "path": "nchmm_viterbi: H2D -> viterbi_kernel -> D2H, one synchronous call per batch"},
             "pcie_bytes_per_batch": int(12 * total + 8 * (n_reads + 1) + 2 * total + 8 * n_reads),
             "identical_to_device_resident_run": True}
 
@@ -334,6 +334,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: per-GPU work fixed (default).  strong: BASELINE config 4 as written, the same 100 000 reads split over N")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
+    ap.add_argument("--serial-launches", action="store_true",
+                    help="queue every step behind the previous one (nchmm_viterbi_dev) instead of letting consecutive steps roll into "
+                         "each other on the context's two lanes (nchmm_viterbi_dev_enqueue / _join); profiling runs use it so that "
+                         "every kernel's duration in the trace is its own")
     ap.add_argument("--events", type=int, default=5000, help="events per read")
     ap.add_argument("--model", default="r73.t")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -406,32 +410,51 @@ def main():
 
     d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
     d_cm, d_sd, d_ls = (torch.from_numpy(x).to(dev) for x in (cm, sd, ls))
-    d_state = torch.empty(total, dtype=torch.int16, device=dev)
-    d_logp = torch.empty(n_reads, dtype=torch.float32, device=dev)
-    d_status = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    # two sets of outputs: consecutive steps overlap (see below) and must not write into the same arrays
+    outs = [(torch.empty(total, dtype=torch.int16, device=dev), torch.empty(n_reads, dtype=torch.float32, device=dev),
+             torch.zeros(n_reads, dtype=torch.int32, device=dev)) for _ in range(1 if args.serial_launches else 2)]
+    d_state, d_logp, d_status = outs[0]
+
+    # A step = one batch through the hot path: viterbi_kernel sweeps every read and each block walks its read back as soon as
+    # the last column is done.  The steps are queued with nchmm_viterbi_dev_enqueue on the context's two lanes and joined once
+    # at the end: the blocks of step k+1 start where the blocks of step k run out of reads, so no CU waits for the slowest
+    # block of a step (what a caller with more than one batch does; --serial-launches queues each step behind the previous one).
+    n_step = [0]
 
     def step():
-        ctx.viterbi_dev(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, d_state, d_logp, d_status)
+        o = outs[n_step[0] % len(outs)]
+        n_step[0] += 1
+        if args.serial_launches:
+            ctx.viterbi_dev(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, *o)
+        else:
+            ctx.viterbi_dev_enqueue(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, *o)
 
     for _ in range(args.warmup):
         step()
+    ctx.viterbi_dev_join()
     torch.cuda.synchronize()
     launches0 = int(ctx.counters()[3])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP events recorded by the library around the kernel on the launch stream; reading them
-        # waits for that launch only (steps are serialised on one stream anyway)
-        kernel_ms.append(ctx.last_kernel_ms()[:2])
+    ctx.viterbi_dev_join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ctx.synchronize()            # (reports a block that found no back-pointer region; cannot happen)
+    local_counters = ctx.counters()
+    # the kernel's own duration: launches one behind the other (nothing beside them), HIP events recorded by the library around
+    # each on the stream it runs on; reading them waits for that launch only.  Right behind the timed region, clocks still up.
+    kernel_ms = []
+    for _ in range(max(3, min(args.steps, 8)) if rank == 0 else 0):
+        ctx.viterbi_dev(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, *outs[0])
+        kernel_ms.append(ctx.last_kernel_ms()[:2])
+    torch.cuda.synchronize()
     # the hot kernels are VALU-issue bound, so their duration follows the shader clock -- and the boxes of one pool do not
     # all sustain the same clock (the same binary: 15.8 ms and 23.2 ms per launch on two boxes).  Probe it while still hot.
     try:
@@ -441,8 +464,7 @@ def main():
         sclk_mhz = float("nan")
     red_dev = dev if (world > 1 and not share_gpu0) else None      # gloo reduces host tensors
     dt = shard.max_over_ranks(dt, red_dev)
-    local_counters = ctx.counters()
-    launches_per_step = (int(local_counters[3]) - launches0) // (2 * max(1, args.steps))
+    launches_per_step = (int(local_counters[3]) - launches0) // max(1, args.steps)
     counters = shard.gather_counters(local_counters, red_dev)
 
     # device memory at the high-water mark (the workspace and staging buffers are kept between calls, so "now" is the peak)
@@ -462,8 +484,6 @@ def main():
     if rank == 0:
         value = global_reads * n_events * args.steps / dt / 1e6
         k_ms = float(np.mean([k[0] for k in kernel_ms]))
-        tb_ms = float(np.mean([k[1] for k in kernel_ms]))
-        # the library times the LAST sub-batch launch of a call; algorithmic bytes of that launch only
         events_per_launch = total if launches_per_step <= 1 else None
         if strong:
             which = "config 4 as written" if (global_reads == C4_TOTAL_READS and n_events == 5000) else "custom (strong scaling)"
@@ -510,19 +530,17 @@ def main():
             pmc = committed_pmc(n_reads, n_events)
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3), "traceback_kernel_ms": round(tb_ms, 3),
+                    "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3),
+                    "kernel_ms_note": f"mean of {len(kernel_ms)} launches queued one behind the other right after the timed region (hipEvents "
+                                      "on the launch stream): sweep + the traceback every block does when its read ends, nothing running "
+                                      "beside it; in the timed region consecutive launches overlap at their edges, so a step costs "
+                                      "ms_per_step, less than a launch lasts",
+                    "steps_overlap": not args.serial_launches,
                     "bytes_per_event": BYTES_PER_EVENT, "events_per_launch": events_per_launch,
                     "kernel_source_sha256_16": kernel_source_hash()}
             if pmc:
                 k = pmc["viterbi_kernel"]
                 roof["traffic"] = int((k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
-                tb = pmc.get("traceback_kernel")
-                if tb and "FETCH_SIZE_KiB" in tb and "WRITE_SIZE_KiB" in tb:
-                    # the 4113 B/event include the traceback's back-pointer read and state write, so its launch belongs in the
-                    # measured traffic as well (it fetches whole 64-byte sectors for the bytes it needs)
-                    roof["traffic_forward_kernel"] = roof["traffic"]
-                    roof["traffic_traceback_kernel"] = int((tb["FETCH_SIZE_KiB"] + tb["WRITE_SIZE_KiB"]) * 1024)
-                    roof["traffic"] += roof["traffic_traceback_kernel"]
                 roof["traffic_source"] = pmc.get("_file")
                 valu = float(k["SQ_INSTS_VALU"])
                 roof["valu_instructions_per_thread_event"] = round(valu / (n_reads * n_events * 8.0), 1)
@@ -533,11 +551,11 @@ def main():
                 roof["valu_floor_frac"] = round(roof["valu_floor_ms"] / k_ms, 4)
             result["roofline"] = roof
         else:
-            # sub-batched call: report the whole step against the roofline (all forward + traceback launches)
+            # a step of several launches: report the whole step against the roofline
             achieved = BYTES_PER_EVENT * total / (dt / args.steps) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                                  "kernel": f"nchmm::viterbi_kernel x{launches_per_step} + nchmm::traceback_kernel x{launches_per_step} per step (wall)",
+                                  "kernel": f"nchmm::viterbi_kernel x{launches_per_step} per step (wall)",
                                   "bytes_per_event": BYTES_PER_EVENT, "events_per_step": total,
                                   "last_launch_kernel_ms": round(k_ms, 3)}
         if world == 1 and not args.no_end_to_end and total <= 64 * 1024 * 1024:

@@ -240,14 +240,31 @@ int nchmm_viterbi(nchmm_ctx* ctx, size_t n_reads, const uint64_t* off, const flo
 
 /* device-pointer form: every pointer is device memory on the context's GPU; enqueues on the
  * context's stream and returns without synchronising.  max_events = max_r (off[r+1]-off[r]) and
- * total_events = off[n_reads] must be supplied by the caller (they size the workspace; the offsets
- * themselves stay on the device).  order (may be NULL) is a permutation of reads giving the
- * processing order (longest first balances the work queue). */
+ * total_events = off[n_reads] must be supplied by the caller (max_events sizes the back-pointer workspace: one
+ * region of 4 KiB x max_events per resident thread block, whatever n_reads is; the offsets themselves stay on
+ * the device).  order (may be NULL) is a permutation of reads giving the processing order (longest first
+ * balances the work queue). */
 int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t total_events,
                       const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
                       const float* d_log_stdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
                       const uint32_t* d_order, uint16_t* d_out_state, float* d_out_path_logp,
                       int32_t* d_out_status);
+
+/* nchmm_viterbi_dev in two halves, for callers that keep several batches going (the reference keeps its cores busy with
+ * one strand per pfor thread, nanocall.cpp:611-621; a GPU is kept busy by letting the thread blocks of the next batch
+ * start where those of the previous one run out of reads).
+ *   enqueue  queues the batch behind whatever is on the context's stream NOW, on one of the context's internal
+ *            streams (two, taken in turn), and returns.  The batch may run beside the batch enqueued before it.
+ *   join     makes the context's stream wait for every batch enqueued so far: what is queued on that stream
+ *            afterwards sees their outputs.  (nchmm_synchronize joins, waits, and reports.)
+ * Between enqueue and join the caller leaves the batch's inputs and outputs alone, and must not hand the same output
+ * arrays to a second batch.  nchmm_viterbi_dev is enqueue followed by join. */
+int nchmm_viterbi_dev_enqueue(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t total_events,
+                              const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
+                              const float* d_log_stdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
+                              const uint32_t* d_order, uint16_t* d_out_state, float* d_out_path_logp,
+                              int32_t* d_out_status);
+int nchmm_viterbi_dev_join(nchmm_ctx* ctx);
 
 /* Viterbi from RAW events, with the host prep of basecall_strand on the device:
  * candidate v decodes raw events [src[v], src[v] + len[v]) of the uploaded (mean, stdv, start) arrays -- several
@@ -264,8 +281,9 @@ int nchmm_viterbi_raw(nchmm_ctx* ctx, size_t n_raw_events, const float* mean, co
 
 /* The two host-pointer forms above, split for callers that stream batches (the reference hides the latency of a strand
  * behind its pfor worker threads, nanocall.cpp:611-621; here the unit is a batch and the latencies are the PCIe copies and
- * the traceback launch).  A batch is cut into read ranges: range k+1 is copied in while range k computes, on a copy-in
- * stream, two compute lanes and a copy-out stream -- the one-call forms are begin followed by end.
+ * the tail of a launch, when its blocks run out of reads one by one).  A batch is cut into read ranges: range k+1 is
+ * copied in while range k computes, on a copy-in stream and two compute lanes taken in turn, results written
+ * by the kernels straight into pinned host memory -- the one-call forms are begin followed by end.
  *   begin  validates, stages and enqueues copy-in + kernels of a batch, and returns (it holds the thread for the
  *          duration of the H2D copies only).  At most TWO batches may be in flight per context (NCHMM_E_INVALID beyond).
  *   end    completes the OLDEST batch in flight: copies its states out range by range as they finish, waits, fills
@@ -407,9 +425,9 @@ int nchmm_basecall_reads(nchmm_ctx* ctx, const nchmm_train_opts* opts, size_t n_
 int nchmm_counters(const nchmm_ctx* ctx, uint64_t out[8]);
 
 /* hipEvent times (ms) of the kernels most recently launched through this context, measured on the
- * stream they ran on: out[0] = Viterbi forward kernel, out[1] = traceback kernel (of the last
- * sub-batch when a call was split), out[2] = forward-backward kernel, out[3] reserved.  Blocks
- * until those kernels have finished. */
+ * stream they ran on: out[0] = the most recent Viterbi launch (sweep + the traceback each block does when
+ * its read ends; a kernel time only when no other launch ran beside it), out[1] = 0 (there is no separate
+ * traceback kernel), out[2] = forward-backward kernel, out[3] reserved.  Blocks until those kernels have finished. */
 int nchmm_last_kernel_ms(nchmm_ctx* ctx, float out[4]);
 
 /* The shader clock (MHz) the device sustains under a full-chip VALU load, measured now by a ~3 ms probe kernel on the
@@ -420,7 +438,7 @@ int nchmm_shader_clock_mhz(nchmm_ctx* ctx, double* out_mhz);
 
 /* Phase counters of the Viterbi kernel, accumulated over launches while the environment variable
  * NCHMM_PROFILE=1 was set at nchmm_create time: out[0] = forward-sweep ticks summed over blocks,
- * [1] = unused, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks), [4] = traceback
+ * [1] = arg-max + traceback ticks, [2] = whole-block ticks, [3] = blocks (100 MHz wall_clock64 ticks), [4] = traceback
  * segments that had to be re-walked, [5] = speculative traceback segments, [6] = wave-columns of the forward sweep
  * that took the exact sum-by-sum group rescan (a smaller alpha could round to the winner's sum), [7] = 3-way combines
  * (per wave and cell) that took the exact lowest-predecessor-index rule because two class winners were equal. */
@@ -432,8 +450,11 @@ int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);
 int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
 
 /* Device memory the context holds now (out[0]) and at its high-water mark (out[1]), in bytes: tables, staging and the
- * back-pointer workspace (4 KiB per event of the largest launch; the reference's Viterbi matrix is 32 KiB per event of ONE read,
- * Viterbi.hpp:50).  NCHMM_WS_BUDGET_MB bounds the workspace: a batch that needs more runs as several launches. */
+ * back-pointer workspace -- one region of 4 KiB per event of the LONGEST read for every thread block that can be resident
+ * (2 per CU, a few to spare), independent of the number of reads: a block walks its read back as soon as it has swept
+ * it and reuses the region (the reference's Viterbi matrix is 32 KiB per event, one per pfor thread, Viterbi.hpp:50).
+ * NCHMM_WS_BUDGET_MB bounds the workspace: reads too long for the full set of regions run on as many blocks as the
+ * budget has regions for. */
 int nchmm_mem_stats(const nchmm_ctx* ctx, uint64_t out[2]);
 
 /* ------------------------------------------------------------------------------------------

@@ -64,6 +64,8 @@ SIGNATURES = {
     "nchmm_put_transitions_fast": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp]),
     "nchmm_viterbi": (C.c_int, [vp, C.c_size_t] + [vp] * 9),
     "nchmm_viterbi_dev": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
+    "nchmm_viterbi_dev_enqueue": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
+    "nchmm_viterbi_dev_join": (C.c_int, [vp]),
     "nchmm_viterbi_raw": (C.c_int, [vp, C.c_size_t, vp, vp, vp, C.c_size_t] + [vp] * 8),
     "nchmm_viterbi_begin": (C.c_int, [vp, C.c_size_t] + [vp] * 9),
     "nchmm_viterbi_raw_begin": (C.c_int, [vp, C.c_size_t, vp, vp, vp, C.c_size_t] + [vp] * 8),

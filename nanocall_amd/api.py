@@ -389,6 +389,18 @@ class Context:
                                       _dp(d_order), _dp(d_out_state), _dp(d_out_logp), _dp(d_out_status)),
               "nchmm_viterbi_dev")
 
+    def viterbi_dev_enqueue(self, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_out_state,
+                            d_out_logp, d_out_status=None, d_model_slot=None, d_trans_slot=None, d_order=None):
+        """nchmm_viterbi_dev_enqueue: queue the batch on one of the context's internal streams (it may run beside the
+        batch queued before it); outputs are complete after viterbi_dev_join() / synchronize()."""
+        check(lib().nchmm_viterbi_dev_enqueue(self._h, n_reads, max_events, total_events, _dp(d_off), _dp(d_cmean),
+                                              _dp(d_stdv), _dp(d_lstdv), _dp(d_model_slot), _dp(d_trans_slot),
+                                              _dp(d_order), _dp(d_out_state), _dp(d_out_logp), _dp(d_out_status)),
+              "nchmm_viterbi_dev_enqueue")
+
+    def viterbi_dev_join(self):
+        check(lib().nchmm_viterbi_dev_join(self._h), "nchmm_viterbi_dev_join")
+
     # -- forward-backward --
     def fwbw(self, off, cmean, stdv, log_stdv, scaled_slot=None, pm_params=None, trans_slot=None,
              st_params=None, want_matrices=False):

@@ -218,6 +218,8 @@ int reserve_slots(nchmm_ctx* c, int n)
 {
     if (n <= c->n_slots) return NCHMM_OK;
     if (c->own_stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int l = 0; l < kVitLanes; ++l)      // a launch on a lane may still be reading the tables that are about to move
+        if (c->lane[l].stream) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
     auto grow = [&](void** p, size_t elem_bytes) -> int {
         void* q = nullptr;
         int rc = dev_alloc(c, &q, elem_bytes * (size_t)n);
@@ -263,6 +265,20 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NCHMM_E_HIP);
     c->stream = c->own_stream;
+    c->lane[0].stream = c->own_stream;
+    for (int l = 1; l < kVitLanes; ++l)
+        if (hipStreamCreateWithFlags(&c->lane[l].stream, hipStreamNonBlocking) != hipSuccess) return fail(NCHMM_E_HIP);
+    for (int l = 0; l < kVitLanes; ++l)
+        if (hipEventCreate(&c->lane[l].ev0) != hipSuccess || hipEventCreate(&c->lane[l].ev1) != hipSuccess
+            || hipEventCreateWithFlags(&c->lane[l].done, hipEventDisableTiming) != hipSuccess)
+            return fail(NCHMM_E_HIP);
+    if (hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming) != hipSuccess) return fail(NCHMM_E_HIP);
+    {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocDefault) != hipSuccess) return fail(NCHMM_E_HIP);
+        c->h_err = (unsigned*)hp;
+        *c->h_err = 0;
+    }
     if ((rc = reserve_slots(c, kMaxSlots))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_train_mask, 512))) return fail(rc);
     if ((rc = dev_alloc(c, (void**)&c->d_masks, kTransFloats))) return fail(rc);
@@ -298,11 +314,13 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         const char* b = std::getenv("NCHMM_FB_BUDGET_MB");
         if (b) c->fb_budget = std::max<size_t>((size_t)std::strtoull(b, nullptr, 10) << 20, (size_t)16 << 20);
     }
-    if (hipEventCreate(&c->ev_vit0) != hipSuccess || hipEventCreate(&c->ev_vit1) != hipSuccess
-        || hipEventCreate(&c->ev_vit2) != hipSuccess
-        || hipEventCreate(&c->ev_fb0) != hipSuccess || hipEventCreate(&c->ev_fb1) != hipSuccess)
+    if (hipEventCreate(&c->ev_fb0) != hipSuccess || hipEventCreate(&c->ev_fb1) != hipSuccess)
         return fail(NCHMM_E_HIP);
     c->vit_slots = c->n_cu * viterbi_blocks_per_cu();
+    // back-pointer regions are handed out per XCD: as many as blocks can be resident there, and some to spare
+    c->slots_per_xcd = (unsigned)((c->vit_slots + (int)kXcds - 1) / (int)kXcds) + 8u;
+    if ((rc = dev_alloc(c, (void**)&c->d_slot_owner, sizeof(unsigned) * kXcds * c->slots_per_xcd))) return fail(rc);
+    if (hipMemset(c->d_slot_owner, 0, sizeof(unsigned) * kXcds * c->slots_per_xcd) != hipSuccess) return fail(NCHMM_E_HIP);
     c->fb_slots = c->n_cu * fwbw_blocks_per_cu();
     *out = c;
     return NCHMM_OK;
@@ -313,6 +331,8 @@ int nchmm_destroy(nchmm_ctx* c)
     if (!c) return NCHMM_E_INVALID;
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
+    for (int l = 0; l < kVitLanes; ++l)
+        if (c->lane[l].stream) (void)hipStreamSynchronize(c->lane[l].stream);
     if (c->d_models) (void)hipFree(c->d_models);
     if (c->d_trans) (void)hipFree(c->d_trans);
     if (c->d_trans_fb) (void)hipFree(c->d_trans_fb);
@@ -324,7 +344,8 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_model_fast) (void)hipFree(c->d_model_fast);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->d_ws) (void)hipFree(c->d_ws);
-    if (c->d_last_state) (void)hipFree(c->d_last_state);
+    if (c->d_slot_owner) (void)hipFree(c->d_slot_owner);
+    if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_fb_aux) (void)hipFree(c->d_fb_aux);
     if (c->d_fb_total) (void)hipFree(c->d_fb_total);
@@ -333,9 +354,13 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
     if (c->d_masks) (void)hipFree(c->d_masks);
-    if (c->ev_vit0) (void)hipEventDestroy(c->ev_vit0);
-    if (c->ev_vit1) (void)hipEventDestroy(c->ev_vit1);
-    if (c->ev_vit2) (void)hipEventDestroy(c->ev_vit2);
+    for (int l = 0; l < kVitLanes; ++l) {
+        if (c->lane[l].ev0) (void)hipEventDestroy(c->lane[l].ev0);
+        if (c->lane[l].ev1) (void)hipEventDestroy(c->lane[l].ev1);
+        if (c->lane[l].done) (void)hipEventDestroy(c->lane[l].done);
+        if (l > 0 && c->lane[l].stream) (void)hipStreamDestroy(c->lane[l].stream);
+    }
+    if (c->ev_entry) (void)hipEventDestroy(c->ev_entry);
     if (c->ev_fb0) (void)hipEventDestroy(c->ev_fb0);
     if (c->ev_fb1) (void)hipEventDestroy(c->ev_fb1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -365,8 +390,12 @@ int nchmm_synchronize(nchmm_ctx* c)
 {
     if (!c) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    for (int l = 0; l < kVitLanes; ++l) {
+        if (c->lane[l].pending) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+        c->lane[l].pending = false;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return NCHMM_OK;
+    return viterbi_check_err(c);
 }
 
 int nchmm_put_model(nchmm_ctx* c, int slot, const float* t6)
@@ -496,42 +525,6 @@ int nchmm_put_transitions(nchmm_ctx* c, int slot, const uint32_t* row_ptr, const
 
 namespace nchmm {
 
-// Launch forward + traceback for reads [first, first + count) whose events start at ev_base and
-// number ev_count, on L.stream, through the context's back-pointer workspace and work queue (so launches of one context
-// must execute one after the other: the callers order their streams with events).  d_order (may be null) is a
-// permutation of exactly these reads.
-int launch_viterbi_range(nchmm_ctx* c, const VitLane& L, size_t first, size_t count, uint64_t ev_base, uint64_t ev_count,
-                         const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
-                         const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status)
-{
-    ViterbiArgs a;
-    a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
-    a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
-    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
-    a.prof = c->profile ? c->d_prof : nullptr;
-    a.ws = c->d_ws; a.ev_base = ev_base; a.first_read = (unsigned)first; a.last_state = L.last_state;
-    a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
-    a.queue = c->d_vq; a.cu_progress = c->d_vq + 16; a.n_reads = (unsigned)count;
-    a.tb_margin = c->tb_margin;
-    a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
-    a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
-    const int grid = (int)std::min<size_t>((size_t)c->vit_slots, count);
-    a.queue_base = c->vq_base;
-    c->vq_base += (unsigned)count + (unsigned)grid;   // every read takes a ticket, every block one more to find the queue empty
-    HIP_TRY(c, hipEventRecord(c->ev_vit0, L.stream));
-    launch_viterbi(a, grid, L.stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_vit1, L.stream));
-    launch_traceback(a, L.stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_vit2, L.stream));
-    c->vit_timed = true;
-    c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kBpRowBytes;
-    c->counters[3] += 2;
-    return NCHMM_OK;
-}
-
 // Largest back-pointer workspace the context is willing to hold: NCHMM_WS_BUDGET_MB, else 60 % of what is free at first use
 int viterbi_ws_budget(nchmm_ctx* c, size_t* out)
 {
@@ -546,76 +539,169 @@ int viterbi_ws_budget(nchmm_ctx* c, size_t* out)
     return NCHMM_OK;
 }
 
+// One region of kBpRowBytes x (longest read) per resident block.  Normal case: a pool of kXcds x p regions -- p = as many
+// blocks as can be resident on an XCD and a few to spare, fewer when the launches are smaller than that -- fits the budget:
+// blocks take and return regions themselves and launches may overlap.  Reads so long that the pool would not fit: as many
+// regions as the budget holds (at least one: a read longer than the budget still runs, alone), one block per region,
+// region = block index, launches one after the other.
+int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count)
+{
+    size_t budget = 0;
+    int rc = viterbi_ws_budget(c, &budget);
+    if (rc != NCHMM_OK) return rc;
+    const size_t need = (size_t)std::max<uint64_t>(longest, 1) * kBpRowBytes;
+    // blocks of up to kVitLanes launches can sit on one XCD at a time
+    const unsigned per_xcd = (unsigned)std::min<size_t>(c->slots_per_xcd, std::max<size_t>(count, 1) * kVitLanes);
+    const bool want_pooled = need <= budget / ((size_t)kXcds * per_xcd);
+    if (c->d_ws && need <= c->slot_bytes && ((c->ws_pooled && per_xcd <= c->ws_per_xcd) || (!c->ws_pooled && !want_pooled))) return NCHMM_OK;
+    // (re)allocate: nothing may be using the regions
+    for (int l = 0; l < kVitLanes; ++l)
+        if (c->lane[l].pending) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+    const unsigned per_xcd_new = c->ws_pooled ? std::max(per_xcd, c->ws_per_xcd) : per_xcd;
+    const size_t keep_slot = c->ws_pooled ? c->slot_bytes : 0;
+    if (c->d_ws) {
+        HIP_TRY(c, hipFree(c->d_ws));
+        c->counters[6] -= c->ws_bytes;
+        c->d_ws = nullptr; c->ws_bytes = 0; c->slot_bytes = 0; c->ws_regions = 0; c->ws_per_xcd = 0;
+    }
+    size_t slot = need, regions = (size_t)kXcds * per_xcd_new;
+    if (want_pooled && std::max(need, keep_slot) <= budget / regions) {
+        slot = std::max(need, keep_slot);
+        slot = std::min(slot + slot / 8, budget / regions);   // head-room so slowly growing batches do not reallocate every call
+    } else if (want_pooled) {
+        regions = (size_t)kXcds * per_xcd;                    // (the pool had grown past what this read length allows)
+    } else {
+        regions = std::min<size_t>(std::max<size_t>(budget / need, 1), (size_t)std::max(c->vit_slots, 1));
+    }
+    slot = (slot + 4095) & ~(size_t)4095;
+    void* p = nullptr;
+    if ((rc = dev_alloc(c, &p, slot * regions))) return rc;
+    c->d_ws = (uint8_t*)p; c->ws_bytes = slot * regions; c->slot_bytes = slot; c->ws_regions = (unsigned)regions;
+    c->ws_pooled = want_pooled;
+    c->ws_per_xcd = want_pooled ? (unsigned)(regions / kXcds) : 0;
+    return NCHMM_OK;
+}
+
+hipStream_t viterbi_next_lane_stream(nchmm_ctx* c) { return c->lane[c->ws_pooled ? c->next_lane : 0].stream; }
+
+int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
+                         const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                         const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out)
+{
+    if (!c->d_ws) return NCHMM_E_INVALID;
+    // without a pool every launch owns regions 0 .. grid-1: one lane, strictly one launch after the other
+    const int li = c->ws_pooled ? c->next_lane : 0;
+    VitLaneState& L = c->lane[li];
+    ViterbiArgs a;
+    a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
+    a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
+    a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
+    a.prof = c->profile ? c->d_prof : nullptr;
+    a.ws = c->d_ws; a.slot_bytes = c->slot_bytes;
+    a.slot_owner = c->ws_pooled ? c->d_slot_owner : nullptr; a.slots_per_xcd = c->ws_per_xcd;
+    a.host_err = c->h_err;
+    a.first_read = (unsigned)first;
+    a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
+    a.queue = c->d_vq + li; a.cu_progress = c->d_vq + 16; a.n_reads = (unsigned)count;
+    c->launch_seq = c->launch_seq % 4095u + 1u;
+    a.launch_tag = c->launch_seq;
+    a.tb_margin = c->tb_margin;
+    a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
+    a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
+    const size_t slots = c->ws_pooled ? (size_t)c->vit_slots : (size_t)c->ws_regions;
+    const int grid = (int)std::min<size_t>(slots, count);
+    a.queue_base = L.vq_base;
+    L.vq_base += (unsigned)count + (unsigned)grid;   // every read takes a ticket, every block one more to find the queue empty
+    if (after) HIP_TRY(c, hipStreamWaitEvent(L.stream, after, 0));
+    if (!c->ws_pooled && c->last_lane >= 0 && c->last_lane != li) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->lane[c->last_lane].done, 0));
+    HIP_TRY(c, hipEventRecord(L.ev0, L.stream));
+    launch_viterbi(a, grid, L.stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(L.ev1, L.stream));
+    HIP_TRY(c, hipEventRecord(L.done, L.stream));
+    L.pending = true;
+    c->last_lane = li;
+    c->next_lane = (li + 1) % kVitLanes;
+    c->vit_timed = true;
+    c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kBpRowBytes;
+    c->counters[3] += 1;
+    if (lane_out) *lane_out = li;
+    return NCHMM_OK;
+}
+
+int viterbi_join(nchmm_ctx* c, hipStream_t s)
+{
+    for (int l = 0; l < kVitLanes; ++l) {
+        VitLaneState& L = c->lane[l];
+        if (!L.pending) continue;
+        if (L.stream != s) HIP_TRY(c, hipStreamWaitEvent(s, L.done, 0));
+        L.pending = false;
+    }
+    return NCHMM_OK;
+}
+
+int viterbi_check_err(nchmm_ctx* c)
+{
+    if (c->h_err && *(volatile unsigned*)c->h_err) {
+        *c->h_err = 0;
+        return NCHMM_E_HIP;
+    }
+    return NCHMM_OK;
+}
+
 }  // namespace nchmm
 
-extern "C" int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
-                      const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
-                      const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
-                      uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
+extern "C" {
+
+// The batch starts behind whatever is on the context's stream now and may run beside the batch queued before it (the blocks
+// of one launch start where the previous launch's blocks run out of reads).  Nothing is waited for here.
+int nchmm_viterbi_dev_enqueue(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
+                              const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                              const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
+                              uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
 {
     if (!c) return NCHMM_E_INVALID;
     if (n_reads == 0) return NCHMM_OK;
     if (!d_off || !d_out_logp || n_reads > 0xFFFFFFF0ull || max_events > 0x7FFFFFF0ull) return NCHMM_E_INVALID;
     if (total_events && (!d_cmean || !d_stdv || !d_lstdv || !d_out_state)) return NCHMM_E_INVALID;
-    if (pipe_in_flight(c)) return NCHMM_E_INVALID;   // the workspace and the queue words are in use (nchmm_viterbi_begin)
+    if (pipe_in_flight(c)) return NCHMM_E_INVALID;   // the host-pointer pipeline owns the lanes (nchmm_viterbi_begin)
     HIP_TRY(c, hipSetDevice(c->device));
-    void* p = c->d_last_state;
-    int rc = ensure(c, &p, &c->last_state_bytes, sizeof(unsigned) * n_reads);
-    c->d_last_state = (unsigned*)p;
+    int rc = viterbi_ws_prepare(c, max_events, n_reads);
     if (rc != NCHMM_OK) return rc;
-    // Back-pointer workspace: kBpRowBytes (4 KiB: one byte per state) per event.  When the whole batch fits the budget it is one
-    // forward + one traceback launch; otherwise the batch is cut into contiguous read ranges.
-    {
-        size_t budget = 0;
-        if ((rc = viterbi_ws_budget(c, &budget))) return rc;
-    }
-    const size_t need_all = std::max<size_t>(total_events, 1) * (size_t)kBpRowBytes;
     c->counters[0] += n_reads;
     c->counters[1] += total_events;
-    if (need_all <= std::max(c->ws_budget, c->ws_bytes)) {
-        p = c->d_ws;
-        rc = ensure(c, &p, &c->ws_bytes, need_all);
-        c->d_ws = (uint8_t*)p;
-        if (rc != NCHMM_OK) return rc;
-        return launch_viterbi_range(c, VitLane{c->stream, c->d_last_state}, 0, n_reads, 0, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
-                            d_order, d_out_state, d_out_logp, d_out_status);
+    // behind what the CALLER has on its stream.  The context's own stream is lane 0: what is on it are this context's earlier
+    // launches (every other entry point that uses it returns synchronised), and waiting for those is what the lanes are there
+    // to avoid.
+    hipEvent_t after = nullptr;
+    if (c->external_stream) {
+        HIP_TRY(c, hipEventRecord(c->ev_entry, c->stream));
+        after = c->ev_entry;
     }
-    // split: needs the offsets on the host (small copy), reads are taken in input order
-    std::vector<uint64_t> off(n_reads + 1);
-    HIP_TRY(c, hipMemcpyAsync(off.data(), d_off, sizeof(uint64_t) * (n_reads + 1), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint64_t budget_events = std::max<uint64_t>(c->ws_budget / kBpRowBytes, max_events);
-    // Every launch ends with a tail in which the persistent blocks run dry one by one.  With reads of similar length a range of
-    // k * (resident blocks) reads drains evenly; 1560 reads on 512 blocks take four rounds for three rounds' worth of work
-    // (measured: 249 instead of 318 Mevents/s), and 1024 long reads cut 806 + 218 by the budget alone ran at 242 instead of
-    // 330.  So: the fewest launches the budget allows, the reads spread evenly over them in whole grid-fulls.
-    const size_t slots = std::max<size_t>((size_t)c->vit_slots, 1);
-    const size_t n_launch = (size_t)((total_events + budget_events - 1) / budget_events);
-    size_t per = (n_reads + n_launch - 1) / n_launch;
-    per = (per + slots - 1) / slots * slots;
-    std::vector<size_t> cut{0};
-    uint64_t ws_events = 1;
-    for (size_t first = 0; first < n_reads;) {
-        size_t last = first;
-        while (last < n_reads && last - first < per && off[last + 1] - off[first] <= budget_events) ++last;
-        if (last == first) return NCHMM_E_NOMEM;   // a single read larger than the workspace
-        if (last < n_reads && last - first < per && (last - first) > slots) last = first + (last - first) / slots * slots;   // cut short by the budget
-        cut.push_back(last);
-        ws_events = std::max<uint64_t>(ws_events, off[last] - off[first]);
-        first = last;
-    }
-    p = c->d_ws;
-    rc = ensure(c, &p, &c->ws_bytes, (size_t)ws_events * kBpRowBytes);
-    c->d_ws = (uint8_t*)p;
-    if (rc != NCHMM_OK) return rc;
-    for (size_t k = 0; k + 1 < cut.size(); ++k) {
-        const size_t first = cut[k], last = cut[k + 1];
-        rc = launch_viterbi_range(c, VitLane{c->stream, c->d_last_state}, first, last - first, off[first], off[last] - off[first], d_off, d_cmean, d_stdv, d_lstdv,
-                          d_model_slot, d_trans_slot, nullptr, d_out_state, d_out_logp, d_out_status);
-        if (rc != NCHMM_OK) return rc;
-    }
-    return NCHMM_OK;
+    return launch_viterbi_range(c, after, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
+                                d_order, d_out_state, d_out_logp, d_out_status, nullptr);
 }
+
+// Put every batch queued by nchmm_viterbi_dev_enqueue in front of whatever comes next on the context's stream.
+int nchmm_viterbi_dev_join(nchmm_ctx* c)
+{
+    if (!c) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return viterbi_join(c, c->stream);
+}
+
+int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
+                      const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                      const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
+                      uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
+{
+    const int rc = nchmm_viterbi_dev_enqueue(c, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot,
+                                             d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status);
+    return rc == NCHMM_OK && n_reads ? nchmm_viterbi_dev_join(c) : rc;
+}
+
+}  // extern "C"
 
 extern "C" {
 
@@ -962,10 +1048,11 @@ int nchmm_last_kernel_ms(nchmm_ctx* c, float out[4])
     if (!c || !out) return NCHMM_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (c->vit_timed) {
-        HIP_TRY(c, hipEventSynchronize(c->ev_vit2));
-        HIP_TRY(c, hipEventElapsedTime(&out[0], c->ev_vit0, c->ev_vit1));
-        HIP_TRY(c, hipEventElapsedTime(&out[1], c->ev_vit1, c->ev_vit2));
+    if (c->vit_timed && c->last_lane >= 0) {
+        // the most recent launch (sweep + in-block traceback): meaningful as a kernel time when nothing ran beside it
+        const VitLaneState& L = c->lane[c->last_lane];
+        HIP_TRY(c, hipEventSynchronize(L.ev1));
+        HIP_TRY(c, hipEventElapsedTime(&out[0], L.ev0, L.ev1));
     }
     if (c->fb_timed) {
         HIP_TRY(c, hipEventSynchronize(c->ev_fb1));

@@ -16,6 +16,19 @@ namespace nchmm {
 struct PipeState;
 }
 
+namespace nchmm {
+// A compute lane of the Viterbi path: consecutive launches go to alternating lanes so that the blocks of one launch start in
+// the places the previous launch's blocks vacate (viterbi_kernel.hip).  Lane 0 runs on the context's own stream.
+constexpr int kVitLanes = 2;
+struct VitLaneState {
+    hipStream_t stream = nullptr;
+    unsigned vq_base = 0;            // what this lane's queue head will read when its next launch starts (never reset)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the lane's most recent launch (timing)
+    hipEvent_t done = nullptr;       // behind the lane's most recent launch (ordering)
+    bool pending = false;            // work queued since the last join
+};
+}  // namespace nchmm
+
 struct nchmm_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
@@ -30,22 +43,31 @@ struct nchmm_ctx {
     float* d_trans_fb = nullptr;    // [kMaxSlots][kFbTransFloats] per-state forward/backward weights for FB
     uint8_t* d_train_mask = nullptr; // [512] transition-training k-mers, one bit per state
     unsigned* d_queue = nullptr;    // forward-backward work-queue heads [1..4], redo count [5]
-    unsigned* d_vq = nullptr;       // Viterbi work-queue head [0] and per-(CU, block slot) progress words [16..]
-    unsigned vq_base = 0;           // what the queue head will read when the next launch starts (zeroed once, never reset)
+    unsigned* d_vq = nullptr;       // Viterbi work-queue heads [lane] and per-(CU, block slot) progress words [16..]
+    nchmm::VitLaneState lane[nchmm::kVitLanes];
+    int next_lane = 0;
+    int last_lane = -1;             // lane of the most recent launch
+    unsigned launch_seq = 0;        // launch tags (1 .. 4095, cyclic)
+    hipEvent_t ev_entry = nullptr;  // what was on the caller's stream when a batch was queued
+    unsigned* h_err = nullptr;      // pinned host word a block sets when it finds no back-pointer region
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
     bool profile = false;
     int tb_margin = 128;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path); profiles/r03_tb_margin.txt:
                                     // 0 of 86 016 speculative segments un-merged at 64, 384 at 32 -- and a miss only costs a re-walk
-    uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace (4 KiB per event of a launch)
-    size_t ws_bytes = 0;
+    uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace: ws_regions regions of slot_bytes (4 KiB per event of the
+    size_t ws_bytes = 0;            // longest read), one per resident block
+    size_t slot_bytes = 0;
+    unsigned ws_regions = 0;
+    bool ws_pooled = false;         // regions are handed out by the blocks themselves (per XCD): launches may overlap
+    unsigned* d_slot_owner = nullptr;   // [kXcds][slots_per_xcd]
+    unsigned slots_per_xcd = 0;     // capacity of the owner table per XCD
+    unsigned ws_per_xcd = 0;        // regions per XCD the workspace holds now (<= slots_per_xcd)
     hipStream_t s_in = nullptr;     // copy-in stream of the host-pointer pipeline (nchmm_pipeline.cpp); it computes on own_stream
     nchmm::PipeState* pipe = nullptr;   // batches in flight (nchmm_pipeline.cpp)
     size_t peak_bytes = 0;          // high-water mark of counters[6] (device bytes held)
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
     size_t fb_budget = 0;           // same for the forward-backward alpha rows (16 KiB per event)
-    unsigned* d_last_state = nullptr; // per read: arg-max state of the last column
-    size_t last_state_bytes = 0;
     float* d_fb_ws = nullptr;       // FB alpha workspace
     size_t fb_ws_floats = 0;
     void* d_fb_aux = nullptr;       // FB per-call scratch: lpd2 | last-row totals | redo list | redo flags | row exponents
@@ -62,7 +84,7 @@ struct nchmm_ctx {
     size_t tab_stage_bytes = 0;
     void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
     size_t h_pin_bytes = 0;
-    hipEvent_t ev_vit0 = nullptr, ev_vit1 = nullptr, ev_vit2 = nullptr, ev_fb0 = nullptr, ev_fb1 = nullptr;
+    hipEvent_t ev_fb0 = nullptr, ev_fb1 = nullptr;
     bool vit_timed = false, fb_timed = false;
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int n_slots = 0;                // capacity of the model / transition slot tables (grows on demand)
@@ -73,17 +95,22 @@ namespace nchmm {
 
 constexpr size_t kQueueWords = 16 + 4096;
 
-// Where a forward + traceback launch pair runs and what it writes into.
-struct VitLane {
-    hipStream_t stream;
-    unsigned* last_state;   // [reads of the batch] arg-max state of the last column, forward -> traceback
-};
 void pipe_destroy(nchmm_ctx* c);
 int pipe_in_flight(const nchmm_ctx* c);
-int launch_viterbi_range(nchmm_ctx* c, const VitLane& L, size_t first, size_t count, uint64_t ev_base, uint64_t ev_count,
+// Size the back-pointer regions for launches of up to `count` reads of up to `longest` events (reallocates only when every
+// lane is idle).
+int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count);
+// Queue one launch (sweep + in-block traceback) for reads [first, first + count) on the next lane; *lane_out = that lane.
+// The launch starts after `after` (an event, may be null) and after the lane's previous launch.  viterbi_ws_prepare first.
+int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
                          const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status);
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out);
+// The stream of the lane the NEXT launch_viterbi_range will use (for kernels that must run in front of it).
+hipStream_t viterbi_next_lane_stream(nchmm_ctx* c);
+// Make `s` wait for everything queued on the lanes; then 1 if a block reported a pool failure.
+int viterbi_join(nchmm_ctx* c, hipStream_t s);
+int viterbi_check_err(nchmm_ctx* c);
 int viterbi_ws_budget(nchmm_ctx* c, size_t* out);
 void mask_weights(float p_skip, float p_stay, float wm[64]);   // nchmm_api.cpp
 

@@ -24,6 +24,13 @@ enum ModelField {
     MF_C /* log_lambda - log_2pi */
 };
 
+// Back-pointer workspace: one REGION per resident block ("slot"), not per read.  A block writes the rows of the read it is
+// sweeping into its region, walks them back itself as soon as the last column is done (in the shadow of the co-resident
+// block's sweep), and reuses the region for its next read.  Regions are handed out per XCD (XCC_ID): a region is only ever
+// touched through one L2, so a block that takes over a region sees exactly what it wrote itself.
+constexpr unsigned kXcds = 8;
+constexpr unsigned kNoSlot = 0xFFFFFFFFu;
+
 struct ViterbiArgs {
     const float* cmean;        // SoA events
     const float* stdv;
@@ -36,15 +43,18 @@ struct ViterbiArgs {
     const float* trans;        // [kMaxSlots][kTransFloats]
     const int32_t* model_fast; // [kMaxSlots] 1 = parameters inside the range the reciprocal division is proven for
     unsigned long long* prof;  // optional [4]: forward ticks, traceback ticks, block ticks, blocks (wall_clock64)
-    uint8_t* ws;               // back-pointer workspace: one kBpRowBytes row per event of the (sub-)batch
-    uint64_t ev_base;          // off[first_read]: event index of the first row of the workspace
-    unsigned first_read;       // reads [first_read, first_read + n_reads) form this (sub-)batch
-    unsigned* cu_progress;     // [4096] per (CU, block slot) events done in this launch; every block zeroes its word on exit
-    unsigned* last_state;      // [n_reads_total] arg-max state of the last column (forward -> traceback)
+    uint8_t* ws;               // back-pointer regions: region s at ws + s * slot_bytes, row i of the current read at + i * kBpRowBytes
+    uint64_t slot_bytes;       // >= kBpRowBytes * (longest read of the launch)
+    unsigned* slot_owner;      // [kXcds][slots_per_xcd] 0 = free; null: region = blockIdx.x (launches do not overlap then)
+    unsigned slots_per_xcd;
+    unsigned* host_err;        // pinned host word: set to 1 by a block that found no region (cannot happen with a sane pool)
+    unsigned first_read;       // reads [first_read, first_read + n_reads) form this launch
+    unsigned* cu_progress;     // [4096] per (CU, block slot): launch tag << 20 | events done in this launch; zeroed on exit
+    unsigned launch_tag;       // 1 .. 4095, distinguishes co-resident blocks of different launches
     uint16_t* out_state;
     float* out_logp;
     int32_t* out_status;
-    unsigned* queue;           // work-queue head: never reset -- this launch's tickets start at queue_base
+    unsigned* queue;           // work-queue head of this launch's lane: never reset -- tickets start at queue_base
     unsigned queue_base;       // value of *queue when the launch starts (host-tracked: every launch adds n_reads + grid)
     unsigned n_reads;
     int tb_margin;             // events a speculative traceback segment runs before its first owned event
@@ -53,7 +63,6 @@ struct ViterbiArgs {
 };
 
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream);
-void launch_traceback(const ViterbiArgs& a, hipStream_t stream);
 int viterbi_blocks_per_cu();
 
 constexpr int kFbTransFloats = 6 * kStates;   // forward c0|c1|c2 then backward c0b|c1b|c2b, per state, log space

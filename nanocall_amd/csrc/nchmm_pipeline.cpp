@@ -187,15 +187,11 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     K.ev_used = 0;
     hipStream_t si = c->s_in, sr = c->own_stream;
 
-    size_t budget = 0;
-    if ((rc = viterbi_ws_budget(c, &budget))) return rc;
     uint64_t longest = 1;
     for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
-    const uint64_t cap_events = std::max<uint64_t>(budget / kBpRowBytes, longest);   // a read longer than the budget still runs, alone
-    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, cap_events, &K.ranges))) return rc;
+    // (the back-pointer workspace is one region per resident block: it does not bound a range)
+    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, ~(uint64_t)0, &K.ranges))) return rc;
     const size_t n_ranges = K.ranges.size();
-    uint64_t ws_events = 1;
-    for (const PipeRange& g : K.ranges) ws_events = std::max<uint64_t>(ws_events, g.e1 - g.e0);
 
     // longest-first processing order inside each range (the device work queue hands reads out in this order)
     K.h_off.assign(off, off + n + 1);
@@ -216,14 +212,14 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
 
     // Device staging of this slot:
     //   [ small: off | mslot | tslot | order | src | drift ]    one copy from the pinned block
-    //   [ last_state | cm | sd | ls | raw mean | stdv | start ]
+    //   [ cm | sd | ls | raw mean | stdv | start ]
     //   [ logp | status | state ]                               direct form only
     // Pinned host block:  [ small (as above) | logp | status | state ]   (the outputs: streaming form only)
     const size_t n_raw = raw ? raw->n_raw : 0;
     size_t o_off = 0, o_ms = o_off + al256(8 * (n + 1)), o_ts = o_ms + al256(4 * n), o_or = o_ts + al256(4 * n);
     size_t o_src = o_or + al256(4 * n), o_dr = o_src + (raw ? al256(8 * n) : 0);
     const size_t small_bytes = std::max<size_t>(o_dr + (raw ? al256(4 * n) : 0), kMinCopy);
-    size_t o_last = small_bytes, o_cm = o_last + al256(4 * n), o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total);
+    size_t o_cm = small_bytes, o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total);
     size_t o_rm = o_ls + al256(4 * total), o_rs = o_rm + al256(4 * n_raw), o_rt = o_rs + al256(4 * n_raw);
     size_t o_lp = o_rt + al256(4 * n_raw), o_ss = o_lp + al256(4 * n), o_st = o_ss + al256(4 * n);
     const size_t out_end = direct ? o_st + al256(2 * total) : o_lp;
@@ -249,13 +245,9 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         HIP_TRY(c, hipHostMalloc(&hp, h_need + h_need / 8, hipHostMallocDefault));
         K.h = (char*)hp; K.h_bytes = h_need + h_need / 8;
     }
-    if (c->ws_bytes < (size_t)ws_events * kBpRowBytes) {
-        if (P->in_flight) HIP_TRY(c, hipStreamSynchronize(sr));       // the batch in flight is using the workspace
-        void* p = c->d_ws;
-        rc = ensure(c, &p, &c->ws_bytes, (size_t)ws_events * kBpRowBytes);
-        c->d_ws = (uint8_t*)p;
-        if (rc != NCHMM_OK) return rc;
-    }
+    size_t biggest = 1;
+    for (const PipeRange& g : K.ranges) biggest = std::max(biggest, g.r1 - g.r0);
+    if ((rc = viterbi_ws_prepare(c, longest, biggest))) return rc;   // (waits for the batch in flight if the regions must grow)
     char* const d = (char*)P->d_stage[slot];
     K.direct = direct; K.n = n; K.total = total; K.d = d;
     K.o_state = o_st; K.o_logp = o_lp; K.o_status = o_ss;
@@ -269,11 +261,12 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     int32_t* const k_status = direct ? (int32_t*)(d + o_ss) : (int32_t*)(K.h + ho_ss);
 
     // the batch starts after whatever the caller queued on the context's stream (table uploads, device-pointer calls)
-    if (c->stream != sr) {
-        hipEvent_t ev_entry;
+    // (the context's own stream is lane 0: what is on it are this context's earlier launches -- every other entry point that
+    // uses it returns synchronised -- and waiting for those is what the lanes are there to avoid)
+    hipEvent_t ev_entry = nullptr;
+    if (c->external_stream) {
         if ((rc = pipe_event(c, K, &ev_entry))) return rc;
         HIP_TRY(c, hipEventRecord(ev_entry, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(sr, ev_entry, 0));
     }
 
     std::memcpy(K.h + o_off, off, 8 * (n + 1));
@@ -344,14 +337,17 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         hipEvent_t ev_in;
         if ((rc = pipe_event(c, K, &ev_in))) return rc;
         HIP_TRY(c, hipEventRecord(ev_in, si));
-        HIP_TRY(c, hipStreamWaitEvent(sr, ev_in, 0));
+        // consecutive ranges run on alternating lanes: the blocks of range k+1 start where those of range k run out of reads
+        hipStream_t sl = viterbi_next_lane_stream(c);
+        HIP_TRY(c, hipStreamWaitEvent(sl, ev_in, 0));
+        if (ev_entry && sl != c->stream) HIP_TRY(c, hipStreamWaitEvent(sl, ev_entry, 0));
         if (tab) {
             const char* db = d + o_tb + tb_off[k];
-            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_model_fast + g.r0), 1, m, sr));   // the scale kernel clears it for an out-of-range model
+            HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_model_fast + g.r0), 1, m, sl));   // the scale kernel clears it for an out-of-range model
             launch_scale_models((const float*)(d + o_tst), (const int32_t*)db, (const float*)(db + al256(4 * m)), c->d_models, c->d_model_fast,
-                                (int)g.r0, m, static_cast<float>(std::log(2.0 * M_PI)), sr);
+                                (int)g.r0, m, static_cast<float>(std::log(2.0 * M_PI)), sl);
             HIP_TRY(c, hipGetLastError());
-            launch_expand_transitions((const float*)(db + al256(4 * m) + al256(32 * m)), c->d_masks, c->d_trans, c->d_trans_fb, (int)g.r0, m, sr);
+            launch_expand_transitions((const float*)(db + al256(4 * m) + al256(32 * m)), c->d_masks, c->d_trans, c->d_trans_fb, (int)g.r0, m, sl);
             HIP_TRY(c, hipGetLastError());
         }
         if (raw) {
@@ -360,17 +356,18 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
             ga.win_src = (const uint64_t*)(d + o_src) + g.r0; ga.off = (const uint64_t*)(d + o_off) + g.r0;
             ga.win_drift = (const float*)(d + o_dr) + g.r0;
             ga.cmean = (float*)(d + o_cm); ga.out_stdv = (float*)(d + o_sd); ga.out_lstdv = (float*)(d + o_ls);
-            launch_em_gather(ga, (unsigned)(g.r1 - g.r0), sr, (unsigned)g.max_events);
+            launch_em_gather(ga, (unsigned)(g.r1 - g.r0), sl, (unsigned)g.max_events);
             HIP_TRY(c, hipGetLastError());
         }
-        rc = launch_viterbi_range(c, VitLane{sr, (unsigned*)(d + o_last)}, g.r0, g.r1 - g.r0, g.e0, g.e1 - g.e0,
+        int lane = 0;
+        rc = launch_viterbi_range(c, nullptr, g.r0, g.r1 - g.r0, g.e1 - g.e0,
                                   (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
                                   (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
                                   trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or) + g.r0, k_state, k_logp,
-                                  k_status);
+                                  k_status, &lane);
         if (rc != NCHMM_OK) return rc;
         if ((rc = pipe_event(c, K, &K.done[k]))) return rc;
-        HIP_TRY(c, hipEventRecord(K.done[k], sr));
+        HIP_TRY(c, hipEventRecord(K.done[k], c->lane[lane].stream));
     }
     c->counters[0] += n;
     c->counters[1] += total;
@@ -415,7 +412,9 @@ int pipe_release(nchmm_ctx* c)
     if (!P || P->in_flight == 0) return NCHMM_E_INVALID;
     PipeCall& K = P->call[P->next_end];
     HIP_TRY(c, hipSetDevice(c->device));
-    hipError_t e = K.done.empty() ? hipSuccess : hipEventSynchronize(K.done.back());
+    hipError_t e = hipSuccess;
+    for (hipEvent_t d : K.done)      // (consecutive ranges sit on different lanes: the last one to be queued need not be the last to finish)
+        if (e == hipSuccess) e = hipEventSynchronize(d);
     P->next_end ^= 1u;
     P->in_flight -= 1;
     HIP_TRY(c, e);
@@ -438,6 +437,7 @@ int pipe_end(nchmm_ctx* c)
         if (K.direct) {
             // nothing is queued behind a lone batch, so the runtime's shader copies into the caller's pageable arrays start
             // at once (they hold this thread until they are done)
+            for (hipEvent_t e : K.done) HIP_TRY(c, hipStreamWaitEvent(sr, e, 0));
             HIP_TRY(c, hipMemcpyAsync(K.out_logp, K.d + K.o_logp, 4 * K.n, hipMemcpyDeviceToHost, sr));
             HIP_TRY(c, hipMemcpyAsync(K.status.data(), K.d + K.o_status, 4 * K.n, hipMemcpyDeviceToHost, sr));
             if (K.total) HIP_TRY(c, hipMemcpyAsync(K.out_state, K.d + K.o_state, 2 * K.total, hipMemcpyDeviceToHost, sr));
@@ -455,11 +455,12 @@ int pipe_end(nchmm_ctx* c)
         }
         return NCHMM_OK;
     };
-    const int rc = body();
+    int rc = body();
+    if (rc == NCHMM_OK) rc = viterbi_check_err(c);
     if (rc != NCHMM_OK) {
         // leave nothing of this batch running behind the caller's back
         (void)hipStreamSynchronize(c->s_in);
-        (void)hipStreamSynchronize(sr);
+        for (int l = 0; l < kVitLanes; ++l) (void)hipStreamSynchronize(c->lane[l].stream);
     }
     P->next_end ^= 1u;
     P->in_flight -= 1;
@@ -485,7 +486,7 @@ int check_slots(const nchmm_ctx* c, size_t n, const int32_t* model_slot, const i
 int fail_drain(nchmm_ctx* c, int rc)
 {
     if (c->s_in) (void)hipStreamSynchronize(c->s_in);
-    (void)hipStreamSynchronize(c->own_stream);
+    for (int l = 0; l < kVitLanes; ++l) (void)hipStreamSynchronize(c->lane[l].stream);
     return rc;
 }
 

@@ -30,14 +30,19 @@
 //   * Selects are written as v_cndmask_b32_e64 with an SGPR-pair mask: on gfx950 the VOP2 form
 //     reading a VCC that was not written by the immediately preceding VALU op issues ~8x slower
 //     (tools/ubench/valu_rate.hip).
-//   * Back-pointers are one byte per state (0 stay, 1+x step, 5+xy skip); row i of a read at
-//     ws + i*4096, state j at byte (t<<4) | (h<<3) | (x<<1) | (y>>1): each thread stores its 8
-//     bytes as one dwordx2 (a wave writes 512 B contiguous), and the 21 candidates of the next
-//     traceback step sit in three 16-byte groups.
-//   * Traceback is a second kernel (traceback_kernel, one wave per read, every read of the batch
-//     at once): the chase is a dependent pointer walk, so it is latency-bound and wants many reads
-//     in flight rather than CUs parked behind a barrier.  Each round trip fetches every 16-byte
-//     group that can hold the byte of rows i, i-1, i-2 (27 lanes x 16 B) and resolves three events.
+//   * Back-pointers are one byte per state (0 stay, 1+x step, 5+xy skip); row i of the read a block is
+//     sweeping at region + i*4096 (one workspace REGION per resident block, nchmm_device.h), state j at
+//     byte (t<<4) | (h<<3) | (x<<1) | (y>>1): each thread stores its 8 bytes as one dwordx2 (a wave
+//     writes 512 B contiguous), and the 21 candidates of the next traceback step sit in three 16-byte
+//     groups.
+//   * Traceback happens in the same block as soon as the last column is done (traceback_block): the
+//     chase is a dependent pointer walk bound by memory latency, so it costs the CU nothing as long as
+//     the co-resident block is in its sweep -- the two blocks of a CU are kept ~one traceback apart
+//     (kSkew) for exactly that.  Each round trip fetches every 16-byte group that can hold the byte of
+//     rows i, i-1 (, i-2) and resolves two (three) events.  Because a region is free again when its
+//     block has walked it, the workspace is (resident blocks) x (longest read), whatever the batch size,
+//     and launches on different streams roll into each other: a block of the next launch starts in the
+//     place of each block that runs out of reads.
 //
 // Float contract: -ffp-contract=off (the only FMAs are the explicit residual corrections and the
 // next-float probe), denormals on, no device log/exp: every log comes from the host libm.
@@ -54,6 +59,13 @@ namespace {
 
 typedef unsigned long long mask_t;
 constexpr unsigned kChunk = 256;   // events staged in LDS at a time
+#ifndef NCHMM_TB_PRIO
+#define NCHMM_TB_PRIO 3
+#endif
+#ifndef NCHMM_VIT_SKEW
+#define NCHMM_VIT_SKEW 384
+#endif
+constexpr unsigned kSkew = NCHMM_VIT_SKEW;   // events the upper block of a CU is kept ahead of the lower one (see viterbi_kernel)
 
 struct __attribute__((aligned(8))) ValSlot {
     float v;
@@ -404,6 +416,144 @@ __device__ __forceinline__ bool event_in_fast_range(float x, float y)
     return __builtin_fabsf(x) <= 1048576.0f && y >= 0.0078125f && y <= 1024.0f;
 }
 
+// predecessor of state j through back-pointer code `slot` (0 stay, 1+x step, 5+xy skip), branch-free
+__device__ __forceinline__ unsigned pred_of(unsigned j, unsigned slot, unsigned& shift_class)
+{
+    const unsigned sc = slot == 0 ? 0u : (slot < 5u ? 1u : 2u);
+    const unsigned hi = (slot - (sc == 1u ? 1u : 5u)) << (12u - 2u * sc);
+    shift_class = sc;
+    return sc == 0 ? j : ((hi | (j >> (2u * sc))) & 4095u);
+}
+
+// ---- traceback: Viterbi::fill_state_seq, Viterbi.hpp:134-141, by the block that has just swept the read ----
+// The chase is a dependent pointer walk bound by memory latency (~0.9 us per round trip), and while a block walks, its half of
+// the CU does nothing else (the co-resident block's sweep is bound by its own dependent chain and does not speed up), so the
+// walk has to be SHORT.  It is cut into segments of kTbSeg events walked at once, one per group of four lanes: 16 per wave,
+// 128 per block and round (10 240 events).  Only the top segment knows its start state; the others start tb_margin events
+// above their boundary from an arbitrary state and rely on Viterbi survivor paths coalescing: if the speculative walk is in
+// the same state as the walk above it at the boundary, everything below is the true path (back-pointers are a function of
+// (event, state)).  All boundaries are compared at once; if any differs (never with the default margin on sane data), wave 0
+// goes through the segments top-down and walks again, from the true state, those whose speculation had not merged -- the result
+// is exact either way.  Per round trip a group fetches the 16-byte group that holds its byte of row cur and the three that can
+// hold the byte of row cur-1 (stay / step / skip) and resolves two events.  Decoded states are collected in LDS and written
+// out once per round, contiguously.
+constexpr int kTbLanes = 4;
+constexpr int kTbSegs = kThreads / kTbLanes;   // 128 segments per round
+#ifndef NCHMM_TB_SEG
+#define NCHMM_TB_SEG 80
+#endif
+constexpr int kTbSeg = NCHMM_TB_SEG;           // events a segment owns
+
+struct __attribute__((aligned(16))) TbShared {
+    uint8_t stage[kTbSegs][kTbLanes][16];
+    uint16_t path[kTbSegs][kTbSeg];     // path[w][k] = state of event (boundary of w) - 1 - k
+    unsigned low[kTbSegs], tent[kTbSegs], bad[kTbSegs];
+};
+
+// One segment per 4-lane group (seg, q = lane within the group; every value below is the same in the four lanes of a group):
+// from state s at event `start` down to event own_lo, recording the states of events own_lo .. bnd-1 and the state met at
+// event bnd.  `on` = this group has a segment.  An unreachable cell (no predecessor: every candidate -INF/NaN) carries no
+// back-pointer (code > 20); it only counts on rows the segment owns (<= bnd).
+__device__ __forceinline__ void tb_walk(const uint8_t* ws, TbShared& T, unsigned seg, unsigned q, bool on, unsigned s, int start, int bnd,
+                                        int own_lo)
+{
+    unsigned tent = start == bnd ? s : 0xFFFFFFFFu, bad = 0;
+    int cur = on ? start : own_lo;
+    const unsigned sh = q ? 2u * (q - 1u) : 0u;
+    while (ballot(cur > own_lo) != 0) {
+        const bool go = cur > own_lo;
+        const int row = cur - (q ? 1 : 0);       // row i holds the back-pointers from event i to event i-1
+        if (go && row > own_lo)
+            *reinterpret_cast<uint4*>(&T.stage[seg][q][0]) =
+                *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + ((s >> sh) & 255u) * 16u);
+        __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
+        __builtin_amdgcn_wave_barrier();
+        if (go) {
+            unsigned sc0, sc1;
+            unsigned slot = T.stage[seg][0][bp_pos(s >> 8)];
+            bad |= (slot > 20u) & (unsigned)(cur <= bnd);
+            const unsigned s1 = pred_of(s, slot > 20u ? 0u : slot, sc0);
+            const int e1 = cur - 1;
+            if (e1 == bnd) tent = s1;
+            if (e1 < bnd && q == 0) T.path[seg][bnd - 1 - e1] = (uint16_t)s1;
+            if (e1 > own_lo) {
+                slot = T.stage[seg][1 + sc0][bp_pos(s1 >> 8)];
+                bad |= (slot > 20u) & (unsigned)(e1 <= bnd);
+                const unsigned s2 = pred_of(s1, slot > 20u ? 0u : slot, sc1);
+                const int e2 = cur - 2;
+                if (e2 == bnd) tent = s2;
+                if (e2 < bnd && q == 0) T.path[seg][bnd - 1 - e2] = (uint16_t)s2;
+                s = s2; cur -= 2;
+            } else {
+                s = s1; cur -= 1;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // stage[] is overwritten by the next round trip
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (on && q == 0) { T.low[seg] = s; T.tent[seg] = tent; T.bad[seg] = bad; }
+}
+
+__device__ __forceinline__ void traceback_block(const ViterbiArgs& P, TbShared& T, const uint8_t* ws, unsigned r, uint64_t e0, int n,
+                                                unsigned s_last)
+{
+    const unsigned tid = threadIdx.x, seg = tid / kTbLanes, q = tid % kTbLanes;
+    uint16_t* __restrict__ os = P.out_state + e0;
+    if (s_last >= (unsigned)kStates) {   // every state -INF / NaN in the last column: no path (block-uniform)
+        if (tid == 0 && P.out_status) P.out_status[r] = -6;
+        return;
+    }
+    if (tid == 0) os[n - 1] = (uint16_t)s_last;
+    int top = n - 1;                     // the state of event `top` is known: s_top
+    unsigned s_top = s_last;
+    int any_bad = 0;
+    unsigned refix = 0, spec = 0;
+    while (top > 0) {
+        const int bot = top > kTbSegs * kTbSeg ? top - kTbSegs * kTbSeg : 0;
+        const int count = top - bot;                        // events bot .. top-1 are resolved in this round
+        const int K = (count + kTbSeg - 1) / kTbSeg;        // segments (<= kTbSegs), L events each (the last may be shorter)
+        const int L = (count + K - 1) / K;
+        const bool on = (int)seg < K;
+        const int bnd = top - (int)seg * L;                 // segment `seg` owns events max(bnd - L, bot) .. bnd - 1
+        const int own_lo = on ? (bnd - L > bot ? bnd - L : bot) : 0;
+        int start = bnd + P.tb_margin;                      // speculative start event
+        if (start > top || seg == 0) start = top;
+        tb_walk(ws, T, seg, q, on, start == top ? s_top : 0u, on ? start : 0, on ? bnd : 0, own_lo);
+        __syncthreads();
+        // every boundary at once: the walk below met the state the walk above ended in
+        const bool differs = on && q == 0 && seg > 0 && T.tent[seg] != T.low[seg - 1];
+        if (__syncthreads_or(differs)) {
+            if (tid < 64) {
+                unsigned truth = s_top;
+                for (int w = 0; w < K; ++w) {
+                    const int b = top - w * L, lo = b - L > bot ? b - L : bot;
+                    if (w > 0 && T.tent[w] != truth) {      // (wave-uniform)
+                        tb_walk(ws, T, (unsigned)w, q, tid < kTbLanes, truth, b, b, lo);
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __builtin_amdgcn_wave_barrier();
+                        ++refix;
+                    }
+                    truth = T.low[w];
+                }
+            }
+            __syncthreads();
+        }
+        any_bad |= __syncthreads_or(on && q == 0 && T.bad[seg] != 0);
+        for (int idx = (int)tid; idx < count; idx += kThreads) {
+            const int w = idx / L;
+            os[top - 1 - idx] = T.path[w][idx - w * L];
+        }
+        spec += (unsigned)(K - 1);
+        s_top = T.low[K - 1];
+        top = bot;
+        __syncthreads();   // path[] / low[] are rewritten by the next round
+    }
+    if (tid == 0) {
+        if (P.out_status) P.out_status[r] = any_bad ? -6 : 0;
+        if (P.prof) { atomicAdd(&P.prof[4], (unsigned long long)refix); atomicAdd(&P.prof[5], (unsigned long long)spec); }
+    }
+}
+
 }  // namespace
 
 #ifndef NCHMM_MIN_WAVES
@@ -416,26 +566,61 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     __shared__ ValSlot sV2[2][256];    // skip-group winners
     __shared__ __attribute__((aligned(16))) float4 sEv[kChunk];     // per event: x, y, 3*log y, 1/y
     ValSlot* const sRed = &sV1[0][0];  // the final arg-max reduction reuses the exchange buffer
-    __shared__ unsigned sWork;
+    static_assert(sizeof(TbShared) <= sizeof(sTab), "the traceback's staging lives in the per-state tables (dead after the sweep)");
+    TbShared& sTb = *reinterpret_cast<TbShared*>(&sTab[0][0]);
+    __shared__ unsigned sWork, sLast;
 
     const unsigned tau = threadIdx.x;
     const unsigned t = tau >> 1, h = tau & 1u;
     unsigned long long t_fwd = 0, t_tb = 0, t_all0 = 0;
     if (P.prof) t_all0 = wall_clock64();
-    // Two blocks share a CU and the older block's waves win issue arbitration (age), which makes one
-    // block ~25 % faster than its neighbour; with two reads per block that idles half of every CU at
-    // the end.  Priority outranks age, so every 256 events each block publishes how many events it
-    // has done (one word per CU slot) and the one that is behind raises its priority.
+    // Two blocks share a CU and the older block's waves win issue arbitration (age), which lets one block run ~25 % ahead of
+    // its neighbour and idles half of the CU when the queue runs dry.  Priority outranks age, so every 256 events each block
+    // publishes how many events it has done (one word per CU slot) and the one that is behind raises its priority -- "behind"
+    // measured against a lead of kSkew events for the block in the upper wave slots: a block walks its back-pointers when its
+    // read ends (traceback_block, ~0.4 ms of memory latency and next to no issue slots), and that is free exactly when the
+    // other block of the CU is in the middle of a sweep.  Blocks of different launches (tags differ) leave it to age.
     unsigned* my_progress = nullptr;
     const unsigned* other_progress = nullptr;
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned upper = ((hw & 15u) >> 1) & 1u;   // this block sits in wave slots 2,3 of each SIMD
     {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
         const unsigned cu = ((xcc << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u)) & 2047u;
-        const unsigned upper = ((hw & 15u) >> 1) & 1u;   // this block sits in wave slots 2,3 of each SIMD
         my_progress = P.cu_progress + 2u * cu + upper;
         other_progress = P.cu_progress + 2u * cu + (upper ^ 1u);
     }
+    // ---- this block's back-pointer region ----
+    if (tau == 0) {
+        unsigned slot = kNoSlot;
+        if (!P.slot_owner) {
+            slot = blockIdx.x;
+        } else {
+            unsigned* const own = P.slot_owner + xcc * P.slots_per_xcd;
+            const unsigned first = (2u * (((hw >> 13) & 7u) * 16u + ((hw >> 8) & 15u)) + upper) % P.slots_per_xcd;
+            // a region is free whenever fewer blocks are resident on this XCD than it has regions: by construction always
+            // (the host sizes the pool past the residency limit), so the bound below only keeps a corrupted pool from
+            // hanging the device: ~1 s, then the block reports through host_err and leaves its reads to the others
+            for (unsigned spin = 0; spin < 4096u && slot == kNoSlot; ++spin) {
+                for (unsigned k = 0; k < P.slots_per_xcd; ++k) {
+                    unsigned i = first + k;
+                    if (i >= P.slots_per_xcd) i -= P.slots_per_xcd;
+                    if (atomicCAS(&own[i], 0u, 1u) == 0u) { slot = xcc * P.slots_per_xcd + i; break; }
+                }
+                if (slot == kNoSlot) for (int z = 0; z < 64; ++z) __builtin_amdgcn_s_sleep(127);
+            }
+            __threadfence();   // acquire: whatever the previous holder of the region did is behind us
+        }
+        sWork = slot;
+    }
+    __syncthreads();
+    const unsigned my_slot = sWork;
+    if (my_slot == kNoSlot) {
+        if (tau == 0 && P.host_err) { __hip_atomic_store(P.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        return;
+    }
+    uint8_t* const ws = P.ws + (uint64_t)my_slot * P.slot_bytes;
+    const unsigned tag = P.launch_tag << 20;
     unsigned done_events = 0;
 
     for (;;) {
@@ -455,7 +640,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         if (n == 0) {
             if (tau == 0) {
                 P.out_logp[r] = __builtin_nanf("");
-                P.last_state[r] = kNoState;
+                if (P.out_status) P.out_status[r] = 0;
             }
             continue;
         }
@@ -469,8 +654,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         const float* __restrict__ ex = P.cmean + e0;
         const float* __restrict__ ey = P.stdv + e0;
         const float* __restrict__ el = P.lstdv + e0;
-        // back-pointer row i of this read: one 4 KiB row per event of the batch, in event order
-        uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
+        // back-pointer row i of this read: row i of the block's region
 
         State S;
 #pragma unroll
@@ -496,9 +680,10 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         for (unsigned base = 0; base < n; base += kChunk) {
             {
                 // wave-uniform: every wave of the block reads the same two words
-                if ((tau & 63u) == 0) __hip_atomic_store(my_progress, done_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned other = __hip_atomic_load(other_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_readfirstlane(other) > done_events) __builtin_amdgcn_s_setprio(1);
+                const unsigned mine = (done_events < 0xFFFFFu - kSkew ? done_events : 0xFFFFFu - kSkew) + (upper ? 0u : kSkew);
+                if ((tau & 63u) == 0) __hip_atomic_store(my_progress, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned other = __builtin_amdgcn_readfirstlane(__hip_atomic_load(other_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((other & 0xFFF00000u) == tag && (other & 0xFFFFFu) > mine) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
                 done_events += kChunk;
             }
@@ -579,9 +764,15 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
             }
             if (tau == 0) {
                 P.out_logp[r] = m.v;                  // Viterbi::path_probability(), Viterbi.hpp:133
-                P.last_state[r] = m.s;                // kStates when every state is -INF/NaN
+                sLast = m.s;                          // kStates when every state is -INF/NaN
             }
         }
+        __syncthreads();   // sLast is there; the tables of this read are dead: the traceback's staging takes their place
+        // the walk issues a few dozen instructions per memory round trip: at top priority it loses no time to the other
+        // block's sweep (which loses nothing measurable in return)
+        __builtin_amdgcn_s_setprio(NCHMM_TB_PRIO);
+        traceback_block(P, sTb, ws, r, e0, (int)n, sLast);
+        __builtin_amdgcn_s_setprio(0);
         if (P.prof) {
             const unsigned long long c2 = wall_clock64();
             t_fwd += c1 - c0;
@@ -591,195 +782,23 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
                 atomicAdd(&P.prof[7], (unsigned long long)S.n_tie);
             }
         }
-        // the other waves wait for the traceback at the top-of-loop barrier; the workspace is reused
+        // (the top-of-loop barrier ends the traceback: the region and the exchange buffer are free for the next read)
     }
     if ((tau & 63u) == 0) __hip_atomic_store(my_progress, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the slot's word as found
+    if (tau == 0 && P.slot_owner) {
+        // (every load and store of this block to its region is complete: the loop's closing barrier waited for them)
+        __threadfence();
+        __hip_atomic_store(P.slot_owner + my_slot, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (P.prof && tau == 0) {
         atomicAdd(&P.prof[0], t_fwd);
         atomicAdd(&P.prof[1], t_tb);
         atomicAdd(&P.prof[2], wall_clock64() - t_all0);
         atomicAdd(&P.prof[3], 1ull);
         if (blockIdx.x < 2048) {
-            const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
             P.prof[8 + 2 * blockIdx.x] = t_all0;
-            P.prof[8 + 4096 + blockIdx.x] = ((unsigned long long)xcc << 32) | hwid;
+            P.prof[8 + 4096 + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
             P.prof[9 + 2 * blockIdx.x] = wall_clock64();
-        }
-    }
-}
-
-// branch-free pred_of for the (wave-uniform) chase
-__device__ __forceinline__ unsigned pred_uniform(unsigned j, unsigned slot, unsigned& shift_class)
-{
-    const unsigned sc = slot == 0 ? 0u : (slot < 5u ? 1u : 2u);
-    const unsigned hi = (slot - (sc == 1u ? 1u : 5u)) << (12u - 2u * sc);
-    shift_class = sc;
-    return sc == 0 ? j : ((hi | (j >> (2u * sc))) & 4095u);
-}
-
-constexpr int kTbWaves = 8;      // traceback segments per read (one wave each)
-
-// One wave follows the back-pointers from (event ev_hi, state s) down to event ev_lo, writing
-// out_state[e] for ev_lo <= e <= min(ev_hi - 1, ev_write_hi) (the start event itself is the caller's).
-// Per round trip it fetches every 16-byte group that can hold the byte it will need in rows cur,
-// cur-1 (1 + 3 groups; LEVELS == 2) and cur-2 (+ 23 groups; LEVELS == 3) and resolves two or three
-// events from LDS.  Three levels minimise round trips (one read per wave: latency-bound); two levels
-// fetch 4.5x fewer sectors per event, which is what matters once 8 waves per read make the
-// traceback bandwidth-bound (every 16-byte group costs a whole 64-byte sector).  Decoded states
-// are collected in LDS and written 192 at a time so that no store sits in front of the next loads.
-// Returns the state at ev_lo; *mark_state receives the state at event `mark` if the walk passes it.
-template <int LEVELS>
-__device__ __forceinline__ unsigned chase(const uint8_t* ws, uint16_t* os, unsigned s, int ev_hi, int ev_lo, int ev_write_hi,
-                                          int mark, unsigned* mark_state, unsigned lane, uint8_t (*sStage)[16],
-                                          uint16_t* sOut, unsigned& bad, int bad_hi)
-{
-    unsigned rowoff, sh, msk, hi;
-    if (lane == 0) { rowoff = 0; sh = 0; msk = 255; hi = 0; }
-    else if (lane < 4) { rowoff = 1; sh = 2 * (lane - 1); msk = 255; hi = 0; }
-    else if (lane < 7) { rowoff = 2; sh = 2 * (lane - 4); msk = 255; hi = 0; }
-    else if (lane < 11) { rowoff = 2; sh = 6; msk = 63; hi = (lane - 7) << 6; }
-    else { rowoff = 2; sh = 8; msk = 15; hi = ((lane - 11) & 15u) << 4; }
-    const bool lane_on = lane < (LEVELS == 3 ? 27u : 4u);
-    int cur = ev_hi;                 // row cur holds the back-pointer from event cur to event cur-1
-    int pending_top = cur - 1;       // event index of sOut[0]
-    unsigned n_pending = 0;
-    while (cur > ev_lo) {
-        const int row = cur - (int)rowoff;
-        const unsigned grp = hi | ((s >> sh) & msk);
-        if (lane_on && row > ev_lo)
-            *reinterpret_cast<uint4*>(&sStage[lane][0]) =
-                *reinterpret_cast<const uint4*>(ws + (uint64_t)row * kStates + grp * 16u);
-        __builtin_amdgcn_s_waitcnt(0);   // the loads above (nothing else is outstanding) and the LDS stores
-        __builtin_amdgcn_wave_barrier();
-        unsigned sc0, sc1, sc2;
-        // an unreachable cell (no predecessor: every candidate -INF/NaN) carries no back-pointer.  It only counts when the
-        // walk is known to be on the true path: rows above bad_hi belong to the speculative run-in of a segment.
-        unsigned slot = sStage[0][bp_pos(s >> 8)];
-        bad |= (slot > 20u) & (unsigned)(cur <= bad_hi);
-        s = pred_uniform(s, slot > 20u ? 0u : slot, sc0);
-        const unsigned s_a = s;
-        unsigned s_b = s, s_c = s;
-        int done = 1;
-        if (cur - 1 > ev_lo) {
-            slot = sStage[1 + sc0][bp_pos(s >> 8)];
-            bad |= (slot > 20u) & (unsigned)(cur - 1 <= bad_hi);
-            s = pred_uniform(s, slot > 20u ? 0u : slot, sc1);
-            s_b = s; done = 2;
-            if (LEVELS == 3 && cur - 2 > ev_lo) {
-                const unsigned tot = sc0 + sc1;
-                const unsigned ln = tot <= 2 ? 4u + tot : (tot == 3 ? 7u + ((s >> 6) & 3u) : 11u + ((s >> 4) & 15u));
-                slot = sStage[ln][bp_pos(s >> 8)];
-                bad |= (slot > 20u) & (unsigned)(cur - 2 <= bad_hi);
-                s = pred_uniform(s, slot > 20u ? 0u : slot, sc2);
-                s_c = s; done = 3;
-            }
-        }
-        if (mark_state) {
-            if (cur - 1 == mark) *mark_state = s_a;
-            if (done > 1 && cur - 2 == mark) *mark_state = s_b;
-            if (done > 2 && cur - 3 == mark) *mark_state = s_c;
-        }
-        if (lane == 0) {
-            sOut[n_pending] = (uint16_t)s_a;
-            if (done > 1) sOut[n_pending + 1] = (uint16_t)s_b;
-            if (done > 2) sOut[n_pending + 2] = (uint16_t)s_c;
-        }
-        n_pending += (unsigned)done;
-        cur -= done;
-        if (n_pending + 3 > 192u || cur <= ev_lo) {
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            // sOut[k] is the state of event pending_top - k
-            for (unsigned k = lane; k < n_pending; k += 64) {
-                const int e = pending_top - (int)k;
-                if (e <= ev_write_hi) os[e] = sOut[k];
-            }
-            pending_top -= (int)n_pending;
-            n_pending = 0;
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    return s;
-}
-
-// Viterbi::fill_state_seq, Viterbi.hpp:134-141.  The chase is a dependent pointer walk bound by
-// HBM latency (~1 us per three events), so a read is cut into up to 8 segments walked by 8 waves
-// at once.  Only the top segment knows its start state; the others start tb_margin (128 by default) events above
-// their segment from an arbitrary state and rely on Viterbi survivor paths coalescing: if the
-// speculative walk is in the same state as the true path at the first event it owns, everything
-// below is the true path (back-pointers are a function of (event, state)).  Wave 0 checks each
-// boundary top-down and re-walks a segment from the true state when its speculation had not merged,
-// so the result is exact either way.
-__global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t sStage[kTbWaves][32][16];
-    __shared__ uint16_t sOut[kTbWaves][192];
-    __shared__ unsigned sLow[kTbWaves + 1], sTent[kTbWaves], sBad[kTbWaves];
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const unsigned r = P.first_read + blockIdx.x;
-    const uint64_t e0 = P.off[r];
-    const int n = (int)(P.off[r + 1] - e0);
-    if (n == 0) {
-        if (threadIdx.x == 0 && P.out_status) P.out_status[r] = 0;
-        return;
-    }
-    const uint8_t* const ws = P.ws + (e0 - P.ev_base) * (uint64_t)kStates;
-    uint16_t* __restrict__ os = P.out_state + e0;
-    const unsigned s_last = P.last_state[r];
-    if (s_last >= (unsigned)kStates) {
-        if (threadIdx.x == 0 && P.out_status) P.out_status[r] = -6;
-        return;
-    }
-    int K = n / 512;
-    K = K < 1 ? 1 : (K > kTbWaves ? kTbWaves : K);
-    const int L = (n + K - 1) / K;                 // segment w owns events [w*L, min((w+1)*L, n) - 1]
-    unsigned bad = 0;
-    if ((int)wave < K) {
-        const int lo = (int)wave * L;
-        if ((int)wave == K - 1) {
-            if (lane == 0) os[n - 1] = (uint16_t)s_last;
-            const unsigned s_lo = K == 1 ? chase<3>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad, n)
-                                         : chase<2>(ws, os, s_last, n - 1, lo, n - 1, -1, nullptr, lane, sStage[wave], sOut[wave], bad, n);
-            if (lane == 0) sLow[wave] = s_lo;
-        } else {
-            const int own_hi = lo + L - 1;             // highest event this segment owns
-            int start = own_hi + 1 + P.tb_margin;      // speculative start event
-            if (start > n - 1) start = n - 1;
-            unsigned tent = 0xFFFFFFFFu;
-            // the state at event own_hi+1 is the first one compared with the segment above
-            // `bad` of this walk is only meaningful from the boundary row down, and only if the walk turns out to have
-            // merged with the true path there (wave 0 decides; otherwise the segment is walked again)
-            const unsigned s_lo = chase<2>(ws, os, 0u, start, lo, own_hi, own_hi + 1, &tent, lane, sStage[wave], sOut[wave], bad,
-                                           own_hi + 1);
-            if (start == own_hi + 1) tent = 0u;        // no margin left: the guess itself sits on the boundary
-            if (lane == 0) { sLow[wave] = s_lo; sTent[wave] = tent; }
-        }
-    }
-    if (lane == 0) sBad[wave] = bad;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned any_bad = sBad[K - 1];                // the top segment starts from the true last state
-        unsigned refix = 0;
-        for (int w = K - 2; w >= 0; --w) {
-            const unsigned truth = sLow[w + 1];        // true state at event (w+1)*L
-            if (sTent[w] == truth) {
-                any_bad |= sBad[w];                    // merged: what it walked from the boundary down was the true path
-            } else {
-                // speculation had not merged: walk this segment again from the true state
-                unsigned b2 = 0;
-                const unsigned s_lo = chase<3>(ws, os, truth, (w + 1) * L, w * L, (w + 1) * L - 1, -1, nullptr, lane, sStage[0],
-                                            sOut[0], b2, n);
-                any_bad |= b2;
-                if (lane == 0) sLow[w] = s_lo;
-                __builtin_amdgcn_s_waitcnt(0);
-                __builtin_amdgcn_wave_barrier();
-                ++refix;
-            }
-        }
-        if (lane == 0) {
-            if (P.out_status) P.out_status[r] = any_bad ? -6 : 0;
-            if (P.prof) { atomicAdd(&P.prof[4], (unsigned long long)refix); atomicAdd(&P.prof[5], (unsigned long long)(K - 1)); }
         }
     }
 }
@@ -787,11 +806,6 @@ __global__ __launch_bounds__(64 * kTbWaves) void traceback_kernel(ViterbiArgs P)
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(viterbi_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
-}
-
-void launch_traceback(const ViterbiArgs& a, hipStream_t stream)
-{
-    hipLaunchKernelGGL(traceback_kernel, dim3(a.n_reads), dim3(64 * kTbWaves), 0, stream, a);
 }
 
 int viterbi_blocks_per_cu()

@@ -117,12 +117,14 @@ def test_no_data_hazards_in_any_kernel(asm):
 def test_the_lint_catches_a_lane_swap_that_lost_its_wait_states(asm):
     """Commit 4e99858 wrote `s_nop 1` into the lane-swap asm because the distance between the asm select that produces its input
     and the DPP read had been kept only by what the compiler happened to schedule in between (the kernel BEFORE that commit also
-    lints clean: the luck had held).  Take the wait states out of today's assembly -- the compiler scheduling nothing there --
-    and the lint must object; likewise for the permlane swaps of the forward-backward reductions."""
-    vit = re.sub(r"\ts_nop 1\n(\tv_mov_b32_dpp [^\n]*quad_perm)", r"\1", asm["viterbi_kernel"])
-    assert vit != asm["viterbi_kernel"]
+    lints clean: the luck had held -- and whether it holds depends on the build, so the test does not lean on it).  Put the
+    producer where the compiler would be free to put it -- a VALU write of the swapped register directly in front of a lane swap
+    whose s_nop is gone -- and the lint must object; likewise for the permlane swaps of the forward-backward reductions."""
+    m = re.search(r"\ts_nop 1\n\t(v_mov_b32_dpp v\d+, (v\d+) [^\n]*quad_perm[^\n]*)", asm["viterbi_kernel"])
+    assert m, "no lane swap with its wait states in the Viterbi kernel?"
+    vit = asm["viterbi_kernel"].replace(m.group(0), f"\tv_add_f32_e32 {m.group(2)}, {m.group(2)}, {m.group(2)}\n\t{m.group(1)}", 1)
     bad, _ = isa_lint.lint(vit)
-    assert any(b[1] == "R1" and "quad_perm" in b[4] for b in bad), "removing the s_nop in front of the lane swap went unnoticed"
+    assert any(b[1] == "R1" and "quad_perm" in b[4] for b in bad), "a lane swap that lost its wait states went unnoticed"
     fb = asm["fwbw_scaled_kernel"]
     m = re.search(r"\t(v_\w+ (v\d+), [^\n]*)\n((?:\t[^\n]*\n){0,6}?)\t(v_permlane(?:16|32)_swap_b32 [^\n]*)", fb)
     assert m, "no v_permlane*_swap in the forward-backward kernels?"

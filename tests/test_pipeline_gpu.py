@@ -1,5 +1,6 @@
-"""The host-pointer pipeline (nchmm_pipeline.cpp): a batch cut into read ranges over a copy-in stream, two compute lanes and
-a copy-out stream must decode exactly what one launch decodes -- i.e. what the oracle decodes (Viterbi.hpp:44-142)."""
+"""The host-pointer pipeline (nchmm_pipeline.cpp): a batch cut into read ranges over a copy-in stream and two compute lanes
+(consecutive ranges overlap: the blocks of one start where the blocks of the other run out of reads) must decode exactly
+what one launch decodes -- i.e. what the oracle decodes (Viterbi.hpp:44-142)."""
 import os
 import subprocess
 import sys
@@ -25,7 +26,7 @@ off, mean, stdv, start, cm, sd, ls = ragged_batch(t, lens, first_read=21)
 with na.Context(0) as ctx:
     ctx.put_model(0, na.scaled_model_table(t, IDENT)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
     st, lp, status = ctx.viterbi(off, cm, sd, ls)
-    launches = int(ctx.counters()[3]) // 2
+    launches = int(ctx.counters()[3])
     src = off[:-1].astype(np.uint64); ln = np.diff(off.astype(np.int64)).astype(np.uint32)
     st2, lp2, status2 = ctx.viterbi_raw(mean, stdv, start, src, ln, np.zeros(len(lens), np.float32))
 ost, olp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
@@ -78,3 +79,36 @@ def test_two_batches_in_flight_equal_one_call_each(gpu_ctx, r73t):
     # and the context still serves the one-call form
     st, lp, status = gpu_ctx.viterbi(batches[0][0], *batches[0][4:])
     assert np.array_equal(st, r0[0])
+
+
+def test_overlapping_device_launches_match_the_oracle(r73t):
+    """nchmm_viterbi_dev_enqueue x 5 on the two lanes, then one join: the launches roll into each other (blocks of launch k+1
+    start where blocks of launch k run out of reads, taking over their back-pointer regions), each into its own outputs.
+    Every batch must decode what the oracle decodes; the regions are sized by the first (longest) batch and reused."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = na.Context(0)
+    try:
+        ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        specs = [([700, 40, 300, 129, 511], 3), ([64, 0, 257, 90], 11), ([400] * 6, 17), ([1, 2, 3, 600], 29), ([513, 128, 33], 41)]
+        jobs = []
+        for lens, fr in specs:
+            off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=fr)
+            d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (off.astype(np.int64), cm, sd, ls)]
+            outs = (torch.empty(int(off[-1]), dtype=torch.int16, device=dev), torch.full((len(lens),), 7.0, dtype=torch.float32, device=dev),
+                    torch.full((len(lens),), 99, dtype=torch.int32, device=dev))
+            jobs.append((lens, off, cm, sd, ls, d, outs))
+        torch.cuda.synchronize()
+        for lens, off, cm, sd, ls, d, outs in jobs:
+            ctx.viterbi_dev_enqueue(len(lens), max(lens), int(off[-1]), *d, *outs)
+        ctx.viterbi_dev_join()
+        got = [(o[0].cpu().numpy().view(np.uint16), o[1].cpu().numpy(), o[2].cpu().numpy()) for *_, o in jobs]   # (torch's stream: after the join)
+        ctx.synchronize()
+        for (lens, off, cm, sd, ls, d, outs), (st, lp, status) in zip(jobs, got):
+            ost, olp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+            nz = np.asarray(lens) > 0
+            assert np.array_equal(st, ost) and lp[nz].tobytes() == olp[nz].tobytes() and np.isnan(lp[~nz]).all() and (status == 0).all()
+    finally:
+        ctx.close()

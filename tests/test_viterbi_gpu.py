@@ -185,10 +185,12 @@ def test_out_of_range_model_takes_true_division_path(gpu_ctx, r73t):
     assert_bits_equal(logp, ologp, "path probability")
 
 
-def test_workspace_split_into_sub_batches(r73t):
-    """With a tiny workspace budget a call is cut into several forward+traceback launches."""
+def test_tiny_workspace_budget_runs_on_one_region(r73t):
+    """With a workspace budget smaller than one region per resident block the launch runs on as many blocks as the budget has
+    regions for -- here one (16 MB against 49 MB for the longest read: a read longer than the budget still runs) -- which
+    sweeps and walks back the reads one after the other through the same region."""
     import os
-    os.environ["NCHMM_WS_BUDGET_MB"] = "16"       # 4 096 events per launch, or one read if longer (read at the first Viterbi call)
+    os.environ["NCHMM_WS_BUDGET_MB"] = "16"
     lens = [9000, 5000, 7000, 3, 12000, 800]
     off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=40)
     try:
@@ -198,7 +200,8 @@ def test_workspace_split_into_sub_batches(r73t):
         states, logp, status = ctx.viterbi(off, cm, sd, ls)
     finally:
         del os.environ["NCHMM_WS_BUDGET_MB"]
-    assert ctx.counters()[3] >= 6                   # at least three (forward, traceback) pairs
+    assert ctx.counters()[3] == 1 and (status == 0).all()
+    assert ctx.mem_stats()[1] < (96 << 20), ctx.mem_stats()        # one 49 MB region + tables and staging
     ctx.close()
     for r in (0, 3, 4, 5):
         a, b = int(off[r]), int(off[r + 1])
