@@ -6,18 +6,20 @@
   N = 1 : BASELINE config 2 -- 1024 synthetic reads x 5 000 events, template-only, builtin r73.t model.
   N > 1 : BASELINE config 4, sharded -- 12 500 reads x 5 000 events PER GPU (100 000 reads over 8 GPUs), one
           rank per GPU, reads assigned by nanocall_amd.shard.lpt_partition, no collective on the data path;
-          one all-reduce (RCCL) gathers the counters and the max-over-ranks time.  The 256 GB of back-pointers
-          per shard exceed the workspace budget, so a step is several forward+traceback launches.
+          one all-reduce (RCCL) gathers the counters and the max-over-ranks time.  A shard is ONE launch: the
+          back-pointer workspace is one region per resident thread block (12 GB), not one row per event (256 GB).
           When the script is started directly (no RANK in the environment) it launches its N ranks itself
           (python -m torch.distributed.run) BEFORE touching the GPU, and fails if fewer than N GPUs are visible.
   --scaling strong : BASELINE config 4 AS WRITTEN at every N -- the same 100 000 reads x 5 000 events split N ways by
-          lpt_partition (N = 1 decodes all 100 000 on one GPU, sub-batched through the back-pointer workspace), so that
+          lpt_partition (N = 1 decodes all 100 000 on one GPU), so that
           value(N) / value(1) is the strong-scaling curve north_star asks for ("scaling": "strong").  --reads then
           means the GLOBAL read count.  The default stays weak (per-GPU work fixed), which is what the driver's
           N = 1 / 2 / 4 / 8 runs without extra flags measure.
 
 A "step" is one full pass of the hot path over the batch: forward sweep + back-pointer streaming + traceback
-for every read, inputs already resident in HBM.  Rank 0 prints ONE JSON line; at N = 1 it also carries
+for every read, inputs already resident in HBM.  Consecutive steps are queued on the context's three lanes
+(nchmm_viterbi_dev_enqueue) and joined once: the thread blocks of step k+1 start where those of step k run out of
+reads (--serial-launches: every step behind the previous one, for profiling).  Rank 0 prints ONE JSON line; at N = 1 it also carries
 `cpu_baseline` (the oracle timed on the host cores, GPU output checked bit for bit against it) and `fwbw`
 (the forward-backward / EM-statistics kernels on the config-3 window shape).
 """

@@ -254,7 +254,7 @@ int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t 
  * one strand per pfor thread, nanocall.cpp:611-621; a GPU is kept busy by letting the thread blocks of the next batch
  * start where those of the previous one run out of reads).
  *   enqueue  queues the batch behind whatever is on the context's stream NOW, on one of the context's internal
- *            streams (two, taken in turn), and returns.  The batch may run beside the batch enqueued before it.
+ *            streams (three, taken in turn), and returns.  The batch may run beside the batch enqueued before it.
  *   join     makes the context's stream wait for every batch enqueued so far: what is queued on that stream
  *            afterwards sees their outputs.  (nchmm_synchronize joins, waits, and reports.)
  * Between enqueue and join the caller leaves the batch's inputs and outputs alone, and must not hand the same output
@@ -282,17 +282,19 @@ int nchmm_viterbi_raw(nchmm_ctx* ctx, size_t n_raw_events, const float* mean, co
 /* The two host-pointer forms above, split for callers that stream batches (the reference hides the latency of a strand
  * behind its pfor worker threads, nanocall.cpp:611-621; here the unit is a batch and the latencies are the PCIe copies and
  * the tail of a launch, when its blocks run out of reads one by one).  A batch is cut into read ranges: range k+1 is
- * copied in while range k computes, on a copy-in stream and two compute lanes taken in turn, results written
+ * copied in while range k computes, on a copy-in stream and three compute lanes taken in turn, results written
  * by the kernels straight into pinned host memory -- the one-call forms are begin followed by end.
  *   begin  validates, stages and enqueues copy-in + kernels of a batch, and returns (it holds the thread for the
- *          duration of the H2D copies only).  At most TWO batches may be in flight per context (NCHMM_E_INVALID beyond).
+ *          duration of the H2D copies only).  At most THREE batches may be in flight per context (one per compute lane; NCHMM_E_INVALID beyond).
  *   end    completes the OLDEST batch in flight: copies its states out range by range as they finish, waits, fills
  *          out_path_logp / out_status, returns 0 or NCHMM_E_NUMERIC as the one-call form does.
  * Every array passed to begin -- inputs and outputs -- must stay valid and untouched until the matching end has
  * returned, and the model / transition slots the batch names must not be rewritten before that.  While a batch is in
  * flight nchmm_viterbi, nchmm_viterbi_raw and nchmm_viterbi_dev return NCHMM_E_INVALID.
  * begin(0); begin(1); end(0); begin(2); end(1); ... keeps the GPU busy: batch k+1 goes up and starts while batch k
- * computes, batch k comes down under the kernels of batch k+1. */
+ * computes, batch k comes down under the kernels of batch k+1.  With reads of very different lengths keep three going
+ * (begin(0); begin(1); begin(2); end(0); begin(3); ...): a launch lasts as long as its longest read, and the long reads of
+ * two batches then finish behind the bulk of the third. */
 int nchmm_viterbi_begin(nchmm_ctx* ctx, size_t n_reads, const uint64_t* off, const float* corrected_mean,
                         const float* stdv, const float* log_stdv, const int32_t* model_slot,
                         const int32_t* trans_slot, uint16_t* out_state, float* out_path_logp, int32_t* out_status);
@@ -301,7 +303,7 @@ int nchmm_viterbi_raw_begin(nchmm_ctx* ctx, size_t n_raw_events, const float* me
                             const int32_t* model_slot, const int32_t* trans_slot, uint16_t* out_state,
                             float* out_path_logp, int32_t* out_status);
 int nchmm_viterbi_end(nchmm_ctx* ctx);
-/* batches begun and not yet ended (0, 1 or 2) */
+/* batches begun and not yet ended (0 .. 3) */
 int nchmm_viterbi_in_flight(const nchmm_ctx* ctx);
 
 /* logf on the device, bit-identical to glibc 2.35 logf as x86-64 CPUs with FMA run it: out[i] = log(in[i]), host

@@ -327,7 +327,7 @@ class Context:
         return states, logp, status
 
     def viterbi_begin(self, off, cmean, stdv, log_stdv, model_slot=None, trans_slot=None, out=None):
-        """nchmm_viterbi_begin: enqueue one batch (copy-in + kernels) and return a ticket; at most two may be in flight.
+        """nchmm_viterbi_begin: enqueue one batch (copy-in + kernels) and return a ticket; at most three may be in flight.
         `out` = (states, logp, status) arrays to reuse (a streaming caller recycles them: fresh pages cost a fault each).
         The ticket keeps every array alive until viterbi_end."""
         off = np.ascontiguousarray(off, np.uint64)

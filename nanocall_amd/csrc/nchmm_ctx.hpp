@@ -17,9 +17,17 @@ struct PipeState;
 }
 
 namespace nchmm {
-// A compute lane of the Viterbi path: consecutive launches go to alternating lanes so that the blocks of one launch start in
-// the places the previous launch's blocks vacate (viterbi_kernel.hip).  Lane 0 runs on the context's own stream.
-constexpr int kVitLanes = 2;
+// A compute lane of the Viterbi path: consecutive launches go to the lanes in turn so that the blocks of one launch start in
+// the places the previous launches' blocks vacate (viterbi_kernel.hip).  Lane 0 runs on the context's own stream.  Three: a
+// launch lasts as long as its longest read (a read is sequential), on log-normally long reads 2.5 x as long as its share of
+// the work -- with three in turn the stragglers of two launches hide behind the bulk of the third (same box, 1024 ragged
+// reads per batch: 220 Mevents/s on two lanes, 301 on three).  Four lanes + the copy-in stream + the caller's are more
+// streams than the runtime has hardware queues for (4): streams then share a queue and wait for each other (267; config 2
+// drops from 343 to 324) -- profiles/r04_lanes_ab.txt.
+#ifndef NCHMM_VIT_LANES
+#define NCHMM_VIT_LANES 3
+#endif
+constexpr int kVitLanes = NCHMM_VIT_LANES;
 struct VitLaneState {
     hipStream_t stream = nullptr;
     unsigned vq_base = 0;            // what this lane's queue head will read when its next launch starts (never reset)
@@ -53,8 +61,8 @@ struct nchmm_ctx {
     int32_t* d_model_fast = nullptr; // [kMaxSlots]
     unsigned long long* d_prof = nullptr; // [4] phase counters when NCHMM_PROFILE=1
     bool profile = false;
-    int tb_margin = 128;            // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path); profiles/r03_tb_margin.txt:
-                                    // 0 of 86 016 speculative segments un-merged at 64, 384 at 32 -- and a miss only costs a re-walk
+    int tb_margin = 64;             // NCHMM_TB_MARGIN overrides (test hook: 0 forces the re-walk path); profiles/r04_inblock_tb_params_ab.txt:
+                                    // 0 of 698 368 speculative segments un-merged at 128, 11 at 64, 3 190 at 32 -- and a miss only costs a re-walk
     uint8_t* d_ws = nullptr;        // viterbi back-pointer workspace: ws_regions regions of slot_bytes (4 KiB per event of the
     size_t ws_bytes = 0;            // longest read), one per resident block
     size_t slot_bytes = 0;

@@ -1,5 +1,5 @@
 // nchmm_pipeline.cpp -- the host-pointer Viterbi entry points (nchmm_viterbi, nchmm_viterbi_raw, and their
-// begin / end halves): copy-in on one stream, kernels on another, two batches in flight.
+// begin / end halves): copy-in on one stream, kernels on three compute lanes taken in turn, up to three batches in flight.
 //
 // The reference's caller hands over one strand at a time and hides every latency behind pfor worker threads
 // (nanocall.cpp:611-621, 645-690).  Here a call carries a batch of reads and the latencies to hide are the PCIe copies
@@ -49,6 +49,8 @@ struct PipeRange {
     size_t max_events;
 };
 
+constexpr int kPipeDepth = kVitLanes;   // batches in flight: one per compute lane
+
 // One batch in flight.
 struct PipeCall {
     bool direct = false;              // one-call form: outputs in device memory, copied straight into the caller's arrays
@@ -71,16 +73,16 @@ struct PipeCall {
 };
 
 struct PipeState {
-    PipeCall call[2];
-    void* d_stage[2] = {nullptr, nullptr};
-    size_t stage_bytes[2] = {0, 0};
+    PipeCall call[kPipeDepth];
+    void* d_stage[kPipeDepth] = {};
+    size_t stage_bytes[kPipeDepth] = {};
     unsigned next_begin = 0, next_end = 0, in_flight = 0;
 };
 
 void pipe_destroy(nchmm_ctx* c)
 {
     if (!c->pipe) return;
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kPipeDepth; ++s) {
         if (c->pipe->d_stage[s]) (void)hipFree(c->pipe->d_stage[s]);
         if (c->pipe->call[s].h) (void)hipHostFree(c->pipe->call[s].h);
         for (hipEvent_t e : c->pipe->call[s].ev) (void)hipEventDestroy(e);
@@ -181,11 +183,11 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     int rc = pipe_init(c);
     if (rc != NCHMM_OK) return rc;
     PipeState* P = c->pipe;
-    if (P->in_flight >= 2 || (tab && P->in_flight)) return NCHMM_E_INVALID;   // (a batch with tables rewrites slots 0 .. n-1)
+    if (P->in_flight >= (unsigned)kPipeDepth || (tab && P->in_flight)) return NCHMM_E_INVALID;   // (a batch with tables rewrites slots 0 .. n-1)
     const unsigned slot = P->next_begin;
     PipeCall& K = P->call[slot];
     K.ev_used = 0;
-    hipStream_t si = c->s_in, sr = c->own_stream;
+    hipStream_t si = c->s_in;
 
     uint64_t longest = 1;
     for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
@@ -371,7 +373,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     }
     c->counters[0] += n;
     c->counters[1] += total;
-    P->next_begin ^= 1u;
+    P->next_begin = (P->next_begin + 1u) % (unsigned)kPipeDepth;
     P->in_flight += 1;
     return NCHMM_OK;
 }
@@ -415,7 +417,7 @@ int pipe_release(nchmm_ctx* c)
     hipError_t e = hipSuccess;
     for (hipEvent_t d : K.done)      // (consecutive ranges sit on different lanes: the last one to be queued need not be the last to finish)
         if (e == hipSuccess) e = hipEventSynchronize(d);
-    P->next_end ^= 1u;
+    P->next_end = (P->next_end + 1u) % (unsigned)kPipeDepth;
     P->in_flight -= 1;
     HIP_TRY(c, e);
     return NCHMM_OK;
@@ -462,7 +464,7 @@ int pipe_end(nchmm_ctx* c)
         (void)hipStreamSynchronize(c->s_in);
         for (int l = 0; l < kVitLanes; ++l) (void)hipStreamSynchronize(c->lane[l].stream);
     }
-    P->next_end ^= 1u;
+    P->next_end = (P->next_end + 1u) % (unsigned)kPipeDepth;
     P->in_flight -= 1;
     if (rc != NCHMM_OK) return rc;
     int worst = NCHMM_OK;

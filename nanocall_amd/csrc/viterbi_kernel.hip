@@ -36,13 +36,13 @@
 //     writes 512 B contiguous), and the 21 candidates of the next traceback step sit in three 16-byte
 //     groups.
 //   * Traceback happens in the same block as soon as the last column is done (traceback_block): the
-//     chase is a dependent pointer walk bound by memory latency, so it costs the CU nothing as long as
-//     the co-resident block is in its sweep -- the two blocks of a CU are kept ~one traceback apart
-//     (kSkew) for exactly that.  Each round trip fetches every 16-byte group that can hold the byte of
-//     rows i, i-1 (, i-2) and resolves two (three) events.  Because a region is free again when its
-//     block has walked it, the workspace is (resident blocks) x (longest read), whatever the batch size,
-//     and launches on different streams roll into each other: a block of the next launch starts in the
-//     place of each block that runs out of reads.
+//     chase is a dependent pointer walk bound by memory latency, and it idles the block's half of the CU
+//     (the co-resident block's sweep is bound by its own dependent chain: alone on a CU it runs 7 % faster,
+//     not twice as fast), so it is cut into 128 segments walked at once by 4-lane groups: ~0.09 ms per
+//     5000-event read against 15 ms of sweep per block.  Because a region is free again when its block has
+//     walked it, the workspace is (resident blocks) x (longest read), whatever the batch size, and launches
+//     on different streams roll into each other: a block of the next launch starts in the place of each
+//     block that runs out of reads.
 //
 // Float contract: -ffp-contract=off (the only FMAs are the explicit residual corrections and the
 // next-float probe), denormals on, no device log/exp: every log comes from the host libm.
@@ -62,10 +62,6 @@ constexpr unsigned kChunk = 256;   // events staged in LDS at a time
 #ifndef NCHMM_TB_PRIO
 #define NCHMM_TB_PRIO 3
 #endif
-#ifndef NCHMM_VIT_SKEW
-#define NCHMM_VIT_SKEW 384
-#endif
-constexpr unsigned kSkew = NCHMM_VIT_SKEW;   // events the upper block of a CU is kept ahead of the lower one (see viterbi_kernel)
 
 struct __attribute__((aligned(8))) ValSlot {
     float v;
@@ -576,10 +572,8 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     if (P.prof) t_all0 = wall_clock64();
     // Two blocks share a CU and the older block's waves win issue arbitration (age), which lets one block run ~25 % ahead of
     // its neighbour and idles half of the CU when the queue runs dry.  Priority outranks age, so every 256 events each block
-    // publishes how many events it has done (one word per CU slot) and the one that is behind raises its priority -- "behind"
-    // measured against a lead of kSkew events for the block in the upper wave slots: a block walks its back-pointers when its
-    // read ends (traceback_block, ~0.4 ms of memory latency and next to no issue slots), and that is free exactly when the
-    // other block of the CU is in the middle of a sweep.  Blocks of different launches (tags differ) leave it to age.
+    // publishes how many events it has done in this launch (one word per CU slot) and the one that is behind raises its
+    // priority.  Blocks of different launches (tags differ) leave it to age: the older launch finishes first.
     unsigned* my_progress = nullptr;
     const unsigned* other_progress = nullptr;
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
@@ -680,7 +674,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         for (unsigned base = 0; base < n; base += kChunk) {
             {
                 // wave-uniform: every wave of the block reads the same two words
-                const unsigned mine = (done_events < 0xFFFFFu - kSkew ? done_events : 0xFFFFFu - kSkew) + (upper ? 0u : kSkew);
+                const unsigned mine = done_events < 0xFFFFFu ? done_events : 0xFFFFFu;
                 if ((tau & 63u) == 0) __hip_atomic_store(my_progress, tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned other = __builtin_amdgcn_readfirstlane(__hip_atomic_load(other_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if ((other & 0xFFF00000u) == tag && (other & 0xFFFFFu) > mine) __builtin_amdgcn_s_setprio(1);

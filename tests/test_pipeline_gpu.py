@@ -50,39 +50,42 @@ def test_forced_ranges_match_the_oracle(reads_per_range):
     assert out["states_equal"] and out["logp_equal"] and out["status_ok"] and out["raw_equal"] and out["empty_nan"], out
 
 
-def test_two_batches_in_flight_equal_one_call_each(gpu_ctx, r73t):
-    """begin(0); begin(1); end(0); begin(2); end(1); end(2) -- a streaming caller -- returns for every batch what the
-    one-call form returns, which is what the oracle returns."""
+def test_three_batches_in_flight_equal_one_call_each(gpu_ctx, r73t):
+    """begin(0); begin(1); begin(2); end(0); begin(3); end(1); end(2); end(3) -- a streaming caller that keeps every lane busy --
+    returns for every batch what the one-call form returns, which is what the oracle returns.  The batches are ragged (a launch
+    lasts as long as its longest read: the short batches overtake the long one on the other lanes)."""
     gpu_ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
     gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
-    batches = [ragged_batch(r73t, lens, first_read=fr) for lens, fr in (([200, 31, 400], 1), ([64, 0, 129, 500, 7], 9), ([350], 30))]
+    batches = [ragged_batch(r73t, lens, first_read=fr) for lens, fr in (([200, 31, 1400], 1), ([64, 0, 129, 500, 7], 9), ([350], 30), ([90, 600, 2], 44))]
     t0 = gpu_ctx.viterbi_begin(batches[0][0], *batches[0][4:])
     t1 = gpu_ctx.viterbi_begin(batches[1][0], *batches[1][4:])
-    assert gpu_ctx.viterbi_in_flight() == 2
-    with pytest.raises(na.NchmmError):       # a third one has no slot
-        gpu_ctx.viterbi_begin(batches[2][0], *batches[2][4:])
-    with pytest.raises(na.NchmmError):       # and the one-call form would have to jump the queue
-        gpu_ctx.viterbi(batches[2][0], *batches[2][4:])
-    r0 = gpu_ctx.viterbi_end(t0)
     t2 = gpu_ctx.viterbi_begin(batches[2][0], *batches[2][4:])
+    assert gpu_ctx.viterbi_in_flight() == 3
+    with pytest.raises(na.NchmmError):       # a fourth one has no lane
+        gpu_ctx.viterbi_begin(batches[3][0], *batches[3][4:])
+    with pytest.raises(na.NchmmError):       # and the one-call form would have to jump the queue
+        gpu_ctx.viterbi(batches[3][0], *batches[3][4:])
+    r0 = gpu_ctx.viterbi_end(t0)
+    t3 = gpu_ctx.viterbi_begin(batches[3][0], *batches[3][4:])
     r1 = gpu_ctx.viterbi_end(t1)
     r2 = gpu_ctx.viterbi_end(t2)
+    r3 = gpu_ctx.viterbi_end(t3)
     assert gpu_ctx.viterbi_in_flight() == 0
-    for (off, mean, stdv, start, cm, sd, ls), (st, lp, status) in zip(batches, (r0, r1, r2)):
+    for (off, mean, stdv, start, cm, sd, ls), (st, lp, status) in zip(batches, (r0, r1, r2, r3)):
         ost, olp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
         nz = np.diff(off.astype(np.int64)) > 0
         assert np.array_equal(st, ost)
         assert_bits_equal(lp[nz], olp[nz], "path probability")
         assert (status == 0).all()
     with pytest.raises(na.NchmmError):       # nothing left to end
-        gpu_ctx.viterbi_end(t2)
+        gpu_ctx.viterbi_end(t3)
     # and the context still serves the one-call form
     st, lp, status = gpu_ctx.viterbi(batches[0][0], *batches[0][4:])
     assert np.array_equal(st, r0[0])
 
 
 def test_overlapping_device_launches_match_the_oracle(r73t):
-    """nchmm_viterbi_dev_enqueue x 5 on the two lanes, then one join: the launches roll into each other (blocks of launch k+1
+    """nchmm_viterbi_dev_enqueue x 5 on the three lanes, then one join: the launches roll into each other (blocks of launch k+1
     start where blocks of launch k run out of reads, taking over their back-pointer regions), each into its own outputs.
     Every batch must decode what the oracle decodes; the regions are sized by the first (longest) batch and reused."""
     import torch

@@ -45,16 +45,24 @@ out["kernels_ms"] = [round(x, 2) for x in ctx.last_kernel_ms()[:2]]
 out["states_sha"] = hashlib.sha256(np.ascontiguousarray(st).tobytes()).hexdigest()[:16]
 
 
-def stream(n_batches=4):
-    tk = [ctx.viterbi_begin(off, cm, sd, ls)]
-    for _ in range(n_batches - 1):
+DEPTH = int(os.environ.get("DEPTH", 2))     # batches in flight (the library takes as many as it has lanes)
+NB = int(os.environ.get("BATCHES", 6))
+
+
+def stream(n_batches):
+    tk = []
+    for _ in range(n_batches):
+        if len(tk) == DEPTH:
+            ctx.viterbi_end(tk.pop(0))
         tk.append(ctx.viterbi_begin(off, cm, sd, ls))
+    while len(tk) > 1:
         ctx.viterbi_end(tk.pop(0))
     return ctx.viterbi_end(tk.pop(0))
 
 
-best, (st2, lp2, status2) = timed(lambda: stream(4))
-out["ragged_streaming_mevents_s"] = round(4 * total / best / 1e6, 1)
+best, (st2, lp2, status2) = timed(lambda: stream(NB))
+out["ragged_streaming_mevents_s"] = round(NB * total / best / 1e6, 1)
+out["streaming_batches"], out["streaming_depth"] = NB, DEPTH
 out["streaming_equal"] = bool(np.array_equal(st, st2) and np.array_equal(lp, lp2))
 
 # the same number of events as equal-length reads

@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT/nanocall_amd/csrc
+run() { (cd $GRAFT_REPO_ROOT && DEPTH=$1 python tools/bench_ragged.py 2>/dev/null | sed "s/^/lanes $2 depth $1 /"; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fwbw 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lanes $2 Mevents/s', d['value'], 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'], 'clock', d['device']['shader_clock_mhz_under_load'], 'end_to_end', d.get('end_to_end', {}).get('value'), 'one_call', d.get('end_to_end', {}).get('one_call', {}).get('value'))"); }
+run 2 2
+touch nchmm_ctx.hpp; make -s CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -DNCHMM_VIT_LANES=3" > /dev/null 2>&1
+run 2 3
+run 3 3
+touch nchmm_ctx.hpp; make -s CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -DNCHMM_VIT_LANES=4" > /dev/null 2>&1
+run 4 4
+touch nchmm_ctx.hpp; make -s > /dev/null 2>&1
