@@ -122,14 +122,14 @@ int pipe_event(nchmm_ctx* c, PipeCall& K, hipEvent_t* out)
     return NCHMM_OK;
 }
 
-// Contiguous read ranges.  Every range costs one traceback latency (~0.45 ms during which the GPU is nearly idle) and
-// buys the overlap of its successor's copy-in with its own kernels; the FIRST range's copy-in is overlapped with nothing.
-//   * up to two grid-fulls of reads (the 1024-read batches a streaming caller sends): one range -- its copy-in overlaps the
-//     previous BATCH instead
-//   * larger: one grid-full first (short head), then ranges that double, capped by the back-pointer workspace; a short
-//     remainder joins its predecessor.  Inner ranges are whole grid-fulls (they drain evenly, see nchmm_viterbi_dev).
+// Contiguous read ranges.  A range buys the overlap of its successor's copy-in with its own kernel and costs next to nothing
+// (its launch rolls into the next one on another lane); the FIRST range's copy-in is overlapped with nothing.
+//   * streaming form, up to two grid-fulls of reads (the 1024-read batches a streaming caller sends): one range -- its
+//     copy-in overlaps the previous BATCH instead
+//   * one-call form (`alone`: nothing in front of it) from one grid-full up, and every larger batch: one grid-full first
+//     (short head), then ranges that double; a short remainder joins its predecessor.  Inner ranges are whole grid-fulls.
 // NCHMM_PIPE_READS (test hook) forces ranges of that many reads.
-int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events, std::vector<PipeRange>* out)
+int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events, bool alone, std::vector<PipeRange>* out)
 {
     slots = std::max<size_t>(slots, 1);
     size_t forced = 0;
@@ -143,7 +143,7 @@ int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events,
         return PipeRange{r0, r1, off[r0], off[r1], 0, mx};
     };
     out->clear();
-    if (!forced && n <= 2 * slots && off[n] - off[0] <= cap_events) {
+    if (!forced && n <= (alone ? slots + slots / 2 : 2 * slots) && off[n] - off[0] <= cap_events) {
         out->push_back(range_of(0, n));
         return NCHMM_OK;
     }
@@ -192,7 +192,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     uint64_t longest = 1;
     for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
     // (the back-pointer workspace is one region per resident block: it does not bound a range)
-    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, ~(uint64_t)0, &K.ranges))) return rc;
+    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, ~(uint64_t)0, direct, &K.ranges))) return rc;
     const size_t n_ranges = K.ranges.size();
 
     // longest-first processing order inside each range (the device work queue hands reads out in this order)
