@@ -115,3 +115,14 @@ def test_overlapping_device_launches_match_the_oracle(r73t):
             assert np.array_equal(st, ost) and lp[nz].tobytes() == olp[nz].tobytes() and np.isnan(lp[~nz]).all() and (status == 0).all()
     finally:
         ctx.close()
+
+
+def test_lane_and_region_soak_small():
+    """tools/soak_lanes.py at a size that takes seconds: ragged batches decoded in random order with 1-3 batches in flight and
+    through nchmm_viterbi_dev_enqueue, every result bit-identical to the one-call result (and, on short reads, to the oracle)."""
+    env = dict(os.environ, ITER="4", BATCHES="5", MAXREADS="900", MAXLEN="4000", ORACLE="3")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_lanes.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    import json
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["mismatching_batches"] == 0 and out["batch_decodes"] == 40 and out["oracle_checked_reads"] >= 12, out
