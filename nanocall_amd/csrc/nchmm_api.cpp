@@ -320,7 +320,10 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     // back-pointer regions are handed out per XCD: as many as blocks can be resident there, and some to spare
     c->slots_per_xcd = (unsigned)((c->vit_slots + (int)kXcds - 1) / (int)kXcds) + 8u;
     if ((rc = dev_alloc(c, (void**)&c->d_slot_owner, sizeof(unsigned) * kXcds * c->slots_per_xcd))) return fail(rc);
-    if (hipMemset(c->d_slot_owner, 0, sizeof(unsigned) * kXcds * c->slots_per_xcd) != hipSuccess) return fail(NCHMM_E_HIP);
+    // NCHMM_TEST_POISON_POOL=1 (test hook): every region marked taken, as a kernel that died with its regions would leave
+    // them -- launches must then fail loudly after their bounded wait, not hang and not return stale outputs
+    const int fill = std::getenv("NCHMM_TEST_POISON_POOL") ? 1 : 0;
+    if (hipMemset(c->d_slot_owner, fill, sizeof(unsigned) * kXcds * c->slots_per_xcd) != hipSuccess) return fail(NCHMM_E_HIP);
     c->fb_slots = c->n_cu * fwbw_blocks_per_cu();
     *out = c;
     return NCHMM_OK;
@@ -645,6 +648,7 @@ int viterbi_check_err(nchmm_ctx* c)
 {
     if (c->h_err && *(volatile unsigned*)c->h_err) {
         *c->h_err = 0;
+        c->last_hip = (int)hipErrorLaunchFailure;   // (the launch ran, but a block left without doing its share)
         return NCHMM_E_HIP;
     }
     return NCHMM_OK;

@@ -126,3 +126,37 @@ def test_lane_and_region_soak_small():
     import json
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["mismatching_batches"] == 0 and out["batch_decodes"] == 40 and out["oracle_checked_reads"] >= 12, out
+
+
+_POISON_CHILD = r"""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.environ["NC_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NC_ROOT"], "tests")); sys.path.insert(0, os.path.join(os.environ["NC_ROOT"], "oracle"))
+import nanocall_amd as na
+from helpers import IDENT, ragged_batch
+t = na.builtin_model("r73.t")
+off, mean, stdv, start, cm, sd, ls = ragged_batch(t, [300, 200, 100], first_read=5)
+out = {}
+with na.Context(0) as ctx:
+    ctx.put_model(0, na.scaled_model_table(t, IDENT)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    t0 = time.time()
+    try:
+        ctx.viterbi(off, cm, sd, ls)
+        out["raised"] = False
+    except na.NchmmError as e:
+        out["raised"] = True; out["code"] = e.code
+    out["seconds"] = round(time.time() - t0, 2)
+print(json.dumps(out))
+"""
+
+
+def test_a_pool_without_free_regions_fails_loudly_and_in_bounded_time():
+    """A block that finds no back-pointer region (cannot happen with a sane pool: the test hook marks every region taken, as a
+    kernel that died holding them would) gives up after its bounded wait and reports through pinned host memory: the call
+    returns an error within seconds -- it neither hangs the device nor hands back whatever the output arrays held."""
+    env = dict(os.environ, NCHMM_TEST_POISON_POOL="1", NC_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-c", _POISON_CHILD], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["raised"] and out["code"] == -3 and out["seconds"] < 30, out      # NCHMM_E_HIP

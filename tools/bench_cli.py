@@ -4,6 +4,8 @@ FAST5 files (a few dozen distinct reads written through tools/make_fast5, copied
 split into the stages the CLI reports.  Prints one JSON line.
 
   READS=2000 EVENTS=3000 THREADS=32 python tools/bench_cli.py [extra nanocall options]
+  RAGGED=1: read lengths log-normal around EVENTS (sigma 0.8, 600 .. 8 x EVENTS events; 48 distinct reads), what real runs
+  look like -- a launch lasts as long as its longest read
 """
 import json
 import os
@@ -21,7 +23,12 @@ import oracle_pipeline as op   # noqa: E402  (only its synthetic read generator:
 n_reads = int(os.environ.get("READS", 2000))
 n_events = int(os.environ.get("EVENTS", 3000))
 threads = int(os.environ.get("THREADS", min(32, os.cpu_count() or 1)))
-distinct = min(n_reads, 24)
+ragged = os.environ.get("RAGGED") == "1"
+distinct = min(n_reads, 48 if ragged else 24)
+import numpy as _np
+_rng = _np.random.default_rng(4242)
+lens = (_np.clip(_np.round(_np.exp(_rng.normal(_np.log(n_events), 0.8, distinct))), 600, 8 * n_events).astype(int) if ragged
+        else _np.full(distinct, n_events))
 cli = os.path.join(ROOT, "nanocall_amd", "bin", "nanocall")
 tool = os.path.join(ROOT, "tools", "make_fast5")
 if not os.path.exists(tool):
@@ -29,8 +36,8 @@ if not os.path.exists(tool):
 tmp = tempfile.mkdtemp(prefix="nanocall_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
 try:
     t0 = time.perf_counter()
-    half = n_events // 2
     for k in range(distinct):
+        half = int(lens[k]) // 2
         ed = op.synth_ed_table("r73", half, half, seed=100 + k, hairpin=8, complement_model="r73.c.p1.006.ont.model" if k % 2 else "r73.c.p2.006.ont.model",
                                scale=1.0 + 0.01 * (k % 5), shift=float(k % 7) - 3.0, drift=0.002 * (k % 3))
         ev = os.path.join(tmp, f"seed{k}.events")
@@ -55,8 +62,8 @@ try:
     stages = [l for l in p.stderr.splitlines() if "stage_wall_secs" in l][-1].split("stage_wall_secs")[1].split()
     stages = {t.split("=")[0]: round(float(t.split("=")[1]), 3) for t in stages}
     n_rec = sum(1 for l in open(out) if l.startswith(">"))
-    ev_in = int(kv["reads"]) * n_events
-    print(json.dumps({"reads": int(kv["reads"]), "events_per_read": n_events, "fasta_records": n_rec, "bases": int(kv["bases"]),
+    ev_in = int(sum(int(lens[r % distinct]) for r in range(int(kv["reads"]))))
+    print(json.dumps({"reads": int(kv["reads"]), "events_per_read": n_events, "ragged": ragged, "longest_read_events": int(lens.max()), "input_events": ev_in, "fasta_records": n_rec, "bases": int(kv["bases"]),
                       "wall_s": round(wall, 3), "training_s": float(kv["training_secs"]), "basecalling_s": float(kv["basecalling_secs"]),
                       "other_s_(summaries, event loading, FASTA)": round(wall - float(kv["training_secs"]) - float(kv["basecalling_secs"]), 3),
                       "reads_per_s": round(int(kv["reads"]) / wall, 1), "input_Mevents_per_s_end_to_end": round(ev_in / wall / 1e6, 2),
