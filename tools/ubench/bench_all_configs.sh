@@ -1,3 +1,5 @@
+# Every bench line of profiles/r04b_*: configs 2, 3, 4 (one shard), 5 (256 / 1024 reads, 12 GB budget), the host path, ragged batches.
+#   bash tools/ubench/bench_all_configs.sh   (on the GPU box; writes gpurun_out/r04b/)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04b
 mkdir -p $O

@@ -1,3 +1,5 @@
+# 2 / 3 / 4 compute lanes (NCHMM_VIT_LANES, compile time; batches in flight follow) on one box: tools/bench_ragged.py with DEPTH
+# batches in flight and bench.py config 2.   bash tools/ubench/lanes_ab.sh  -> profiles/r04_lanes_ab.txt
 cd $GRAFT_REPO_ROOT/nanocall_amd/csrc
 run() { (cd $GRAFT_REPO_ROOT && DEPTH=$1 python tools/bench_ragged.py 2>/dev/null | sed "s/^/lanes $2 depth $1 /"; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fwbw 2>/dev/null | python -c "
 import sys, json

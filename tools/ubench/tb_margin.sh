@@ -9,7 +9,7 @@ import sys, json, re
 m = '$m'
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('margin', m, 'Mevents/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'], 'tb_ms', d['roofline']['traceback_kernel_ms'])
+        d = json.loads(l); print('margin', m, 'Mevents/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'], 'tb_ms', d['roofline'].get('traceback_kernel_ms', 0))
     elif 'phase ticks' in l:
         r = re.search(r're-walked=(\d+) of (\d+)', l); print('margin', m, 'segments re-walked', r.group(1), 'of', r.group(2))
 "

@@ -6,7 +6,7 @@ cd $R/nanocall_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -fno-slp-vectorize"
 run() { (cd $R && for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fwbw --no-end-to-end 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Mevents/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'], 'tb_ms', d['roofline']['traceback_kernel_ms'], 'clock', d['device']['shader_clock_mhz_under_load'])"; done); }
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Mevents/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'], 'tb_ms', d['roofline'].get('traceback_kernel_ms', 0), 'clock', d['device']['shader_clock_mhz_under_load'])"; done); }
 echo "== tree"; run
 cp "$V" /tmp/viterbi_variant.hip
 /opt/rocm/bin/hipcc $FLAGS -c /tmp/viterbi_variant.hip -o viterbi_kernel.o && make -s > /dev/null 2>&1

@@ -5,7 +5,7 @@ cd $R/nanocall_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -fno-slp-vectorize"
 run() { (cd $R && for i in $(seq 1 ${RUNS:-2}); do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fwbw --no-end-to-end 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Mevents/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'], 'tb_ms', d['roofline']['traceback_kernel_ms'], 'clock', d['device']['shader_clock_mhz_under_load'])"; done); }
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('Mevents/s', d['value'], 'kernel_ms', d['roofline']['kernel_ms'], 'tb_ms', d['roofline'].get('traceback_kernel_ms', 0), 'clock', d['device']['shader_clock_mhz_under_load'])"; done); }
 echo "== tree"; run
 for v in "$@"; do
     cp "$(realpath $R/$v 2>/dev/null || realpath $v)" /tmp/viterbi_variant.hip
