@@ -122,14 +122,16 @@ int pipe_event(nchmm_ctx* c, PipeCall& K, hipEvent_t* out)
     return NCHMM_OK;
 }
 
-// Contiguous read ranges.  A range buys the overlap of its successor's copy-in with its own kernel and costs next to nothing
-// (its launch rolls into the next one on another lane); the FIRST range's copy-in is overlapped with nothing.
+// Contiguous read ranges.  The first range's copy-in is overlapped with nothing, so a batch that goes up alone starts with a
+// short head -- one grid-full of reads -- and everything else follows as ONE range whose copy-in runs under the head's kernel:
+// its launch rolls into the head's on the next lane, and its longest reads, wherever they sit in the batch, are handed out
+// first (a launch lasts as long as its longest read: 4096 log-normally long reads in one call 296 -> 309 Mevents/s, config-3
+// decode 305 -> 333 against ranges that double, profiles/r04b_range_policy_ab.txt).
 //   * streaming form, up to two grid-fulls of reads (the 1024-read batches a streaming caller sends): one range -- its
 //     copy-in overlaps the previous BATCH instead
-//   * one-call form (`alone`: nothing in front of it) from one grid-full up, and every larger batch: one grid-full first
-//     (short head), then ranges that double; a short remainder joins its predecessor.  Inner ranges are whole grid-fulls.
+//   * one-call form (`alone`) from 1.5 grid-fulls up, and every larger batch: head + rest
 // NCHMM_PIPE_READS (test hook) forces ranges of that many reads.
-int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events, bool alone, std::vector<PipeRange>* out)
+int cut_ranges(const uint64_t* off, size_t n, size_t slots, bool alone, std::vector<PipeRange>* out)
 {
     slots = std::max<size_t>(slots, 1);
     size_t forced = 0;
@@ -143,32 +145,20 @@ int cut_ranges(const uint64_t* off, size_t n, size_t slots, uint64_t cap_events,
         return PipeRange{r0, r1, off[r0], off[r1], 0, mx};
     };
     out->clear();
-    if (!forced && n <= (alone ? slots + slots / 2 : 2 * slots) && off[n] - off[0] <= cap_events) {
+    if (forced) {
+        for (size_t r0 = 0; r0 < n; r0 += forced) out->push_back(range_of(r0, std::min(n, r0 + forced)));
+        return NCHMM_OK;
+    }
+    if (n <= (alone ? slots + slots / 2 : 2 * slots)) {
         out->push_back(range_of(0, n));
         return NCHMM_OK;
     }
-    size_t want_reads = forced ? forced : slots;
-    uint64_t want_events = forced ? 0 : (uint64_t)1 << 20;
-    for (size_t r0 = 0; r0 < n;) {
-        size_t r1 = r0;
-        while (r1 < n) {
-            if (off[r1 + 1] - off[r0] > cap_events) break;
-            if (r1 - r0 >= want_reads && off[r1] - off[r0] >= want_events) break;
-            ++r1;
-        }
-        if (r1 == r0) return NCHMM_E_NOMEM;   // (cannot happen: cap_events >= the longest read)
-        if (!forced && r1 < n && r1 - r0 > slots) r1 = r0 + (r1 - r0) / slots * slots;
-        out->push_back(range_of(r0, r1));
-        r0 = r1;
-        if (!forced) { want_reads *= 2; want_events *= 2; }
-    }
-    if (!forced && out->size() >= 2) {
-        const PipeRange a = (*out)[out->size() - 2], b = out->back();
-        if (2 * (b.e1 - b.e0) < a.e1 - a.e0 && b.e1 - a.e0 <= cap_events) {
-            out->pop_back();
-            out->back() = range_of(a.r0, b.r1);
-        }
-    }
+    // the head: one grid-full of reads, and at least 1 M events (short reads: too little work to cover the copy-in of the rest)
+    size_t r1 = slots;
+    while (r1 < n && off[r1] - off[0] < ((uint64_t)1 << 20)) ++r1;
+    if (n - r1 < slots / 2) r1 = n;      // (a remainder not worth a launch)
+    out->push_back(range_of(0, r1));
+    if (r1 < n) out->push_back(range_of(r1, n));
     return NCHMM_OK;
 }
 
@@ -192,7 +182,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     uint64_t longest = 1;
     for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
     // (the back-pointer workspace is one region per resident block: it does not bound a range)
-    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, ~(uint64_t)0, direct, &K.ranges))) return rc;
+    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, direct, &K.ranges))) return rc;
     const size_t n_ranges = K.ranges.size();
 
     // longest-first processing order inside each range (the device work queue hands reads out in this order)

@@ -9,11 +9,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --serial-launches: every step behind the previous one, so that each kernel in the trace ran alone and its duration is its own (by default
 # consecutive steps roll into each other on the lanes of the context and a launch spans more than its share of the wall time)
-BENCH="python3 $ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-fwbw --serial-launches"
+# --no-end-to-end: that leg streams batches through the lanes, i.e. overlaps its launches again
+BENCH="python3 $ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-fwbw --no-end-to-end --serial-launches"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o vit -- $BENCH > $OUT/stats.log 2>&1
 # the default command (what the driver runs): steps overlap at their edges
-BENCH_DEFAULT="python3 $ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-fwbw"
+BENCH_DEFAULT="python3 $ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-fwbw --no-end-to-end"
 $BENCH_DEFAULT > $OUT/bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_overlap -o vit -- $BENCH_DEFAULT > $OUT/stats_overlap.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq1 -o vit -- $BENCH > $OUT/pmc_sq1.log 2>&1
