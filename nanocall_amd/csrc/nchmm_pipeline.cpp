@@ -8,22 +8,24 @@
 // after 20 ms 17 % slower (profiles/r04_hostpath_gap.json).  A caller that wants the device-resident rate from host
 // arrays must therefore keep kernels back to back, which one synchronous call per batch cannot do.
 //
-// What the timeline of the first attempt showed (profiles/r04_pipeline_timeline.md) and what follows from it:
-//   * The forward sweep is resident with every VGPR of every SIMD taken.  Anything the runtime implements as a shader
-//     kernel -- memsets, copies under 16 KiB, every device-to-host copy -- then waits for a free wave slot, i.e. for the
-//     whole sweep, and so does the traceback kernel of the previous range.  Only SDMA copies (host-to-device of >= 16 KiB)
-//     run beside a sweep.
-//       - no memset in front of a launch: queue tickets count up across launches (ViterbiArgs::queue_base)
+// What the timelines showed (profiles/r04_pipeline_timeline.md) and what follows from it:
+//   * A sweep is resident with every VGPR of every SIMD taken.  Anything the runtime implements as a shader kernel --
+//     memsets, copies under 16 KiB, every device-to-host copy -- then waits for a block to exit.  Only SDMA copies
+//     (host-to-device of >= 16 KiB) run beside a sweep.
+//       - no memset in front of a launch: queue tickets count up across launches (ViterbiArgs::queue_base), the
+//         back-pointer regions are taken and returned by the blocks themselves
 //       - the small inputs travel as ONE padded block from pinned memory (SDMA), on the copy-in stream
-//       - streaming outputs are not copied at all: the kernels write states / log-probs / status straight into a pinned
+//       - streaming outputs are not copied at all: the kernel writes states / log-probs / status straight into a pinned
 //         host block (2 B per event over PCIe, posted writes); `end` moves them into the caller's arrays on the CPU
-//       - two compute lanes bought nothing (the traceback of range k starved until range k+1 had drained): one compute
-//         stream, and ranges as large as the workspace allows -- each costs one traceback latency (~0.45 ms)
-//   * HIP streams share a handful of hardware queues; a copy stream that lands on the compute stream's queue waits
-//     behind its kernels.  The pipeline therefore owns exactly one extra stream (copy-in) and computes on the context's
-//     own stream.
+//   * A launch lasts as long as its longest read and its blocks run out of reads one by one.  Launches do not depend on each
+//     other (each block walks its read back itself and owns its back-pointer region meanwhile, viterbi_kernel.hip), so
+//     consecutive launches -- ranges of a batch, batches of a stream -- go to the context's three compute lanes in turn and
+//     roll into each other.  (Round 3 had a separate traceback kernel per range; a second lane then bought nothing, because
+//     the traceback of range k starved until the sweep of range k+1 had drained.)
+//   * HIP streams share four hardware queues; a stream that lands on another's queue waits behind its kernels.  Three lanes
+//     (lane 0 is the context's own stream) + the copy-in stream are all the pipeline owns.
 //
-//   begin(k+1) queues the H2D copies of batch k+1 (they run under the kernels of batch k) and its kernels behind them;
+//   begin(k+1) queues the H2D copies of batch k+1 (they run under the kernel of batch k) and its launches behind them;
 //   end(k) waits for batch k range by range and hands its results over while batch k+1 computes.
 #include "nanocall_hip.h"
 #include "nchmm_ctx.hpp"
