@@ -538,6 +538,9 @@ def main():
                                       "beside it; in the timed region consecutive launches overlap at their edges, so a step costs "
                                       "ms_per_step, less than a launch lasts",
                     "steps_overlap": not args.serial_launches,
+                    # the same bytes against the rate the timed region sustained (launches overlapping at their edges): what a
+                    # caller with more than one batch gets per launch; `frac` above stays the conservative kernel-alone figure
+                    "frac_at_step_rate": round(BYTES_PER_EVENT * events_per_launch / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                     "bytes_per_event": BYTES_PER_EVENT, "events_per_launch": events_per_launch,
                     "kernel_source_sha256_16": kernel_source_hash()}
             if pmc:
