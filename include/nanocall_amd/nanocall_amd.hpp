@@ -17,9 +17,11 @@
 // bit-identical to the reference.  A nanocall maintainer switches by including this header instead
 // of the reference headers and adding `using namespace nanocall_amd;`.
 //
-// Throughput note: the reference calls fill() once per strand from a pfor worker thread.  That works
-// here too (one context per thread), but a GPU wants many reads per launch: Viterbi::fill_batch and
-// Parameter_Trainer::train_one_round (which already batches its 2-4 windows) are the efficient forms.
+// Throughput note: the reference calls fill() once per strand from a pfor worker thread.  That works here
+// as it stands: Viterbi::fill hands the strand to nchmm_viterbi_strand, which combines the calls that are
+// in progress on all threads into batched launches (about half the calling threads' strands per launch) --
+// give the pfor as many worker threads as strands should be in flight.  Viterbi::fill_batch (many strands,
+// one model) and Parameter_Trainer::train_one_round (which batches its 2-4 windows) are the explicit forms.
 #ifndef NANOCALL_AMD_HPP
 #define NANOCALL_AMD_HPP
 
@@ -33,6 +35,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -70,6 +73,22 @@ public:
         return _ctx;
     }
     ~Device() { if (_ctx) nchmm_destroy(_ctx); }
+    // One context per GPU shared by every thread of the process, used ONLY through nchmm_viterbi_strand (which is thread-safe and
+    // combines the strands of concurrent callers into batched launches): what Viterbi::fill runs on.
+    static nchmm_ctx* shared_ctx(int dev)
+    {
+        static std::mutex m;
+        static std::vector<Device*> per_dev;      // (kept until exit: worker threads may still be inside a call at any time)
+        std::lock_guard<std::mutex> g(m);
+        if (dev < 0) throw Error(NCHMM_E_INVALID, "Device::shared_ctx");
+        if ((size_t)dev >= per_dev.size()) per_dev.resize((size_t)dev + 1, nullptr);
+        if (!per_dev[dev]) {
+            Device* d = new Device();
+            check(nchmm_create(&d->_ctx, dev), "nchmm_create");
+            per_dev[dev] = d;
+        }
+        return per_dev[dev]->_ctx;
+    }
 private:
     nchmm_ctx* _ctx = nullptr;
 };
@@ -286,11 +305,13 @@ public:
         pm.load_from_vector(table);
         return is;
     }
+    // the library's S x 6 table of this model
+    void pack6(float* t6) const { check(nchmm_model_pack6(reinterpret_cast<const float*>(_state.data()), t6), "nchmm_model_pack6"); }
     // upload as the library's S x 6 table into `slot`
     void put(int slot) const
     {
         std::vector<float> t6(n_states * 6);
-        check(nchmm_model_pack6(reinterpret_cast<const float*>(_state.data()), t6.data()), "nchmm_model_pack6");
+        pack6(t6.data());
         check(nchmm_put_model(Device::instance().ctx(), slot, t6.data()), "nchmm_put_model");
     }
 private:
@@ -460,13 +481,37 @@ public:
     unsigned n_events() const { return _n_events; }
     Float_Type path_probability() const { return _path_probability; }
 
-    // Viterbi.hpp:44-99: fills ev[i].model_state_idx / model_state / move
+    // Viterbi.hpp:44-99: fills ev[i].model_state_idx / model_state / move.  One strand per call, as the reference's
+    // basecall_strand makes it from every pfor worker thread (nanocall.cpp:645-690, :611-621): concurrent calls -- from any
+    // number of threads, each with its own model and transitions -- are combined into batched launches on the GPU's shared
+    // context (nchmm_viterbi_strand); the call returns when this strand is decoded.  Run the pfor with as many worker threads
+    // as you want strands in flight (they sleep here): ~1000 fill the GPU.
     void fill(const Pore_Model_Type& pm, const State_Transitions_Type& st, Event_Sequence_Type& ev)
     {
-        std::vector<Event_Sequence_Type*> evs{&ev};
-        std::vector<Float_Type> pp = fill_batch(pm, st, evs);
         _n_events = (unsigned)ev.size();
-        _path_probability = pp[0];
+        if (std::isnan(st.p_skip()) || std::isnan(st.p_stay())) {
+            // transitions read from a file: no (p_skip, p_stay) to hand over -- the thread's own context, a launch to itself
+            std::vector<Event_Sequence_Type*> evs{&ev};
+            _path_probability = fill_batch(pm, st, evs)[0];
+            return;
+        }
+        const size_t n = ev.size();
+        std::vector<float> t6(n_states * 6), soa(3 * n);
+        pm.pack6(t6.data());
+        float* const cm = soa.data(); float* const sd = cm + n; float* const ls = sd + n;
+        for (size_t i = 0; i < n; ++i) { cm[i] = ev[i].corrected_mean; sd[i] = ev[i].stdv; ls[i] = ev[i].log_stdv; }
+        std::vector<uint16_t> s(n);
+        float pp = 0;
+        const int rc = nchmm_viterbi_strand(Device::shared_ctx(Device::device_id()), t6.data(), st.p_skip(), st.p_stay(), n, cm, sd, ls, s.data(), &pp);
+        if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) check(rc, "nchmm_viterbi_strand");
+        _path_probability = pp;
+        if (rc == NCHMM_E_NUMERIC) return;   // reference has undefined behaviour here (Viterbi.hpp:125-141); leave events untouched
+        for (size_t i = 0; i < n; ++i) {     // fill_state_seq / fill_move_seq write-back (Viterbi.hpp:134-150)
+            const unsigned j = s[i];
+            ev[i].model_state_idx = j;
+            for (unsigned c = 0; c < Kmer_Size; ++c) ev[i].model_state[c] = "ACGT"[(j >> (2 * (Kmer_Size - 1 - c))) & 3u];   // Kmer::to_string
+            ev[i].move = i > 0 ? (int)Kmer_Type::min_skip(s[i - 1], j) : 0;
+        }
     }
     // many strands that share one scaled model and one transition table, one launch
     static std::vector<Float_Type> fill_batch(const Pore_Model_Type& pm, const State_Transitions_Type& st,

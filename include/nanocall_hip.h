@@ -266,6 +266,24 @@ int nchmm_viterbi_dev_enqueue(nchmm_ctx* ctx, size_t n_reads, size_t max_events,
                               int32_t* d_out_status);
 int nchmm_viterbi_dev_join(nchmm_ctx* ctx);
 
+/* ONE strand per call, from MANY host threads at once -- the reference's own call shape: basecall_strand builds the scaled model
+ * and the transitions of a strand and runs `vit.fill(pm, *transitions_ptr, corrected_events)` (nanocall.cpp:645-690), inside a
+ * pfor whose worker threads each hold one strand (:611-621).  Thread-safe on one context: calls that are in progress at the
+ * same time are combined into batched launches (two batches alternate: one collects callers while the other is on the device),
+ * each caller staging its own strand and taking its own results; a call returns when its strand is decoded.  With T calling
+ * threads about T/2 strands go into every launch, so the GPU fills up at T of the order of a thousand (worker threads that
+ * sleep in this call cost nothing); one caller alone gets a launch to itself.
+ *   table_Sx6   the scaled model as nchmm_put_model takes it;  (p_skip, p_stay): transitions = compute_transitions_fast of them
+ *   returns 0, NCHMM_E_NUMERIC for this strand (every state -INF/NaN in the last column), or the error of its batch.
+ * While threads are inside this call the context must not be used through any other entry point.
+ * nchmm_model_image / nchmm_put_model_images are its building blocks (the device image of a model built on the caller's
+ * thread; many images uploaded into consecutive slots with one copy). */
+int nchmm_viterbi_strand(nchmm_ctx* ctx, const float* table_Sx6, float p_skip, float p_stay, size_t n_events,
+                         const float* corrected_mean, const float* stdv, const float* log_stdv, uint16_t* out_state,
+                         float* out_path_logp);
+int nchmm_model_image(const float* table_Sx6, float* image_8xS, int32_t* fast);
+int nchmm_put_model_images(nchmm_ctx* ctx, int first_slot, size_t n, const float* images_nx8xS, const int32_t* fast_n);
+
 /* Viterbi from RAW events, with the host prep of basecall_strand on the device:
  * candidate v decodes raw events [src[v], src[v] + len[v]) of the uploaded (mean, stdv, start) arrays -- several
  * candidates may share a range (one strand, several models / parameter sets, nanocall.cpp:715-732,809-818) -- after

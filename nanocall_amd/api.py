@@ -398,6 +398,19 @@ class Context:
                                               _dp(d_order), _dp(d_out_state), _dp(d_out_logp), _dp(d_out_status)),
               "nchmm_viterbi_dev_enqueue")
 
+    def viterbi_strand(self, table_Sx6, p_skip, p_stay, cmean, stdv, log_stdv):
+        """nchmm_viterbi_strand: one strand, blocking, thread-safe on one context (concurrent calls are combined into launches;
+        ctypes releases the GIL for the duration).  Returns (states u16[n], path_logp, status)."""
+        t6 = _f32(table_Sx6)
+        cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
+        n = cm.shape[0]
+        states = np.empty(n, np.uint16)
+        lp = C.c_float(0.0)
+        rc = lib().nchmm_viterbi_strand(self._h, _p(t6), C.c_float(p_skip), C.c_float(p_stay), n, _p(cm), _p(sd), _p(ls), _p(states), C.byref(lp))
+        if rc not in (0, -6):
+            check(rc, "nchmm_viterbi_strand")
+        return states, np.float32(lp.value), rc
+
     def viterbi_dev_join(self):
         check(lib().nchmm_viterbi_dev_join(self._h), "nchmm_viterbi_dev_join")
 

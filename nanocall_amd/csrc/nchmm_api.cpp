@@ -343,6 +343,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_vq) (void)hipFree(c->d_vq);
     if (c->s_in) { (void)hipStreamSynchronize(c->s_in); (void)hipStreamDestroy(c->s_in); }
+    combine_destroy(c);
     pipe_destroy(c);
     if (c->d_model_fast) (void)hipFree(c->d_model_fast);
     if (c->d_prof) (void)hipFree(c->d_prof);
@@ -416,6 +417,34 @@ int nchmm_put_model(nchmm_ctx* c, int slot, const float* t6)
                          hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_model_fast + slot, &fast, sizeof(int32_t), hipMemcpyHostToDevice));
     c->model_set[slot] = true;
+    return NCHMM_OK;
+}
+
+// The device image of a scaled model (what nchmm_put_model builds from the S x 6 table), on the host: callers that stage many
+// models in parallel (nchmm_viterbi_strand) build their own and upload them together.
+int nchmm_model_image(const float* t6, float* image, int32_t* fast)
+{
+    if (!t6 || !image || !fast) return NCHMM_E_INVALID;
+    *fast = 1;
+    for (int j = 0; j < kStates; ++j) {
+        const float* s = t6 + (size_t)j * 6;
+        model_image_row(image, j, s[0], s[1], s[2], s[3], s[4], s[5], fast);
+    }
+    return NCHMM_OK;
+}
+
+int nchmm_put_model_images(nchmm_ctx* c, int first_slot, size_t n, const float* images, const int32_t* fast)
+{
+    if (!c || first_slot < 0 || (n && (!images || !fast)) || n > (1u << 20)) return NCHMM_E_INVALID;
+    if (n == 0) return NCHMM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = reserve_slots(c, first_slot + (int)n);
+    if (rc != NCHMM_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // a running kernel may still read these slots
+    HIP_TRY(c, hipMemcpyAsync(c->d_models + (size_t)first_slot * kModelFloats, images, sizeof(float) * kModelFloats * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_model_fast + first_slot, fast, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < n; ++k) c->model_set[first_slot + k] = 1;
     return NCHMM_OK;
 }
 

@@ -73,6 +73,7 @@ struct nchmm_ctx {
     unsigned ws_per_xcd = 0;        // regions per XCD the workspace holds now (<= slots_per_xcd)
     hipStream_t s_in = nullptr;     // copy-in stream of the host-pointer pipeline (nchmm_pipeline.cpp); it computes on own_stream
     nchmm::PipeState* pipe = nullptr;   // batches in flight (nchmm_pipeline.cpp)
+    void* combiner = nullptr;           // nchmm_viterbi_strand's batcher (nchmm_combine.cpp), created on first use
     size_t peak_bytes = 0;          // high-water mark of counters[6] (device bytes held)
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
     size_t fb_budget = 0;           // same for the forward-backward alpha rows (16 KiB per event)
@@ -104,6 +105,7 @@ namespace nchmm {
 constexpr size_t kQueueWords = 16 + 4096;
 
 void pipe_destroy(nchmm_ctx* c);
+void combine_destroy(nchmm_ctx* c);
 int pipe_in_flight(const nchmm_ctx* c);
 // Size the back-pointer regions for launches of up to `count` reads of up to `longest` events (reallocates only when every
 // lane is idle).

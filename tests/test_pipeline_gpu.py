@@ -160,3 +160,36 @@ def test_a_pool_without_free_regions_fails_loudly_and_in_bounded_time():
     import json
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["raised"] and out["code"] == -3 and out["seconds"] < 30, out      # NCHMM_E_HIP
+
+
+def test_one_strand_per_call_from_many_threads_is_combined_and_exact(r73t, r9t):
+    """nchmm_viterbi_strand: the reference's call shape (basecall_strand: one strand per call with its own scaled model and
+    transitions, from every pfor worker at once, nanocall.cpp:611-621,645-690).  40 threads decode 120 strands of 5 different
+    (model, scaling, transition) kinds through ONE context; every strand must equal the oracle's decode, and the launches must
+    have been shared (fewer launches than strands)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import nc_oracle as oracle
+    kinds = [(r73t, IDENT, 0.3, 0.1), (r73t, (1.04, 1.5, 0.0, 1.1, 0.95, 1.2), 0.25, 0.12), (r9t, IDENT, 0.3, 0.1),
+             (r9t, (0.97, -2.0, 0.0, 0.9, 1.05, 0.8), 0.33, 0.08), (r73t, (1.0, 0.5, 0.0, 1.3, 1.0, 1.0), 0.17, 0.2)]
+    tables = [na.scaled_model_table(t, p) for t, p, _, _ in kinds]
+    rng = np.random.default_rng(5)
+    jobs = []
+    for r in range(120):
+        k = r % len(kinds)
+        n = int(rng.integers(1, 420))
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(kinds[k][0], [n], first_read=1000 + r)
+        jobs.append((k, cm, sd, ls))
+    with na.Context(0) as ctx:
+        launches0 = int(ctx.counters()[3])
+        with ThreadPoolExecutor(40) as ex:
+            got = list(ex.map(lambda j: ctx.viterbi_strand(tables[j[0]], kinds[j[0]][2], kinds[j[0]][3], j[1], j[2], j[3]), jobs))
+        launches = int(ctx.counters()[3]) - launches0
+        # a lone caller gets a launch to itself
+        st1, lp1, rc1 = ctx.viterbi_strand(tables[0], 0.3, 0.1, *jobs[0][1:])
+    assert launches < len(jobs) / 2, launches
+    oms = [oracle.Model(t, p) for t, p, _, _ in kinds]
+    ots = [oracle.Transitions(ps, pt) for _, _, ps, pt in kinds]
+    for (k, cm, sd, ls), (st, lp, rc) in zip(jobs, got):
+        s, mv, olp = oracle.viterbi(oms[k], ots[k], cm, sd, ls)
+        assert rc == 0 and np.array_equal(st, s) and np.float32(lp).tobytes() == np.float32(olp).tobytes()
+    assert rc1 == 0 and np.array_equal(st1, got[0][0]) and lp1 == got[0][1]

@@ -7,8 +7,10 @@
 #include <cstring>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include "nchmm_internal.hpp"
+#include "nchmm_combine.hpp"
 #include <random>
 #include "nanocall_hip.h"
 int main(){
@@ -66,4 +68,41 @@ int main(){
         } });
     for (auto& t : callers) t.join();
     if (bad.load()) return 30; }
+  { // StrandCombiner (nchmm_viterbi_strand's batcher) with a host stand-in for the device: 24 threads x 150 strands of random
+    // length, small batches (so that they fill up, close early, and a strand longer than a batch comes along); every caller
+    // must get ITS strand's results -- states derived from its own events, logp from its own image and transition parameters
+    struct FakeRunner {
+      std::atomic<long>* runs; std::atomic<long>* strands;
+      void release(nchmm::CombineBatch& B) { std::free(B.images); std::free(B.fast); std::free(B.p_skip); std::free(B.p_stay); std::free(B.off); std::free(B.cm); std::free(B.sd); std::free(B.ls);
+        std::free(B.states); std::free(B.logp); std::free(B.status);
+        B.images = nullptr; B.fast = nullptr; B.p_skip = B.p_stay = nullptr; B.off = nullptr; B.cm = B.sd = B.ls = nullptr; B.states = nullptr; B.logp = nullptr; B.status = nullptr; B.cap_reads = B.cap_events = 0; }
+      int alloc(nchmm::CombineBatch& B, size_t reads, size_t events) { release(B);
+        B.images = (float*)std::malloc(sizeof(float) * nchmm::kImageFloats * reads); B.fast = (int32_t*)std::malloc(4 * reads); B.p_skip = (float*)std::malloc(4 * reads);
+        B.p_stay = (float*)std::malloc(4 * reads); B.off = (uint64_t*)std::malloc(8 * (reads + 1)); B.cm = (float*)std::malloc(4 * events); B.sd = (float*)std::malloc(4 * events);
+        B.ls = (float*)std::malloc(4 * events); B.states = (uint16_t*)std::malloc(2 * events); B.logp = (float*)std::malloc(4 * reads); B.status = (int32_t*)std::malloc(4 * reads);
+        B.off[0] = 0; B.cap_reads = reads; B.cap_events = events; return 0; }
+      int run(nchmm::CombineBatch& B) { runs->fetch_add(1); strands->fetch_add((long)B.n);
+        for (size_t r = 0; r < B.n; ++r) { for (uint64_t e = B.off[r]; e < B.off[r + 1]; ++e) B.states[e] = (uint16_t)((unsigned)B.cm[e] & 4095u);
+          B.logp[r] = B.images[r * nchmm::kImageFloats + 17] + B.p_skip[r] * 8.f + B.p_stay[r]; B.status[r] = (B.off[r + 1] - B.off[r]) % 7 == 3 ? -6 : 0; }
+        std::this_thread::sleep_for(std::chrono::microseconds(300)); return 0; } };
+    std::atomic<long> runs{0}, strands{0}, bad{0};
+    {
+      nchmm::StrandCombiner<FakeRunner> sc(FakeRunner{&runs, &strands}, 8, 600, 50);
+      std::vector<std::thread> callers;
+      for (int id = 0; id < 24; ++id)
+        callers.emplace_back([&sc, &bad, id] {
+          std::mt19937 r(100 + id);
+          for (int rep = 0; rep < 150; ++rep) {
+            const size_t n = 1 + r() % ((rep % 40 == 7) ? 1500 : 200);      // (some longer than a whole batch)
+            std::vector<float> cm(n), sd(n, 1.f), ls(n, 0.f); for (size_t i = 0; i < n; ++i) cm[i] = (float)((id * 131 + rep * 17 + i) & 4095);
+            std::vector<uint16_t> st(n, 0xFFFF); float lp = -1; const float tag = (float)(id * 1000 + rep);
+            const int rc = sc.submit([&](float* img, int32_t* fast) { img[17] = tag; *fast = 1; }, (float)(id % 5), (float)(rep % 3), n, cm.data(), sd.data(), ls.data(), st.data(), &lp);
+            if (rc != (n % 7 == 3 ? -6 : 0)) bad++;
+            if (lp != tag + (float)(id % 5) * 8.f + (float)(rep % 3)) bad++;
+            for (size_t i = 0; i < n; ++i) if (st[i] != (uint16_t)((id * 131 + rep * 17 + i) & 4095)) { bad++; break; }
+          } });
+      for (auto& t : callers) t.join();
+    }
+    printf("combiner: %ld strands in %ld batches\n", strands.load(), runs.load());
+    if (bad.load() || strands.load() != 24 * 150 || runs.load() >= strands.load()) return 31; }
   puts("host ABI under ASan/UBSan: ok"); return 0; }
