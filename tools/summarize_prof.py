@@ -19,26 +19,29 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recurs
         print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 # the --stats average runs over EVERY launch of the command: warm-up steps (cold clocks) and the host-pointer leg's calls
 # (the kernel after a PCIe gap) as well as the timed steps; the per-call trace separates them
-warm, steps = int(os.environ.get("PROF_WARMUP", 3)), int(os.environ.get("PROF_STEPS", 12))
+# bench.py's launches, in order: settling launches (as many as it takes), W warm-up steps, K timed steps, then max(3, min(K, 8))
+# launches one behind the other for roofline.kernel_ms (the profiled commands carry --no-end-to-end): the timed region is counted
+# from the END of the trace
+steps = int(os.environ.get("PROF_STEPS", 12))
+tail = max(3, min(steps, 8))
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
-    for kern in ("viterbi_kernel",):
-        d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-             for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
-        d = [x[1] for x in sorted(d)]
-        if len(d) >= warm + steps:
-            timed, rest = d[warm:warm + steps], d[:warm] + d[warm + steps:]
-            print(f"{kern}: launches {warm + 1}..{warm + steps} (bench.py's timed region) mean {sum(timed) / len(timed):.3f} ms "
-                  f"[{min(timed):.3f}, {max(timed):.3f}]; the other {len(rest)} (warm-up, host-pointer leg) mean "
-                  f"{sum(rest) / max(1, len(rest)):.3f} ms")
+    d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+         for r in csv.DictReader(open(f)) if "viterbi_kernel" in r["Kernel_Name"]]
+    d = [x[1] for x in sorted(d)]
+    if len(d) >= steps + tail:
+        timed, rest = d[-(steps + tail):-tail], d[:-(steps + tail)] + d[-tail:]
+        print(f"viterbi_kernel ({len(d)} launches, every one behind the previous): the {steps} of bench.py's timed region mean "
+              f"{sum(timed) / len(timed):.3f} ms [{min(timed):.3f}, {max(timed):.3f}]; the other {len(rest)} (settling, warm-up, the "
+              f"kernel_ms leg) mean {sum(rest) / max(1, len(rest)):.3f} ms")
 # the default bench command (consecutive steps roll into each other on the context's lanes): how the launches overlap
 for f in glob.glob(os.path.join(out, "stats_overlap", "**", "*kernel_trace.csv"), recursive=True):
     d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "viterbi_kernel" in r["Kernel_Name"])
-    if len(d) >= warm + steps:
-        t = d[warm:warm + steps]
+    if len(d) >= steps + tail:
+        t = d[-(steps + tail):-tail]
         span = (t[-1][1] - t[0][0]) / 1e6
         dur = [(b - a) / 1e6 for a, b in t]
         lap = [(t[i][1] - t[i + 1][0]) / 1e6 for i in range(len(t) - 1)]
-        print(f"== overlapping steps (default bench command), launches {warm + 1}..{warm + steps}: first start to last end {span:.3f} ms = "
+        print(f"== overlapping steps (default bench command), the {steps} launches of the timed region: first start to last end {span:.3f} ms = "
               f"{span / len(t):.3f} ms per launch; each launch lasts {sum(dur) / len(dur):.3f} ms [{min(dur):.3f}, {max(dur):.3f}] from the "
               f"dispatch of its first block to the exit of its last; consecutive launches overlap by {sum(lap) / len(lap):.3f} ms "
               f"[{min(lap):.3f}, {max(lap):.3f}]")
