@@ -305,6 +305,8 @@ public:
         pm.load_from_vector(table);
         return is;
     }
+    // the S x 10 states as the library lays them out (nchmm_model_load)
+    const float* states_Sx10() const { return reinterpret_cast<const float*>(_state.data()); }
     // the library's S x 6 table of this model
     void pack6(float* t6) const { check(nchmm_model_pack6(reinterpret_cast<const float*>(_state.data()), t6), "nchmm_model_pack6"); }
     // upload as the library's S x 6 table into `slot`
@@ -625,7 +627,7 @@ struct Parameter_Trainer {
     static std::vector<unsigned>& st_train_kmers() { static std::vector<unsigned> v; return v; }
     static unsigned& pm_train_drift() { static unsigned v = 1; return v; }
 
-    // Parameter_Trainer.hpp:541-579.  Device slots used: 62/63 scaled models + transitions.
+    // Parameter_Trainer.hpp:541-579.
     static void train_one_round(const std::vector<std::pair<const Event_Sequence_Type*, unsigned>>& event_seq_ptrs,
                                 const std::array<const Pore_Model_Type*, 2>& model_ptrs,
                                 const State_Transitions_Type& default_transitions,
@@ -635,27 +637,31 @@ struct Parameter_Trainer {
                                 std::array<State_Transition_Parameters_Type, 2>& new_st_params, Float_Type& fit, bool& done,
                                 bool train_scaling, bool train_transitions)
     {
-        nchmm_ctx* ctx = Device::instance().ctx();
         done = false;
-        // fill_train_data :99-155
+        // fill_train_data :99-155.  One call per read, from every pfor worker (nanocall.cpp:282-579): the windows of the calls
+        // that are in progress on all threads are combined into batched launches on the GPU's shared context (nchmm_fwbw_windows).
         bool have[2] = {false, false};
         for (const auto& p : event_seq_ptrs) have[p.second] = true;
+        const float* unscaled[2] = {nullptr, nullptr};
+        float tr_skip[2] = {0, 0}, tr_stay[2] = {0, 0};
+        int model_of[2] = {-1, -1};
+        size_t n_models = 0;
+        bool parametric = true;
+        State_Transitions_Type custom[2];
         for (unsigned st = 0; st < 2; ++st) {
             if (!have[st]) continue;
-            Pore_Model_Type scaled(*model_ptrs[st]);
-            scaled.scale(crt_pm_params);
-            scaled.put(62 + st);
-            if (!crt_st_params[st].is_default()) {
-                State_Transitions_Type custom;
-                custom.compute_transitions_fast(crt_st_params[st]);
-                custom.put(62 + st);
-            } else {
-                default_transitions.put(62 + st);
-            }
+            const State_Transitions_Type* tr = &default_transitions;
+            if (!crt_st_params[st].is_default()) { custom[st].compute_transitions_fast(crt_st_params[st]); tr = &custom[st]; }
+            parametric = parametric && !std::isnan(tr->p_skip()) && !std::isnan(tr->p_stay());
+            // (the library scales the model by crt_pm_params on the device: Pore_Model::scale, bit for bit)
+            unscaled[n_models] = model_ptrs[st]->states_Sx10(); tr_skip[n_models] = tr->p_skip(); tr_stay[n_models] = tr->p_stay();
+            model_of[st] = (int)n_models++;
         }
+        const float pm6[6] = {crt_pm_params.scale, crt_pm_params.shift, crt_pm_params.drift, crt_pm_params.var, crt_pm_params.scale_sd,
+                              crt_pm_params.var_sd};
         std::vector<uint64_t> off{0};
         std::vector<float> cm, sd, ls, mean, start;
-        std::vector<int32_t> s_slot;
+        std::vector<int32_t> s_slot, w_model;
         std::vector<float> stp, w_pm;
         for (const auto& p : event_seq_ptrs) {
             Event_Sequence_Type corrected(*p.first);
@@ -664,6 +670,7 @@ struct Parameter_Trainer {
             for (const auto& e : *p.first) { mean.push_back(e.mean); start.push_back(e.start); }
             off.push_back(cm.size());
             s_slot.push_back(62 + (int)p.second);
+            w_model.push_back(model_of[p.second]);
             for (float v : {crt_pm_params.scale, crt_pm_params.shift, crt_pm_params.drift, crt_pm_params.var, crt_pm_params.scale_sd,
                             crt_pm_params.var_sd})
                 w_pm.push_back(v);
@@ -671,8 +678,23 @@ struct Parameter_Trainer {
         }
         const size_t n_win = event_seq_ptrs.size(), total = cm.size();
         std::vector<float> lpd(n_win), pm_sums(6 * total), st_sums(3 * n_win);
-        check(nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), w_pm.data(), s_slot.data(),
-                         stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr), "nchmm_fwbw");
+        if (parametric) {
+            check(nchmm_fwbw_windows(Device::shared_ctx(Device::device_id()), n_models, unscaled, pm6, tr_skip, tr_stay, n_win, off.data(), cm.data(),
+                                     sd.data(), ls.data(), w_model.data(), stp.data(), lpd.data(), pm_sums.data(), st_sums.data()),
+                  "nchmm_fwbw_windows");
+        } else {
+            // default transitions read from a file: no (p_skip, p_stay) to hand over -- the thread's own context.  Slots 62/63.
+            nchmm_ctx* ctx = Device::instance().ctx();
+            for (unsigned st = 0; st < 2; ++st) {
+                if (!have[st]) continue;
+                Pore_Model_Type scaled(*model_ptrs[st]);
+                scaled.scale(crt_pm_params);
+                scaled.put(62 + (int)st);
+                (crt_st_params[st].is_default() ? default_transitions : custom[st]).put(62 + (int)st);
+            }
+            check(nchmm_fwbw(ctx, n_win, off.data(), cm.data(), sd.data(), ls.data(), s_slot.data(), w_pm.data(), s_slot.data(),
+                             stp.data(), lpd.data(), pm_sums.data(), st_sums.data(), nullptr, nullptr), "nchmm_fwbw");
+        }
         fit = 0;
         for (float v : lpd) fit += v;   // :154
         if (train_scaling) {

@@ -355,6 +355,23 @@ int nchmm_fwbw(nchmm_ctx* ctx, size_t n_win, const uint64_t* off, const float* c
                float* out_log_pr_data, float* out_pm_sums, float* out_st_sums,
                float* out_alpha, float* out_beta);
 
+/* One read's training windows per call, from MANY host threads at once -- the reference's call shape again:
+ * Parameter_Trainer::train_one_round (Parameter_Trainer.hpp:541-579) scales the one or two models of a read by the current
+ * parameters, runs forward-backward over its 2-4 windows and sums, inside the pfor of train_reads (nanocall.cpp:282-579).
+ * Thread-safe on one context: calls in progress at the same time are combined into batched nchmm_fwbw launches exactly as
+ * nchmm_viterbi_strand combines strands (each caller stages its own windows and takes its own sums).
+ *   unscaled_Sx10[m]   the UNSCALED model of the call's m-th strand (nchmm_model_load layout; stays valid during the call),
+ *   pm_params          the Pore_Model_Parameters {scale, shift, drift, var, scale_sd, var_sd} every model of the call is scaled
+ *                      by (Pore_Model::scale, on the device: a model travels as 32 bytes, not as a 128 KiB image)
+ *   p_skip[m], p_stay[m]                   its transitions: compute_transitions_fast(p_skip[m], p_stay[m]),  m < n_models
+ *   off / corrected_mean / stdv / log_stdv the windows, SoA like nchmm_fwbw; win_model[w] < n_models
+ *   st_params (n_win x 2 {p_stay, p_skip}, NULL = those of the window's model); outputs as nchmm_fwbw (sums may be NULL).
+ * While threads are inside this call (or nchmm_viterbi_strand) the context must not be used through any other entry point. */
+int nchmm_fwbw_windows(nchmm_ctx* ctx, size_t n_models, const float* const* unscaled_Sx10, const float* pm_params,
+                       const float* p_skip, const float* p_stay, size_t n_win, const uint64_t* off, const float* corrected_mean,
+                       const float* stdv, const float* log_stdv, const int32_t* win_model, const float* st_params,
+                       float* out_log_pr_data, float* out_pm_sums, float* out_st_sums);
+
 int nchmm_fwbw_dev(nchmm_ctx* ctx, size_t n_win, size_t max_events, size_t total_events,
                    const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
                    const float* d_log_stdv, const int32_t* d_scaled_slot, const float* d_pm_params,

@@ -414,6 +414,27 @@ class Context:
     def viterbi_dev_join(self):
         check(lib().nchmm_viterbi_dev_join(self._h), "nchmm_viterbi_dev_join")
 
+    def fwbw_windows(self, unscaled_states, pm_params, p_skip, p_stay, off, cmean, stdv, log_stdv, win_model, st_params=None):
+        """nchmm_fwbw_windows: one read's training windows over its own models (unscaled S x 10 states from model_load, all scaled
+        by pm_params on the device), blocking, thread-safe on one context (concurrent calls are combined into launches).
+        Returns dict(log_pr_data, pm_sums, st_sums) like fwbw."""
+        tabs = [_f32(t) for t in unscaled_states]
+        ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+        pm6 = _f32(pm_params)
+        ps, pt = _f32(p_skip), _f32(p_stay)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = off.shape[0] - 1
+        total = int(off[-1]) if n > 0 else 0
+        cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
+        wm = np.ascontiguousarray(win_model, np.int32)
+        sp = None if st_params is None else _f32(st_params).reshape(n, 2)
+        lpd = np.empty(n, np.float32)
+        pm = np.empty((total, 6), np.float32)
+        stt = np.empty((n, 3), np.float32)
+        check(lib().nchmm_fwbw_windows(self._h, len(tabs), ptrs, _p(pm6), _p(ps), _p(pt), n, _p(off), _p(cm), _p(sd), _p(ls), _p(wm), _p(sp),
+                                       _p(lpd), _p(pm), _p(stt)), "nchmm_fwbw_windows")
+        return dict(log_pr_data=lpd, pm_sums=pm, st_sums=stt)
+
     # -- forward-backward --
     def fwbw(self, off, cmean, stdv, log_stdv, scaled_slot=None, pm_params=None, trans_slot=None,
              st_params=None, want_matrices=False):

@@ -74,6 +74,7 @@ struct nchmm_ctx {
     hipStream_t s_in = nullptr;     // copy-in stream of the host-pointer pipeline (nchmm_pipeline.cpp); it computes on own_stream
     nchmm::PipeState* pipe = nullptr;   // batches in flight (nchmm_pipeline.cpp)
     void* combiner = nullptr;           // nchmm_viterbi_strand's batcher (nchmm_combine.cpp), created on first use
+    void* win_combiner = nullptr;       // nchmm_fwbw_windows' batcher
     size_t peak_bytes = 0;          // high-water mark of counters[6] (device bytes held)
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
     size_t fb_budget = 0;           // same for the forward-backward alpha rows (16 KiB per event)

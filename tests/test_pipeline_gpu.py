@@ -193,3 +193,37 @@ def test_one_strand_per_call_from_many_threads_is_combined_and_exact(r73t, r9t):
         s, mv, olp = oracle.viterbi(oms[k], ots[k], cm, sd, ls)
         assert rc == 0 and np.array_equal(st, s) and np.float32(lp).tobytes() == np.float32(olp).tobytes()
     assert rc1 == 0 and np.array_equal(st1, got[0][0]) and lp1 == got[0][1]
+
+
+def test_training_windows_per_call_from_many_threads_equal_one_batched_call(r73t):
+    """nchmm_fwbw_windows: train_one_round's shape (one read per call: its two models scaled by the read's current parameters,
+    its four windows, from every pfor worker, Parameter_Trainer.hpp:541-579 inside nanocall.cpp:282-579).  32 threads run 96
+    reads through ONE context; every read's log-likelihoods and EM sums must be bit-identical to what nchmm_fwbw gives for the
+    same windows in a batch of their own over models scaled on the HOST, and the calls must have shared launches."""
+    from concurrent.futures import ThreadPoolExecutor
+    c_tab = na.builtin_model("r73.c.p1")
+    unscaled = [na.model_load(r73t), na.model_load(c_tab)]
+    rng = np.random.default_rng(11)
+    reads = []
+    for r in range(96):
+        pm = (float(rng.uniform(0.95, 1.05)), float(rng.uniform(-2, 2)), 0.0, float(rng.uniform(0.9, 1.2)), float(rng.uniform(0.9, 1.1)), float(rng.uniform(0.8, 1.3)))
+        st = [(float(rng.uniform(0.06, 0.15)), float(rng.uniform(0.2, 0.35))) for _ in range(2)]        # (p_stay, p_skip) per strand
+        lens = [int(rng.integers(60, 101)) for _ in range(4)]
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=3000 + r)
+        wm = np.array([0, 0, 1, 1], np.int32)
+        stp = np.array([st[m] for m in wm], np.float32)
+        reads.append(dict(p_skip=[st[0][1], st[1][1]], p_stay=[st[0][0], st[1][0]], off=off, cm=cm, sd=sd, ls=ls, wm=wm, pm=pm, stp=stp))
+    with na.Context(0) as ctx:
+        launches0 = int(ctx.counters()[3])
+        with ThreadPoolExecutor(32) as ex:
+            got = list(ex.map(lambda R: ctx.fwbw_windows(unscaled, R["pm"], R["p_skip"], R["p_stay"], R["off"], R["cm"], R["sd"], R["ls"], R["wm"], R["stp"]), reads))
+        launches = int(ctx.counters()[3]) - launches0
+    assert launches < len(reads) / 2, launches
+    with na.Context(0) as ref:
+        for R, G in zip(reads, got):
+            for m, tab in enumerate((r73t, c_tab)):
+                ref.put_model(m, na.scaled_model_table(tab, R["pm"]))
+                ref.put_transitions(m, *na.transitions_fast(R["p_skip"][m], R["p_stay"][m]))
+            want = ref.fwbw(R["off"], R["cm"], R["sd"], R["ls"], scaled_slot=R["wm"], pm_params=R["pm"], trans_slot=R["wm"], st_params=R["stp"])
+            for k in ("log_pr_data", "pm_sums", "st_sums"):
+                assert G[k].tobytes() == want[k].tobytes(), k

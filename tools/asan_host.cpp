@@ -73,16 +73,17 @@ int main(){
     // must get ITS strand's results -- states derived from its own events, logp from its own image and transition parameters
     struct FakeRunner {
       std::atomic<long>* runs; std::atomic<long>* strands;
-      void release(nchmm::CombineBatch& B) { std::free(B.images); std::free(B.fast); std::free(B.p_skip); std::free(B.p_stay); std::free(B.off); std::free(B.cm); std::free(B.sd); std::free(B.ls);
+      void release(nchmm::StrandBatch& B) { std::free(B.images); std::free(B.fast); std::free(B.p_skip); std::free(B.p_stay); std::free(B.off); std::free(B.cm); std::free(B.sd); std::free(B.ls);
         std::free(B.states); std::free(B.logp); std::free(B.status);
-        B.images = nullptr; B.fast = nullptr; B.p_skip = B.p_stay = nullptr; B.off = nullptr; B.cm = B.sd = B.ls = nullptr; B.states = nullptr; B.logp = nullptr; B.status = nullptr; B.cap_reads = B.cap_events = 0; }
-      int alloc(nchmm::CombineBatch& B, size_t reads, size_t events) { release(B);
-        B.images = (float*)std::malloc(sizeof(float) * nchmm::kImageFloats * reads); B.fast = (int32_t*)std::malloc(4 * reads); B.p_skip = (float*)std::malloc(4 * reads);
+        B.images = nullptr; B.fast = nullptr; B.p_skip = B.p_stay = nullptr; B.off = nullptr; B.cm = B.sd = B.ls = nullptr; B.states = nullptr; B.logp = nullptr; B.status = nullptr;
+        B.cap[0] = B.cap[1] = B.cap[2] = 0; }
+      int alloc(nchmm::StrandBatch& B, const size_t cap[3]) { release(B); const size_t reads = cap[0], events = cap[1];
+        B.images = (float*)std::malloc(sizeof(float) * nchmm::kImageFloats * cap[2]); B.fast = (int32_t*)std::malloc(4 * cap[2]); B.p_skip = (float*)std::malloc(4 * reads);
         B.p_stay = (float*)std::malloc(4 * reads); B.off = (uint64_t*)std::malloc(8 * (reads + 1)); B.cm = (float*)std::malloc(4 * events); B.sd = (float*)std::malloc(4 * events);
         B.ls = (float*)std::malloc(4 * events); B.states = (uint16_t*)std::malloc(2 * events); B.logp = (float*)std::malloc(4 * reads); B.status = (int32_t*)std::malloc(4 * reads);
-        B.off[0] = 0; B.cap_reads = reads; B.cap_events = events; return 0; }
-      int run(nchmm::CombineBatch& B) { runs->fetch_add(1); strands->fetch_add((long)B.n);
-        for (size_t r = 0; r < B.n; ++r) { for (uint64_t e = B.off[r]; e < B.off[r + 1]; ++e) B.states[e] = (uint16_t)((unsigned)B.cm[e] & 4095u);
+        B.off[0] = 0; B.cap[0] = reads; B.cap[1] = events; B.cap[2] = cap[2]; return 0; }
+      int run(nchmm::StrandBatch& B) { runs->fetch_add(1); const size_t n = B.used[0]; strands->fetch_add((long)n);
+        for (size_t r = 0; r < n; ++r) { for (uint64_t e = B.off[r]; e < B.off[r + 1]; ++e) B.states[e] = (uint16_t)((unsigned)B.cm[e] & 4095u);
           B.logp[r] = B.images[r * nchmm::kImageFloats + 17] + B.p_skip[r] * 8.f + B.p_stay[r]; B.status[r] = (B.off[r + 1] - B.off[r]) % 7 == 3 ? -6 : 0; }
         std::this_thread::sleep_for(std::chrono::microseconds(300)); return 0; } };
     std::atomic<long> runs{0}, strands{0}, bad{0};
