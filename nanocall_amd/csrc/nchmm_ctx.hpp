@@ -24,10 +24,7 @@ namespace nchmm {
 // reads per batch: 220 Mevents/s on two lanes, 301 on three).  Four lanes + the copy-in stream + the caller's are more
 // streams than the runtime has hardware queues for (4): streams then share a queue and wait for each other (267; config 2
 // drops from 343 to 324) -- profiles/r04_lanes_ab.txt.
-#ifndef NCHMM_VIT_LANES
-#define NCHMM_VIT_LANES 3
-#endif
-constexpr int kVitLanes = NCHMM_VIT_LANES;
+constexpr int kVitLanes = 3;
 struct VitLaneState {
     hipStream_t stream = nullptr;
     unsigned vq_base = 0;            // what this lane's queue head will read when its next launch starts (never reset)

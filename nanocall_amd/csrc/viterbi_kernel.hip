@@ -59,9 +59,7 @@ namespace {
 
 typedef unsigned long long mask_t;
 constexpr unsigned kChunk = 256;   // events staged in LDS at a time
-#ifndef NCHMM_TB_PRIO
-#define NCHMM_TB_PRIO 3
-#endif
+constexpr int kTbPrio = 3;         // wave priority during the in-block traceback (tools/ubench/vit_ab_defs.sh: 0 and 3 measure the same)
 
 struct __attribute__((aligned(8))) ValSlot {
     float v;
@@ -435,10 +433,7 @@ __device__ __forceinline__ unsigned pred_of(unsigned j, unsigned slot, unsigned&
 // out once per round, contiguously.
 constexpr int kTbLanes = 4;
 constexpr int kTbSegs = kThreads / kTbLanes;   // 128 segments per round
-#ifndef NCHMM_TB_SEG
-#define NCHMM_TB_SEG 80
-#endif
-constexpr int kTbSeg = NCHMM_TB_SEG;           // events a segment owns
+constexpr int kTbSeg = 80;                     // events a segment owns (40 / 80 / 128 measured: profiles/r04_inblock_tb_params_ab.txt)
 
 struct __attribute__((aligned(16))) TbShared {
     uint8_t stage[kTbSegs][kTbLanes][16];
@@ -764,7 +759,7 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
         __syncthreads();   // sLast is there; the tables of this read are dead: the traceback's staging takes their place
         // the walk issues a few dozen instructions per memory round trip: at top priority it loses no time to the other
         // block's sweep (which loses nothing measurable in return)
-        __builtin_amdgcn_s_setprio(NCHMM_TB_PRIO);
+        __builtin_amdgcn_s_setprio(kTbPrio);
         traceback_block(P, sTb, ws, r, e0, (int)n, sLast);
         __builtin_amdgcn_s_setprio(0);
         if (P.prof) {

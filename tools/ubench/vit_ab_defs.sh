@@ -1,7 +1,7 @@
-# Viterbi kernel A/B on one box over preprocessor switches of the tree's viterbi_kernel.hip (NCHMM_VIT_SKEW, NCHMM_TB_PRIO, ...):
-# for every argument (a quoted list of -D flags; "" = the tree) the kernel is rebuilt with it, the library relinked, and bench.py
-# run REPS times with overlapping steps and once with --serial-launches; the tree is restored at the end.
-#   bash tools/ubench/vit_ab_defs.sh "" "-DNCHMM_VIT_SKEW=768" "-DNCHMM_TB_PRIO=0"
+# Viterbi kernel A/B on one box over the named constants of the tree's viterbi_kernel.hip (kTbSeg, kTbPrio, ...): for every
+# argument (a space-separated list of NAME=VALUE; "" = the tree) a COPY of the kernel with those constants edited is compiled, the
+# library relinked, and bench.py run REPS times with overlapping and once with serialised steps; the tree's object is rebuilt at the end.
+#   bash tools/ubench/vit_ab_defs.sh "" "kTbSeg=40" "kTbPrio=0"         (product sources carry no switches: the edit is made here)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 REPS=${REPS:-3}
 cd $R/nanocall_amd/csrc
@@ -15,7 +15,13 @@ run() { (cd $R && for i in $(seq $REPS); do python bench.py --steps 20 --warmup 
         [ -n "${PROFILE:-}" ] && NCHMM_PROFILE=1 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fwbw --no-end-to-end --serial-launches ${BENCH_ARGS:-} 2>&1 >/dev/null | grep -E "phase ticks|blocks\]" ); }
 for D in "$@"; do
   echo "== variant [$D]"
-  /opt/rocm/bin/hipcc $FLAGS $D -c viterbi_kernel.hip -o viterbi_kernel.o && make -s > /dev/null 2>&1 && run
+  cp viterbi_kernel.hip /tmp/viterbi_variant.hip
+  for kv in $D; do
+    name=${kv%%=*}; val=${kv#*=}
+    grep -q "constexpr [a-z ]* $name = " /tmp/viterbi_variant.hip || { echo "no constant $name in viterbi_kernel.hip"; continue 2; }
+    sed -i "s/\(constexpr [a-z ]* $name = \)[0-9]*;/\1$val;/" /tmp/viterbi_variant.hip
+  done
+  /opt/rocm/bin/hipcc $FLAGS -I$R/nanocall_amd/csrc -c /tmp/viterbi_variant.hip -o viterbi_kernel.o && make -s > /dev/null 2>&1 && run
 done
 rm -f viterbi_kernel.o; make -s > /dev/null 2>&1
 echo "== tree restored"
