@@ -605,7 +605,18 @@ __global__ __launch_bounds__(kThreads, NCHMM_MIN_WAVES) void viterbi_kernel(Vite
     __syncthreads();
     const unsigned my_slot = sWork;
     if (my_slot == kNoSlot) {
-        if (tau == 0 && P.host_err) { __hip_atomic_store(P.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        // no region: report, and take tickets like any other block so that the lane's ticket count stays what the host expects
+        // (every launch draws n_reads + grid of them) -- the reads this block draws are marked failed, not left stale
+        if (tau == 0) {
+            if (P.host_err) __hip_atomic_store(P.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (;;) {
+                const unsigned widx = atomicAdd(P.queue, 1u) - P.queue_base;
+                if (widx >= P.n_reads) break;
+                const unsigned r = P.order ? P.order[widx] : P.first_read + widx;
+                P.out_logp[r] = __builtin_nanf("");
+                if (P.out_status) P.out_status[r] = -3;   // NCHMM_E_HIP
+            }
+        }
         return;
     }
     uint8_t* const ws = P.ws + (uint64_t)my_slot * P.slot_bytes;

@@ -140,11 +140,13 @@ out = {}
 with na.Context(0) as ctx:
     ctx.put_model(0, na.scaled_model_table(t, IDENT)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
     t0 = time.time()
-    try:
-        ctx.viterbi(off, cm, sd, ls)
-        out["raised"] = False
-    except na.NchmmError as e:
-        out["raised"] = True; out["code"] = e.code
+    out["codes"] = []
+    for attempt in range(2):          # the second launch must find the lane's ticket count where the host expects it
+        try:
+            ctx.viterbi(off, cm, sd, ls)
+            out["codes"].append(0)
+        except na.NchmmError as e:
+            out["codes"].append(e.code)
     out["seconds"] = round(time.time() - t0, 2)
 print(json.dumps(out))
 """
@@ -159,7 +161,7 @@ def test_a_pool_without_free_regions_fails_loudly_and_in_bounded_time():
     assert p.returncode == 0, p.stderr[-3000:]
     import json
     out = json.loads(p.stdout.strip().splitlines()[-1])
-    assert out["raised"] and out["code"] == -3 and out["seconds"] < 30, out      # NCHMM_E_HIP
+    assert out["codes"] == [-3, -3] and out["seconds"] < 30, out      # NCHMM_E_HIP, both times
 
 
 def test_one_strand_per_call_from_many_threads_is_combined_and_exact(r73t, r9t):
