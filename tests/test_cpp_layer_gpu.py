@@ -158,3 +158,20 @@ def test_reference_call_sites_train_loop_and_basecall_strand(tmp_path):
             states, mv, lp = oracle.viterbi(om, ot, cm, sd, ls)
             assert np.float32(float.fromhex(f[2])).tobytes() == np.float32(lp).tobytes()
             assert f[3] == oracle.base_seq(states, mv)
+
+
+def test_header_swap_call_sites_from_many_threads_are_exact(tool):
+    """The reference's call shapes kept as they are, from pfor-like worker threads (tools/bench_cpp_layer, bench_train_threads):
+    Viterbi::fill on one strand per call with the thread's own copy of the model -- every strand's states and path probability
+    equal to what fill_batch decoded -- and Parameter_Trainer::train_one_round on one read per call -- every fit equal to the
+    single-threaded run (nchmm_viterbi_strand / nchmm_fwbw_windows combine the calls; the kernels treat reads independently)."""
+    import json
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "bench_cpp_layer", "bench_train_threads"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(ROOT, "tools", "bench_cpp_layer"), "160", "700", "48"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["mismatches_vs_fill_batch"] == 0 and "48 worker threads" in out["what"], out
+    r = subprocess.run([os.path.join(ROOT, "tools", "bench_train_threads"), "300", "1", "40"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    assert len(lines) == 2 and all(l["fits_differing_from_first_run"] == 0 for l in lines), lines
