@@ -229,3 +229,28 @@ def test_training_windows_per_call_from_many_threads_equal_one_batched_call(r73t
             want = ref.fwbw(R["off"], R["cm"], R["sd"], R["ls"], scaled_slot=R["wm"], pm_params=R["pm"], trans_slot=R["wm"], st_params=R["stp"])
             for k in ("log_pr_data", "pm_sums", "st_sums"):
                 assert G[k].tobytes() == want[k].tobytes(), k
+
+
+def test_combined_calls_edge_shapes(r73t):
+    """nchmm_viterbi_strand on an empty and a one-event strand, nchmm_fwbw_windows on a one-event window and on a call with an
+    empty window between two others: the same answers as the batched entry points."""
+    tab = na.scaled_model_table(r73t, IDENT)
+    with na.Context(0) as ctx:
+        ctx.put_model(0, tab)
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        z = np.zeros(0, np.float32)
+        s, lp, rc = ctx.viterbi_strand(tab, 0.3, 0.1, z, z, z)
+        assert rc == 0 and np.isnan(lp) and len(s) == 0
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [1], first_read=3)
+        s, lp, rc = ctx.viterbi_strand(tab, 0.3, 0.1, cm, sd, ls)
+        ost, olp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        assert rc == 0 and np.array_equal(s, ost) and np.float32(lp).tobytes() == olp[0].tobytes()
+        un = [na.model_load(r73t)]
+        for lens in ([1], [5, 0, 7]):
+            off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=9)
+            zero = np.zeros(len(lens), np.int32)
+            g = ctx.fwbw_windows(un, IDENT, [0.3], [0.1], off, cm, sd, ls, zero)
+            w = ctx.fwbw(off, cm, sd, ls, scaled_slot=zero, pm_params=IDENT, trans_slot=zero, st_params=np.tile(np.float32([0.1, 0.3]), (len(lens), 1)))
+            for k in ("log_pr_data", "pm_sums", "st_sums"):
+                same = (g[k].view(np.uint32) == w[k].view(np.uint32)) | (np.isnan(g[k]) & np.isnan(w[k]))
+                assert same.all(), (lens, k)

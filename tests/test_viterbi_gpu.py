@@ -403,3 +403,17 @@ def test_product_before_torch_shares_one_hip_runtime(tmp_path):
     p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.strip().startswith("ok"), p.stdout
+
+
+def test_read_lengths_around_the_traceback_geometry(gpu_ctx, r73t):
+    """The in-block traceback walks 128 segments of up to 80 events per round (10 240 events): reads one event either side of a
+    segment, of a round and of two rounds, all-empty batches and reads of one to three events -- each against the oracle."""
+    gpu_ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+    gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    for lens in ([0, 0, 0], [1], [2], [1, 0, 2, 3], [79, 80, 81, 82, 160, 161, 10239, 10240, 10241, 10242, 20481]):
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, lens, first_read=7)
+        st, lp, status = gpu_ctx.viterbi(off, cm, sd, ls)
+        ost, olp = oracle_viterbi_batch(r73t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+        nz = np.asarray(lens) > 0
+        assert np.array_equal(st, ost), lens
+        assert lp[nz].tobytes() == olp[nz].tobytes() and np.isnan(lp[~nz]).all() and (status == 0).all(), lens
