@@ -273,6 +273,7 @@ int nchmm_create(nchmm_ctx** out, int device_id)
             || hipEventCreateWithFlags(&c->lane[l].done, hipEventDisableTiming) != hipSuccess)
             return fail(NCHMM_E_HIP);
     if (hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming) != hipSuccess) return fail(NCHMM_E_HIP);
+    if (hipEventCreateWithFlags(&c->ev_big, hipEventDisableTiming) != hipSuccess) return fail(NCHMM_E_HIP);
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocDefault) != hipSuccess) return fail(NCHMM_E_HIP);
@@ -349,6 +350,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_slot_owner) (void)hipFree(c->d_slot_owner);
+    if (c->d_ws_big) (void)hipFree(c->d_ws_big);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_fb_aux) (void)hipFree(c->d_fb_aux);
@@ -365,6 +367,7 @@ int nchmm_destroy(nchmm_ctx* c)
         if (l > 0 && c->lane[l].stream) (void)hipStreamDestroy(c->lane[l].stream);
     }
     if (c->ev_entry) (void)hipEventDestroy(c->ev_entry);
+    if (c->ev_big) (void)hipEventDestroy(c->ev_big);
     if (c->ev_fb0) (void)hipEventDestroy(c->ev_fb0);
     if (c->ev_fb1) (void)hipEventDestroy(c->ev_fb1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -616,22 +619,45 @@ int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count)
 
 hipStream_t viterbi_next_lane_stream(nchmm_ctx* c) { return c->lane[c->ws_pooled ? c->next_lane : 0].stream; }
 
-int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
-                         const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
-                         const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status, int* lane_out)
+// The outliers of a batch.  Reads too long for regions of which the whole pool fits the budget get a few regions of their own
+// (one block per region, region = block index), so that one 300 000-event read does not put the whole batch on a tenth of the
+// GPU: the rest goes through the pool as usual and the outliers run beside it as one more launch (launch_viterbi_outliers).
+int viterbi_big_prepare(nchmm_ctx* c, uint64_t longest, size_t n_long, size_t budget_big)
 {
-    if (!c->d_ws) return NCHMM_E_INVALID;
-    // without a pool every launch owns regions 0 .. grid-1: one lane, strictly one launch after the other
-    const int li = c->ws_pooled ? c->next_lane : 0;
+    const size_t need = ((size_t)std::max<uint64_t>(longest, 1) * kBpRowBytes + 4095) & ~(size_t)4095;
+    const size_t regions = std::min<size_t>(std::min<size_t>(std::max<size_t>(n_long, 1), (size_t)std::max(c->vit_slots, 1)), std::max<size_t>(budget_big / need, 1));
+    if (c->d_ws_big && need <= c->big_slot_bytes && regions <= c->big_regions) return NCHMM_OK;
+    for (int l = 0; l < kVitLanes; ++l)      // (re)allocate: a launch of outliers may be using the regions
+        if (c->lane[l].pending) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+    if (c->d_ws_big) {
+        HIP_TRY(c, hipFree(c->d_ws_big));
+        c->counters[6] -= c->big_slot_bytes * c->big_regions;
+        c->d_ws_big = nullptr; c->big_slot_bytes = 0; c->big_regions = 0;
+    }
+    void* p = nullptr;
+    const int rc = dev_alloc(c, &p, need * regions);
+    if (rc != NCHMM_OK) return rc;
+    c->d_ws_big = (uint8_t*)p; c->big_slot_bytes = need; c->big_regions = (unsigned)regions;
+    return NCHMM_OK;
+}
+
+namespace {
+
+// One launch on the next lane.  pooled: regions from the pool (ws / slot_bytes / per_xcd of the context); else region = block
+// index in `ws`, at most `regions` blocks, and `serial_after` (may be null) = the launch that used those regions before.
+int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_bytes, size_t regions, hipEvent_t after, hipEvent_t serial_after,
+                        size_t first, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean, const float* d_stdv,
+                        const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
+                        uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int li, int* lane_out)
+{
     VitLaneState& L = c->lane[li];
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
     a.models = c->d_models; a.trans = c->d_trans; a.model_fast = c->d_model_fast;
     a.prof = c->profile ? c->d_prof : nullptr;
-    a.ws = c->d_ws; a.slot_bytes = c->slot_bytes;
-    a.slot_owner = c->ws_pooled ? c->d_slot_owner : nullptr; a.slots_per_xcd = c->ws_per_xcd;
+    a.ws = ws; a.slot_bytes = slot_bytes;
+    a.slot_owner = pooled ? c->d_slot_owner : nullptr; a.slots_per_xcd = c->ws_per_xcd;
     a.host_err = c->h_err;
     a.first_read = (unsigned)first;
     a.out_state = d_out_state; a.out_logp = d_out_logp; a.out_status = d_out_status;
@@ -641,12 +667,12 @@ int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t co
     a.tb_margin = c->tb_margin;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
-    const size_t slots = c->ws_pooled ? (size_t)c->vit_slots : (size_t)c->ws_regions;
+    const size_t slots = pooled ? (size_t)c->vit_slots : regions;
     const int grid = (int)std::min<size_t>(slots, count);
     a.queue_base = L.vq_base;
     L.vq_base += (unsigned)count + (unsigned)grid;   // every read takes a ticket, every block one more to find the queue empty
     if (after) HIP_TRY(c, hipStreamWaitEvent(L.stream, after, 0));
-    if (!c->ws_pooled && c->last_lane >= 0 && c->last_lane != li) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->lane[c->last_lane].done, 0));
+    if (serial_after) HIP_TRY(c, hipStreamWaitEvent(L.stream, serial_after, 0));
     HIP_TRY(c, hipEventRecord(L.ev0, L.stream));
     launch_viterbi(a, grid, L.stream);
     HIP_TRY(c, hipGetLastError());
@@ -658,6 +684,38 @@ int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t co
     c->vit_timed = true;
     c->counters[2] += (uint64_t)(ev_count > count ? ev_count - count : 0) * kBpRowBytes;
     c->counters[3] += 1;
+    if (lane_out) *lane_out = li;
+    return NCHMM_OK;
+}
+
+}  // namespace
+
+int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
+                         const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                         const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out)
+{
+    if (!c->d_ws) return NCHMM_E_INVALID;
+    // without a pool every launch owns regions 0 .. grid-1: one lane, strictly one launch after the other
+    const int li = c->ws_pooled ? c->next_lane : 0;
+    hipEvent_t serial = (!c->ws_pooled && c->last_lane >= 0 && c->last_lane != li) ? c->lane[c->last_lane].done : nullptr;
+    return launch_on_next_lane(c, c->ws_pooled, c->d_ws, c->slot_bytes, c->ws_regions, after, serial, first, count, ev_count, d_off, d_cmean, d_stdv,
+                               d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status, li, lane_out);
+}
+
+// The outliers of a batch (d_order lists them): one block per region of d_ws_big, behind the previous launch of outliers.
+int launch_viterbi_outliers(nchmm_ctx* c, hipEvent_t after, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean,
+                            const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
+                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out)
+{
+    if (!c->d_ws_big || !d_order || !c->ws_pooled) return NCHMM_E_INVALID;
+    int li = 0;
+    const int rc = launch_on_next_lane(c, false, c->d_ws_big, c->big_slot_bytes, c->big_regions, after, c->big_pending ? c->ev_big : nullptr, 0, count, ev_count,
+                                       d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status,
+                                       c->next_lane, &li);
+    if (rc != NCHMM_OK) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_big, c->lane[li].stream));
+    c->big_pending = true;
     if (lane_out) *lane_out = li;
     return NCHMM_OK;
 }

@@ -65,6 +65,11 @@ struct nchmm_ctx {
     size_t slot_bytes = 0;
     unsigned ws_regions = 0;
     bool ws_pooled = false;         // regions are handed out by the blocks themselves (per XCD): launches may overlap
+    uint8_t* d_ws_big = nullptr;    // regions for the outliers of a batch (reads too long for the pool): big_regions x big_slot_bytes
+    size_t big_slot_bytes = 0;
+    unsigned big_regions = 0;
+    hipEvent_t ev_big = nullptr;    // behind the most recent launch of outliers (they use regions 0 .. grid-1: one at a time)
+    bool big_pending = false;
     unsigned* d_slot_owner = nullptr;   // [kXcds][slots_per_xcd]
     unsigned slots_per_xcd = 0;     // capacity of the owner table per XCD
     unsigned ws_per_xcd = 0;        // regions per XCD the workspace holds now (<= slots_per_xcd)
@@ -114,6 +119,10 @@ int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t co
                          const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
                          float* d_out_logp, int32_t* d_out_status, int* lane_out);
+int viterbi_big_prepare(nchmm_ctx* c, uint64_t longest, size_t n_long, size_t budget_big);
+int launch_viterbi_outliers(nchmm_ctx* c, hipEvent_t after, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean,
+                            const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
+                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out);
 // The stream of the lane the NEXT launch_viterbi_range will use (for kernels that must run in front of it).
 hipStream_t viterbi_next_lane_stream(nchmm_ctx* c);
 // Make `s` wait for everything queued on the lanes; then 1 if a block reported a pool failure.

@@ -196,6 +196,38 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     for (const PipeRange& g : K.ranges)
         std::stable_sort(order.begin() + g.r0, order.begin() + g.r1,
                          [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    // Outliers.  When the longest read is too long for a full pool of regions within the budget, but only a few reads are that
+    // long, those few go through regions of their own as one more launch (launch_viterbi_outliers) and the pool is sized for
+    // the rest; otherwise (most reads long, or none too long) everything goes the usual way.
+    size_t biggest = 1;
+    for (const PipeRange& g : K.ranges) biggest = std::max(biggest, g.r1 - g.r0);
+    uint64_t pool_longest = longest;          // what the pool's regions must hold
+    std::vector<uint32_t> outliers;           // read indices, longest first
+    std::vector<size_t> n_out(n_ranges, 0);   // per range: how many of its (sorted) reads are outliers -- a prefix of its order
+    {
+        size_t budget = 0;
+        if ((rc = viterbi_ws_budget(c, &budget))) return rc;
+        const size_t pool = (size_t)kXcds * std::min<size_t>(c->slots_per_xcd, biggest * kVitLanes);
+        if ((size_t)longest * kBpRowBytes > budget / pool) {
+            const uint64_t small_cap = (uint64_t)(budget / 10 * 7 / pool / kBpRowBytes);   // events a pooled region may hold
+            size_t n_long = 0;
+            uint64_t longest_short = 1;
+            for (size_t r = 0; r < n; ++r) {
+                const uint64_t len = off[r + 1] - off[r];
+                if (len > small_cap) ++n_long; else longest_short = std::max(longest_short, len);
+            }
+            if (small_cap >= 256 && n_long * 8 <= n) {
+                pool_longest = longest_short;
+                for (size_t k = 0; k < n_ranges; ++k) {
+                    const PipeRange& g = K.ranges[k];
+                    while (g.r0 + n_out[k] < g.r1 && off[order[g.r0 + n_out[k]] + 1] - off[order[g.r0 + n_out[k]]] > small_cap) ++n_out[k];
+                    outliers.insert(outliers.end(), order.begin() + g.r0, order.begin() + g.r0 + n_out[k]);
+                }
+                std::stable_sort(outliers.begin(), outliers.end(), [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+                if ((rc = viterbi_big_prepare(c, longest, outliers.size(), budget / 10 * 3))) return rc;
+            }
+        }
+    }
     if (raw) {
         uint64_t hi = 0;
         for (PipeRange& g : K.ranges) {
@@ -211,7 +243,8 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     // Pinned host block:  [ small (as above) | logp | status | state ]   (the outputs: streaming form only)
     const size_t n_raw = raw ? raw->n_raw : 0;
     size_t o_off = 0, o_ms = o_off + al256(8 * (n + 1)), o_ts = o_ms + al256(4 * n), o_or = o_ts + al256(4 * n);
-    size_t o_src = o_or + al256(4 * n), o_dr = o_src + (raw ? al256(8 * n) : 0);
+    size_t o_ol = o_or + al256(4 * n);        // the outliers' list
+    size_t o_src = o_ol + al256(4 * outliers.size()), o_dr = o_src + (raw ? al256(8 * n) : 0);
     const size_t small_bytes = std::max<size_t>(o_dr + (raw ? al256(4 * n) : 0), kMinCopy);
     size_t o_cm = small_bytes, o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total);
     size_t o_rm = o_ls + al256(4 * total), o_rs = o_rm + al256(4 * n_raw), o_rt = o_rs + al256(4 * n_raw);
@@ -239,9 +272,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         HIP_TRY(c, hipHostMalloc(&hp, h_need + h_need / 8, hipHostMallocDefault));
         K.h = (char*)hp; K.h_bytes = h_need + h_need / 8;
     }
-    size_t biggest = 1;
-    for (const PipeRange& g : K.ranges) biggest = std::max(biggest, g.r1 - g.r0);
-    if ((rc = viterbi_ws_prepare(c, longest, biggest))) return rc;   // (waits for the batch in flight if the regions must grow)
+    if ((rc = viterbi_ws_prepare(c, pool_longest, biggest))) return rc;   // (waits for the batch in flight if the regions must grow)
     char* const d = (char*)P->d_stage[slot];
     K.direct = direct; K.n = n; K.total = total; K.d = d;
     K.o_state = o_st; K.o_logp = o_lp; K.o_status = o_ss;
@@ -273,6 +304,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     if (model_slot) std::memcpy(K.h + o_ms, model_slot, 4 * n);
     if (trans_slot) std::memcpy(K.h + o_ts, trans_slot, 4 * n);
     std::memcpy(K.h + o_or, order.data(), 4 * n);
+    if (!outliers.empty()) std::memcpy(K.h + o_ol, outliers.data(), 4 * outliers.size());
     if (raw) {
         std::memcpy(K.h + o_src, raw->src, 8 * n);
         std::memcpy(K.h + o_dr, raw->drift, 4 * n);
@@ -285,6 +317,8 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         for (size_t v = 0; v < n; ++v) { c->model_set[v] = 1; c->trans_set[v] = 1; }
     }
     uint64_t raw_up = 0;
+    std::vector<int> range_lane(n_ranges, 0);
+    std::vector<hipEvent_t> range_ev(n_ranges, nullptr);
     for (size_t k = 0; k < n_ranges; ++k) {
         const PipeRange& g = K.ranges[k];
         const size_t ne = (size_t)(g.e1 - g.e0);
@@ -353,15 +387,50 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
             launch_em_gather(ga, (unsigned)(g.r1 - g.r0), sl, (unsigned)g.max_events);
             HIP_TRY(c, hipGetLastError());
         }
-        int lane = 0;
-        rc = launch_viterbi_range(c, nullptr, g.r0, g.r1 - g.r0, g.e1 - g.e0,
-                                  (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
-                                  (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
-                                  trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or) + g.r0, k_state, k_logp,
-                                  k_status, &lane);
+        if (!outliers.empty()) {
+            // what the outliers' launch waits for: this range's copy-in, gather and tables (not its launch)
+            if ((rc = pipe_event(c, K, &range_ev[k]))) return rc;
+            HIP_TRY(c, hipEventRecord(range_ev[k], sl));
+        }
+        int lane = (int)(k % kVitLanes);
+        if (g.r1 - g.r0 > n_out[k]) {
+            rc = launch_viterbi_range(c, nullptr, g.r0, g.r1 - g.r0 - n_out[k], g.e1 - g.e0,
+                                      (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
+                                      (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
+                                      trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or) + g.r0 + n_out[k], k_state, k_logp,
+                                      k_status, &lane);
+            if (rc != NCHMM_OK) return rc;
+        } else {
+            // (a range of outliers only: what was queued in front of its launch -- tables, gather -- is on stream sl)
+            for (int l = 0; l < kVitLanes; ++l) if (c->lane[l].stream == sl) lane = l;
+        }
+        range_lane[k] = lane;
+        if (outliers.empty()) {
+            if ((rc = pipe_event(c, K, &K.done[k]))) return rc;
+            HIP_TRY(c, hipEventRecord(K.done[k], c->lane[lane].stream));
+        }
+    }
+    if (!outliers.empty()) {
+        // one more launch for the outliers of all ranges, then the ranges' completion events behind it (a range is complete when
+        // its outliers are)
+        hipStream_t so = viterbi_next_lane_stream(c);
+        for (size_t k = 0; k < n_ranges; ++k) HIP_TRY(c, hipStreamWaitEvent(so, range_ev[k], 0));   // (the outliers' events, gathered or copied in, and tables)
+        int lane_o = 0;
+        uint64_t ev_out = 0;
+        for (uint32_t r : outliers) ev_out += off[r + 1] - off[r];
+        rc = launch_viterbi_outliers(c, nullptr, outliers.size(), ev_out, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
+                                     (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
+                                     trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_ol), k_state, k_logp, k_status, &lane_o);
         if (rc != NCHMM_OK) return rc;
-        if ((rc = pipe_event(c, K, &K.done[k]))) return rc;
-        HIP_TRY(c, hipEventRecord(K.done[k], c->lane[lane].stream));
+        hipEvent_t ev_o;
+        if ((rc = pipe_event(c, K, &ev_o))) return rc;
+        HIP_TRY(c, hipEventRecord(ev_o, c->lane[lane_o].stream));
+        for (size_t k = 0; k < n_ranges; ++k) {
+            hipStream_t sk = c->lane[range_lane[k]].stream;
+            if (n_out[k]) HIP_TRY(c, hipStreamWaitEvent(sk, ev_o, 0));
+            if ((rc = pipe_event(c, K, &K.done[k]))) return rc;
+            HIP_TRY(c, hipEventRecord(K.done[k], sk));
+        }
     }
     c->counters[0] += n;
     c->counters[1] += total;

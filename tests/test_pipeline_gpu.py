@@ -254,3 +254,45 @@ def test_combined_calls_edge_shapes(r73t):
             for k in ("log_pr_data", "pm_sums", "st_sums"):
                 same = (g[k].view(np.uint32) == w[k].view(np.uint32)) | (np.isnan(g[k]) & np.isnan(w[k]))
                 assert same.all(), (lens, k)
+
+
+_OUTLIER_CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["NC_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NC_ROOT"], "tests")); sys.path.insert(0, os.path.join(os.environ["NC_ROOT"], "oracle"))
+import nanocall_amd as na
+from helpers import IDENT, ragged_batch, oracle_viterbi_batch
+t = na.builtin_model("r73.t")
+rng = np.random.default_rng(3)
+lens = [int(x) for x in rng.integers(40, 400, 60)]
+lens[7] = 5200; lens[41] = 3900; lens[59] = 0          # two outliers (and an empty read) among short reads
+off, mean, stdv, start, cm, sd, ls = ragged_batch(t, lens, first_read=77)
+with na.Context(0) as ctx:
+    ctx.put_model(0, na.scaled_model_table(t, IDENT)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    st, lp, status = ctx.viterbi(off, cm, sd, ls)
+    launches = int(ctx.counters()[3])
+    src = off[:-1].astype(np.uint64); ln = np.diff(off.astype(np.int64)).astype(np.uint32)
+    st2, lp2, status2 = ctx.viterbi_raw(mean, stdv, start, src, ln, np.zeros(len(lens), np.float32))
+    t1 = ctx.viterbi_begin(off, cm, sd, ls); t2 = ctx.viterbi_begin(off, cm, sd, ls)      # two batches with outliers in flight
+    r1 = ctx.viterbi_end(t1); r2 = ctx.viterbi_end(t2)
+    peak = ctx.mem_stats()[1]
+ost, olp = oracle_viterbi_batch(t, IDENT, 0.3, 0.1, off, cm, sd, ls)
+nz = np.diff(off.astype(np.int64)) > 0
+same = lambda s, l: bool(np.array_equal(s, ost) and l[nz].tobytes() == olp[nz].tobytes())
+print(json.dumps({"launches": launches, "one_call": same(st, lp), "raw": same(st2, lp2), "streamed": same(*r1[:2]) and same(*r2[:2]),
+                  "status_ok": bool((status == 0).all() and (status2 == 0).all()), "peak_mb": peak >> 20}))
+"""
+
+
+def test_a_few_very_long_reads_get_regions_of_their_own():
+    """Under a workspace budget in which a full pool of regions cannot hold the longest read (2 GB: 576 regions of ~590 events),
+    the two reads that are longer go through regions of their own as one more launch beside the pooled one, instead of putting the
+    whole batch on a handful of blocks: same decode as the oracle through the one-call, the raw and the streaming forms, and the
+    workspace stays inside the budget."""
+    env = dict(os.environ, NCHMM_WS_BUDGET_MB="2000", NC_ROOT=ROOT)
+    p = subprocess.run([sys.executable, "-c", _OUTLIER_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["launches"] == 2 and out["one_call"] and out["raw"] and out["streamed"] and out["status_ok"], out
+    assert out["peak_mb"] < 2300, out
