@@ -431,14 +431,14 @@ def main():
         else:
             ctx.viterbi_dev_enqueue(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, *o)
 
-    # Untimed, before the W warm-up steps: launches until the kernel time has settled (three in a row within 1.5 %, at most 30).
-    # A GPU that comes out of idle -- a fresh lease, or a profiler session that has just ended -- takes anything from 50 to several
-    # hundred ms of load to reach the clock it then holds (profiles/r04_hostpath_gap.json); W = 5 steps are 75 ms.
+    # Untimed, before the W warm-up steps: launches until the kernel time has settled (at least 8, then four in a row within 1 %,
+    # at most 40).  A GPU that comes out of idle -- a fresh lease, or a profiler session that has just ended -- takes anything from
+    # 50 to several hundred ms of load to reach the clock it then holds (profiles/r04_hostpath_gap.json); W = 5 steps are 75 ms.
     settle = []
-    for _ in range(30):
+    for _ in range(40):
         ctx.viterbi_dev(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, *outs[0])
         settle.append(ctx.last_kernel_ms()[0])
-        if len(settle) >= 3 and max(settle[-3:]) <= 1.015 * min(settle[-3:]):
+        if len(settle) >= 8 and max(settle[-4:]) <= 1.01 * min(settle[-4:]):
             break
     c_settle = [int(x) for x in ctx.counters()]      # (the reported counters cover warm-up + timed steps, as before)
     for _ in range(args.warmup):
