@@ -338,7 +338,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--serial-launches", action="store_true",
                     help="queue every step behind the previous one (nchmm_viterbi_dev) instead of letting consecutive steps roll into "
-                         "each other on the context's two lanes (nchmm_viterbi_dev_enqueue / _join); profiling runs use it so that "
+                         "each other on the context's three lanes (nchmm_viterbi_dev_enqueue / _join); profiling runs use it so that "
                          "every kernel's duration in the trace is its own")
     ap.add_argument("--events", type=int, default=5000, help="events per read")
     ap.add_argument("--model", default="r73.t")
@@ -418,7 +418,7 @@ def main():
     d_state, d_logp, d_status = outs[0]
 
     # A step = one batch through the hot path: viterbi_kernel sweeps every read and each block walks its read back as soon as
-    # the last column is done.  The steps are queued with nchmm_viterbi_dev_enqueue on the context's two lanes and joined once
+    # the last column is done.  The steps are queued with nchmm_viterbi_dev_enqueue on the context's three lanes and joined once
     # at the end: the blocks of step k+1 start where the blocks of step k run out of reads, so no CU waits for the slowest
     # block of a step (what a caller with more than one batch does; --serial-launches queues each step behind the previous one).
     n_step = [0]
