@@ -233,9 +233,9 @@ public:
     static const unsigned n_states = 1u << (2 * Kmer_Size);
 
     Pore_Model() : _strand(2) {}
-    void clear() { _state.clear(); }
+    void clear() { _state.clear(); _origin.reset(); _n_scale = 0; }
     const Pore_Model_State_Type& state(unsigned i) const { return _state.at(i); }
-    Pore_Model_State_Type& state(unsigned i) { return _state.at(i); }
+    Pore_Model_State_Type& state(unsigned i) { _origin.reset(); return _state.at(i); }   // (edited by hand: no longer "a loaded model scaled once")
     const std::vector<Pore_Model_State_Type>& get_state_vector() const { return _state; }   // Pore_Model.hpp:183
     // the library's S x 10 layout (nchmm_put_models_scaled, nchmm_train_reads, ... take tables in this form)
     const float* data() const { return reinterpret_cast<const float*>(_state.data()); }
@@ -252,12 +252,26 @@ public:
         _state.resize(n_states);
         check(nchmm_model_load(t.data(), reinterpret_cast<float*>(_state.data())), "nchmm_model_load");
         update_statistics();
+        // the loaded states, shared by every copy of this model: a copy that is then scaled once -- `pm = models.at(name);
+        // pm.scale(pm_params)`, nanocall.cpp:653-657 -- can tell the library "this table, these parameters" (provenance())
+        _origin = std::make_shared<const std::vector<Pore_Model_State_Type>>(_state);
+        _n_scale = 0;
     }
     void scale(const Pore_Model_Parameters_Type& p)   // Pore_Model.hpp:190-201
     {
         const float par[6] = {p.scale, p.shift, p.drift, p.var, p.scale_sd, p.var_sd};
         check(nchmm_model_scale(reinterpret_cast<float*>(_state.data()), par), "nchmm_model_scale");
         update_statistics();
+        if (_n_scale++ == 0) std::memcpy(_scaled_by, par, sizeof(par));
+    }
+    // (unscaled S x 10 states, parameters) when this model is a loaded model scaled at most once; false otherwise
+    bool provenance(const float** base, float p6[6]) const
+    {
+        if (!_origin || _n_scale > 1 || _origin->size() != _state.size()) return false;
+        *base = reinterpret_cast<const float*>(_origin->data());
+        const float ident[6] = {1, 0, 0, 1, 1, 1};
+        std::memcpy(p6, _n_scale ? _scaled_by : ident, sizeof(ident));
+        return true;
     }
     // Pore_Model.hpp:295-299 (host evaluation, for callers outside the DP such as debug dumps)
     Float_Type log_pr_corrected_emission(unsigned i, const Event_Type& e) const
@@ -318,6 +332,9 @@ public:
     }
 private:
     std::vector<Pore_Model_State_Type> _state;
+    std::shared_ptr<const std::vector<Pore_Model_State_Type>> _origin;
+    float _scaled_by[6] = {1, 0, 0, 1, 1, 1};
+    unsigned _n_scale = 0;
     Float_Type _mean = 0, _stdv = 0;
     unsigned _strand;
     void update_statistics()   // Pore_Model.hpp:307-313; alg::mean_stdv_of is hpptools (absent): nchmm_mean_stdv states what is assumed
@@ -498,13 +515,22 @@ public:
             return;
         }
         const size_t n = ev.size();
-        std::vector<float> t6(n_states * 6), soa(3 * n);
-        pm.pack6(t6.data());
+        std::vector<float> soa(3 * n);
         float* const cm = soa.data(); float* const sd = cm + n; float* const ls = sd + n;
         for (size_t i = 0; i < n; ++i) { cm[i] = ev[i].corrected_mean; sd[i] = ev[i].stdv; ls[i] = ev[i].log_stdv; }
         std::vector<uint16_t> s(n);
         float pp = 0;
-        const int rc = nchmm_viterbi_strand(Device::shared_ctx(Device::device_id()), t6.data(), st.p_skip(), st.p_stay(), n, cm, sd, ls, s.data(), &pp);
+        nchmm_ctx* const ctx = Device::shared_ctx(Device::device_id());
+        const float* base = nullptr; float p6[6];
+        int rc;
+        if (pm.provenance(&base, p6)) {
+            // a loaded model scaled once: the table and the parameters travel, Pore_Model::scale runs on the device
+            rc = nchmm_viterbi_strand_scaled(ctx, base, p6, st.p_skip(), st.p_stay(), n, cm, sd, ls, s.data(), &pp);
+        } else {
+            std::vector<float> t6(n_states * 6);
+            pm.pack6(t6.data());
+            rc = nchmm_viterbi_strand(ctx, t6.data(), st.p_skip(), st.p_stay(), n, cm, sd, ls, s.data(), &pp);
+        }
         if (rc != NCHMM_OK && rc != NCHMM_E_NUMERIC) check(rc, "nchmm_viterbi_strand");
         _path_probability = pp;
         if (rc == NCHMM_E_NUMERIC) return;   // reference has undefined behaviour here (Viterbi.hpp:125-141); leave events untouched

@@ -281,6 +281,12 @@ int nchmm_viterbi_dev_join(nchmm_ctx* ctx);
 int nchmm_viterbi_strand(nchmm_ctx* ctx, const float* table_Sx6, float p_skip, float p_stay, size_t n_events,
                          const float* corrected_mean, const float* stdv, const float* log_stdv, uint16_t* out_state,
                          float* out_path_logp);
+/* the same with the strand's model given as where it came from: an UNSCALED table (nchmm_model_load layout, valid during the call)
+ * and the Pore_Model_Parameters it is scaled by -- `pm = models.at(name); pm.scale(pm_params)` in basecall_strand (nanocall.cpp:653-657)
+ * -- so that 32 bytes travel instead of a 128 KiB image and Pore_Model::scale runs on the device (bit for bit) */
+int nchmm_viterbi_strand_scaled(nchmm_ctx* ctx, const float* unscaled_Sx10, const float* pm_params, float p_skip, float p_stay,
+                                size_t n_events, const float* corrected_mean, const float* stdv, const float* log_stdv,
+                                uint16_t* out_state, float* out_path_logp);
 int nchmm_model_image(const float* table_Sx6, float* image_8xS, int32_t* fast);
 int nchmm_put_model_images(nchmm_ctx* ctx, int first_slot, size_t n, const float* images_nx8xS, const int32_t* fast_n);
 

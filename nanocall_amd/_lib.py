@@ -67,6 +67,7 @@ SIGNATURES = {
     "nchmm_viterbi_dev_enqueue": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t] + [vp] * 10),
     "nchmm_viterbi_dev_join": (C.c_int, [vp]),
     "nchmm_viterbi_strand": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_size_t, vp, vp, vp, vp, vp]),
+    "nchmm_viterbi_strand_scaled": (C.c_int, [vp, vp, vp, C.c_float, C.c_float, C.c_size_t, vp, vp, vp, vp, vp]),
     "nchmm_fwbw_windows": (C.c_int, [vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 9),
     "nchmm_model_image": (C.c_int, [vp, vp, vp]),
     "nchmm_put_model_images": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp]),

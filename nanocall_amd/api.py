@@ -411,6 +411,18 @@ class Context:
             check(rc, "nchmm_viterbi_strand")
         return states, np.float32(lp.value), rc
 
+    def viterbi_strand_scaled(self, unscaled_states, pm_params, p_skip, p_stay, cmean, stdv, log_stdv):
+        """nchmm_viterbi_strand_scaled: as viterbi_strand, the model given as (unscaled S x 10 states from model_load, parameters)."""
+        un, pm6 = _f32(unscaled_states), _f32(pm_params)
+        cm, sd, ls = _f32(cmean), _f32(stdv), _f32(log_stdv)
+        n = cm.shape[0]
+        states = np.empty(n, np.uint16)
+        lp = C.c_float(0.0)
+        rc = lib().nchmm_viterbi_strand_scaled(self._h, _p(un), _p(pm6), C.c_float(p_skip), C.c_float(p_stay), n, _p(cm), _p(sd), _p(ls), _p(states), C.byref(lp))
+        if rc not in (0, -6):
+            check(rc, "nchmm_viterbi_strand_scaled")
+        return states, np.float32(lp.value), rc
+
     def viterbi_dev_join(self):
         check(lib().nchmm_viterbi_dev_join(self._h), "nchmm_viterbi_dev_join")
 

@@ -36,6 +36,9 @@ void debug_line(const char* what, size_t items, size_t events, std::chrono::stea
 struct StrandRunner {
     nchmm_ctx* c;
     std::vector<int32_t>* slots;   // 0, 1, 2, ... (strand k decodes with model slot k and transition slot k)
+    std::vector<const float*>* tables;   // distinct unscaled tables of a run of strands given as (table, parameters)
+    std::vector<int32_t>* table_idx;
+    std::vector<float>* states;
 
     void release(StrandBatch& B)
     {
@@ -47,13 +50,15 @@ struct StrandRunner {
         if (hipSetDevice(c->device) != hipSuccess) return NCHMM_E_HIP;
         release(B);
         const size_t reads = cap[0], events = cap[1];
-        const size_t bytes = al256(sizeof(float) * kImageFloats * reads) + 5 * al256(4 * reads) + al256(8 * (reads + 1)) + 3 * al256(4 * events) + al256(2 * events);
+        const size_t bytes = al256(sizeof(float) * kImageFloats * reads) + 5 * al256(4 * reads) + al256(8 * reads) + al256(24 * reads) + al256(8 * (reads + 1))
+                             + 3 * al256(4 * events) + al256(2 * events);
         void* p = nullptr;
         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return NCHMM_E_NOMEM;
         Carver q{(char*)p, 0};
         B.images = q.take<float>(kImageFloats * reads);
         B.fast = q.take<int32_t>(reads); B.p_skip = q.take<float>(reads); B.p_stay = q.take<float>(reads);
         B.logp = q.take<float>(reads); B.status = q.take<int32_t>(reads);
+        B.base = q.take<const float*>(reads); B.scale6 = q.take<float>(6 * reads);
         B.off = q.take<uint64_t>(reads + 1);
         B.cm = q.take<float>(events); B.sd = q.take<float>(events); B.ls = q.take<float>(events);
         B.states = q.take<uint16_t>(events);
@@ -67,7 +72,30 @@ struct StrandRunner {
         if (slots->size() < n) { slots->resize(n); std::iota(slots->begin(), slots->end(), 0); }
         const bool dbg = std::getenv("NCHMM_DEBUG") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        int rc = nchmm_put_model_images(c, 0, n, B.images, B.fast);
+        // models: runs of consecutive strands of one kind -- by image (one copy per run), or scaled on the device from the
+        // distinct unscaled tables of the run (a handful)
+        int rc = NCHMM_OK;
+        for (size_t k0 = 0; k0 < n && rc == NCHMM_OK;) {
+            size_t k1 = k0 + 1;
+            while (k1 < n && (B.base[k1] != nullptr) == (B.base[k0] != nullptr)) ++k1;
+            if (!B.base[k0]) {
+                rc = nchmm_put_model_images(c, (int)k0, k1 - k0, B.images + k0 * kImageFloats, B.fast + k0);
+            } else {
+                tables->clear();
+                table_idx->resize(k1 - k0);
+                for (size_t k = k0; k < k1; ++k) {
+                    size_t t = 0;
+                    while (t < tables->size() && (*tables)[t] != B.base[k]) ++t;
+                    if (t == tables->size()) tables->push_back(B.base[k]);
+                    (*table_idx)[k - k0] = (int32_t)t;
+                }
+                const size_t per = (size_t)kStates * 10;
+                states->resize(per * tables->size());
+                for (size_t t = 0; t < tables->size(); ++t) std::memcpy(states->data() + per * t, (*tables)[t], per * sizeof(float));
+                rc = nchmm_put_models_scaled(c, (int)k0, k1 - k0, states->data(), table_idx->data(), B.scale6 + 6 * k0);
+            }
+            k0 = k1;
+        }
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == NCHMM_OK) rc = nchmm_put_transitions_fast(c, 0, n, B.p_skip, B.p_stay);
         const auto t2 = std::chrono::steady_clock::now();
@@ -143,8 +171,11 @@ struct WindowRunner {
 
 struct Combiner {
     std::vector<int32_t> slots;
+    std::vector<const float*> tables;
+    std::vector<int32_t> table_idx;
+    std::vector<float> states;
     StrandCombiner<StrandRunner> sc;
-    Combiner(nchmm_ctx* c, size_t reads, size_t events, unsigned linger) : sc(StrandRunner{c, &slots}, reads, events, linger) {}
+    Combiner(nchmm_ctx* c, size_t reads, size_t events, unsigned linger) : sc(StrandRunner{c, &slots, &tables, &table_idx, &states}, reads, events, linger) {}
 };
 
 struct WinCombiner {
@@ -175,10 +206,12 @@ void combine_destroy(nchmm_ctx* c)
 }
 }  // namespace nchmm
 
-extern "C" int nchmm_viterbi_strand(nchmm_ctx* c, const float* table_Sx6, float p_skip, float p_stay, size_t n_events, const float* cmean,
-                                    const float* stdv, const float* lstdv, uint16_t* out_state, float* out_logp)
+namespace {
+
+int strand_call(nchmm_ctx* c, const float* table_Sx6, const float* unscaled_Sx10, const float* pm_params6, float p_skip, float p_stay, size_t n_events,
+                const float* cmean, const float* stdv, const float* lstdv, uint16_t* out_state, float* out_logp)
 {
-    if (!c || !table_Sx6 || !out_logp || (n_events && (!cmean || !stdv || !lstdv || !out_state))) return NCHMM_E_INVALID;
+    if (!c || !out_logp || (n_events && (!cmean || !stdv || !lstdv || !out_state))) return NCHMM_E_INVALID;
     if (n_events > 0x7FFFFFF0ull) return NCHMM_E_INVALID;
     if (n_events == 0) { *out_logp = __builtin_nanf(""); return NCHMM_OK; }
     Combiner* K;
@@ -194,7 +227,25 @@ extern "C" int nchmm_viterbi_strand(nchmm_ctx* c, const float* table_Sx6, float 
         K = static_cast<Combiner*>(c->combiner);
     }
     return K->sc.submit([&](float* image, int32_t* fast) { (void)nchmm_model_image(table_Sx6, image, fast); }, p_skip, p_stay, n_events,
-                        cmean, stdv, lstdv, out_state, out_logp);
+                        cmean, stdv, lstdv, out_state, out_logp, unscaled_Sx10, pm_params6);
+}
+
+}  // namespace
+
+extern "C" int nchmm_viterbi_strand(nchmm_ctx* c, const float* table_Sx6, float p_skip, float p_stay, size_t n_events, const float* cmean,
+                                    const float* stdv, const float* lstdv, uint16_t* out_state, float* out_logp)
+{
+    if (!table_Sx6) return NCHMM_E_INVALID;
+    return strand_call(c, table_Sx6, nullptr, nullptr, p_skip, p_stay, n_events, cmean, stdv, lstdv, out_state, out_logp);
+}
+
+// The strand's model as the caller got it: an unscaled table and the Pore_Model_Parameters it was scaled by (pm.scale(pm_params) in
+// basecall_strand, nanocall.cpp:653-657) -- 32 bytes to the device instead of a 128 KiB image; Pore_Model::scale runs there.
+extern "C" int nchmm_viterbi_strand_scaled(nchmm_ctx* c, const float* unscaled_Sx10, const float* pm_params6, float p_skip, float p_stay, size_t n_events,
+                                           const float* cmean, const float* stdv, const float* lstdv, uint16_t* out_state, float* out_logp)
+{
+    if (!unscaled_Sx10 || !pm_params6) return NCHMM_E_INVALID;
+    return strand_call(c, nullptr, unscaled_Sx10, pm_params6, p_skip, p_stay, n_events, cmean, stdv, lstdv, out_state, out_logp);
 }
 
 // The same for one read's training windows (train_one_round, Parameter_Trainer.hpp:541-579, from every worker of the pfor of

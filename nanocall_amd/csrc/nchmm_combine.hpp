@@ -150,9 +150,13 @@ private:
 };
 
 // ---- payload of nchmm_viterbi_strand: one strand = one item, its events, one model image ----
+// A strand's model comes either as its device image (built by the caller from the scaled S x 6 table) or, when the caller knows
+// where it came from, as (unscaled S x 10 states, scaling parameters): 32 bytes instead of 128 KiB, scaled on the device.
 struct StrandBatch : CombineCore {
-    float* images = nullptr;      // [cap[2]][kImageFloats]
+    float* images = nullptr;      // [cap[2]][kImageFloats]   (strands with base[k] == nullptr)
     int32_t* fast = nullptr;      // [cap[2]]
+    const float** base = nullptr; // [cap[0]]  unscaled states of strand k's model, or nullptr
+    float* scale6 = nullptr;      // [cap[0]][6]
     float* p_skip = nullptr;      // [cap[0]]
     float* p_stay = nullptr;
     uint64_t* off = nullptr;      // [cap[0] + 1]
@@ -170,9 +174,10 @@ public:
     StrandCombiner(Runner r, size_t max_reads, size_t max_events, unsigned linger_us) : bc_(r, caps(max_reads, max_events).c, linger_us) {}
     // fill_image(dst, &fast) writes the kImageFloats of the strand's model.  Returns the batch's error code, or the strand's own
     // status (0 / negative) when the batch ran.
+    // base / scale6: the model as (unscaled states, parameters) instead (fill_image is then not called); nullptr: by image.
     template <typename FillImage>
     int submit(FillImage&& fill_image, float p_skip, float p_stay, size_t n_events, const float* cm, const float* sd, const float* ls,
-               uint16_t* out_state, float* out_logp)
+               uint16_t* out_state, float* out_logp, const float* base = nullptr, const float* scale6 = nullptr)
     {
         const size_t need[kCombineDims] = {1, n_events, 1};
         return bc_.submit(need,
@@ -180,7 +185,9 @@ public:
                 const size_t idx = p.at[0], at = p.at[1];
                 B.off[idx + 1] = at + n_events;      // (off[0] = 0 from alloc; strand idx starts where strand idx-1 ends)
                 B.fast[idx] = 1;
-                fill_image(B.images + idx * kImageFloats, &B.fast[idx]);
+                B.base[idx] = base;
+                if (base) std::memcpy(B.scale6 + 6 * idx, scale6, 6 * sizeof(float));
+                else fill_image(B.images + idx * kImageFloats, &B.fast[idx]);
                 B.p_skip[idx] = p_skip; B.p_stay[idx] = p_stay;
                 if (n_events) {
                     std::memcpy(B.cm + at, cm, n_events * sizeof(float));

@@ -181,10 +181,20 @@ def test_one_strand_per_call_from_many_threads_is_combined_and_exact(r73t, r9t):
         n = int(rng.integers(1, 420))
         off, mean, stdv, start, cm, sd, ls = ragged_batch(kinds[k][0], [n], first_read=1000 + r)
         jobs.append((k, cm, sd, ls))
+    unscaled = [na.model_load(t) for t, _, _, _ in kinds]
+
+    def call(ctx, i, j):
+        # every other strand hands its model over as (unscaled table, parameters) -- scaled on the device -- instead of as the scaled
+        # table: both kinds sit side by side in the batches
+        k = j[0]
+        if i % 2:
+            return ctx.viterbi_strand_scaled(unscaled[k], kinds[k][1], kinds[k][2], kinds[k][3], j[1], j[2], j[3])
+        return ctx.viterbi_strand(tables[k], kinds[k][2], kinds[k][3], j[1], j[2], j[3])
+
     with na.Context(0) as ctx:
         launches0 = int(ctx.counters()[3])
         with ThreadPoolExecutor(40) as ex:
-            got = list(ex.map(lambda j: ctx.viterbi_strand(tables[j[0]], kinds[j[0]][2], kinds[j[0]][3], j[1], j[2], j[3]), jobs))
+            got = list(ex.map(lambda ij: call(ctx, ij[0], ij[1]), enumerate(jobs)))
         launches = int(ctx.counters()[3]) - launches0
         # a lone caller gets a launch to itself
         st1, lp1, rc1 = ctx.viterbi_strand(tables[0], 0.3, 0.1, *jobs[0][1:])

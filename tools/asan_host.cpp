@@ -74,13 +74,13 @@ int main(){
     struct FakeRunner {
       std::atomic<long>* runs; std::atomic<long>* strands;
       void release(nchmm::StrandBatch& B) { std::free(B.images); std::free(B.fast); std::free(B.p_skip); std::free(B.p_stay); std::free(B.off); std::free(B.cm); std::free(B.sd); std::free(B.ls);
-        std::free(B.states); std::free(B.logp); std::free(B.status);
+        std::free(B.states); std::free(B.logp); std::free(B.status); std::free(B.base); std::free(B.scale6); B.base = nullptr; B.scale6 = nullptr;
         B.images = nullptr; B.fast = nullptr; B.p_skip = B.p_stay = nullptr; B.off = nullptr; B.cm = B.sd = B.ls = nullptr; B.states = nullptr; B.logp = nullptr; B.status = nullptr;
         B.cap[0] = B.cap[1] = B.cap[2] = 0; }
       int alloc(nchmm::StrandBatch& B, const size_t cap[3]) { release(B); const size_t reads = cap[0], events = cap[1];
         B.images = (float*)std::malloc(sizeof(float) * nchmm::kImageFloats * cap[2]); B.fast = (int32_t*)std::malloc(4 * cap[2]); B.p_skip = (float*)std::malloc(4 * reads);
         B.p_stay = (float*)std::malloc(4 * reads); B.off = (uint64_t*)std::malloc(8 * (reads + 1)); B.cm = (float*)std::malloc(4 * events); B.sd = (float*)std::malloc(4 * events);
-        B.ls = (float*)std::malloc(4 * events); B.states = (uint16_t*)std::malloc(2 * events); B.logp = (float*)std::malloc(4 * reads); B.status = (int32_t*)std::malloc(4 * reads);
+        B.ls = (float*)std::malloc(4 * events); B.states = (uint16_t*)std::malloc(2 * events); B.logp = (float*)std::malloc(4 * reads); B.status = (int32_t*)std::malloc(4 * reads); B.base = (const float**)std::malloc(8 * reads); B.scale6 = (float*)std::malloc(24 * reads);
         B.off[0] = 0; B.cap[0] = reads; B.cap[1] = events; B.cap[2] = cap[2]; return 0; }
       int run(nchmm::StrandBatch& B) { runs->fetch_add(1); const size_t n = B.used[0]; strands->fetch_add((long)n);
         for (size_t r = 0; r < n; ++r) { for (uint64_t e = B.off[r]; e < B.off[r + 1]; ++e) B.states[e] = (uint16_t)((unsigned)B.cm[e] & 4095u);
