@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# torch first, as bench.py and any torch-based host would have it: its HIP runtime is then the one in the process before the product
+# library asks for one.  (The other order -- the product initialises HIP, torch arrives later -- is what
+# test_product_before_torch_shares_one_hip_runtime exercises on purpose, in a fresh interpreter of its own.)
+try:
+    import torch  # noqa: F401
+except Exception:      # no torch: the C ABI tests do not need it
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
