@@ -372,7 +372,8 @@ int nchmm_fwbw(nchmm_ctx* ctx, size_t n_win, const uint64_t* off, const float* c
  *   p_skip[m], p_stay[m]                   its transitions: compute_transitions_fast(p_skip[m], p_stay[m]),  m < n_models
  *   off / corrected_mean / stdv / log_stdv the windows, SoA like nchmm_fwbw; win_model[w] < n_models
  *   st_params (n_win x 2 {p_stay, p_skip}, NULL = those of the window's model); outputs as nchmm_fwbw (sums may be NULL).
- * While threads are inside this call (or nchmm_viterbi_strand) the context must not be used through any other entry point. */
+ * Calls of nchmm_viterbi_strand and nchmm_fwbw_windows may be in progress on one context at the same time (their batches take turns on
+ * the device); while threads are inside either, the context must not be used through any OTHER entry point. */
 int nchmm_fwbw_windows(nchmm_ctx* ctx, size_t n_models, const float* const* unscaled_Sx10, const float* pm_params,
                        const float* p_skip, const float* p_stay, size_t n_win, const uint64_t* off, const float* corrected_mean,
                        const float* stdv, const float* log_stdv, const int32_t* win_model, const float* st_params,

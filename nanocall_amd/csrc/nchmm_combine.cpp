@@ -68,6 +68,7 @@ struct StrandRunner {
     }
     int run(StrandBatch& B)
     {
+        std::lock_guard<std::mutex> device(c->combine_run);   // (a batch of training windows may be running on another thread)
         const size_t n = B.used[0];
         if (slots->size() < n) { slots->resize(n); std::iota(slots->begin(), slots->end(), 0); }
         const bool dbg = std::getenv("NCHMM_DEBUG") != nullptr;
@@ -141,6 +142,7 @@ struct WindowRunner {
     }
     int run(WindowBatch& B)
     {
+        std::lock_guard<std::mutex> device(c->combine_run);   // (a batch of strands may be running on another thread)
         const size_t n_win = B.used[0], n_mod = B.used[2];
         const bool dbg = std::getenv("NCHMM_DEBUG") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();

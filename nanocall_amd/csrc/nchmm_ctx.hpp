@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 namespace nchmm {
@@ -77,6 +78,7 @@ struct nchmm_ctx {
     nchmm::PipeState* pipe = nullptr;   // batches in flight (nchmm_pipeline.cpp)
     void* combiner = nullptr;           // nchmm_viterbi_strand's batcher (nchmm_combine.cpp), created on first use
     void* win_combiner = nullptr;       // nchmm_fwbw_windows' batcher
+    std::mutex combine_run;             // one combined batch on the device at a time, strands or windows (the context is not re-entrant)
     size_t peak_bytes = 0;          // high-water mark of counters[6] (device bytes held)
     size_t ws_budget = 0;           // largest workspace we are willing to allocate (bytes)
     size_t fb_budget = 0;           // same for the forward-backward alpha rows (16 KiB per event)

@@ -306,3 +306,35 @@ def test_a_few_very_long_reads_get_regions_of_their_own():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["launches"] == 2 and out["one_call"] and out["raw"] and out["streamed"] and out["status_ok"], out
     assert out["peak_mb"] < 2300, out
+
+
+def test_strands_and_training_windows_at_once_on_one_context(r73t):
+    """nchmm_viterbi_strand and nchmm_fwbw_windows in progress on ONE context at the same time (a host that trains some reads while
+    it decodes others): their batches take turns on the device; every result as if it had been alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    import nc_oracle as oracle
+    tab = na.scaled_model_table(r73t, IDENT)
+    un = [na.model_load(r73t)]
+    strands, wins = [], []
+    for r in range(40):
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [150 + 7 * r], first_read=500 + r)
+        strands.append((cm, sd, ls))
+        off, mean, stdv, start, cm, sd, ls = ragged_batch(r73t, [80, 100], first_read=900 + r)
+        wins.append((off, cm, sd, ls))
+    with na.Context(0) as ctx:
+        with ThreadPoolExecutor(24) as ex:
+            fs = [ex.submit(ctx.viterbi_strand, tab, 0.3, 0.1, *s) for s in strands]
+            fw = [ex.submit(ctx.fwbw_windows, un, IDENT, [0.3], [0.1], w[0], w[1], w[2], w[3], np.zeros(2, np.int32)) for w in wins]
+            got_s = [f.result() for f in fs]
+            got_w = [f.result() for f in fw]
+        ctx.put_model(0, tab)
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        for w, g in zip(wins, got_w):
+            want = ctx.fwbw(w[0], w[1], w[2], w[3], scaled_slot=np.zeros(2, np.int32), pm_params=IDENT, trans_slot=np.zeros(2, np.int32),
+                            st_params=np.tile(np.float32([0.1, 0.3]), (2, 1)))
+            for k in ("log_pr_data", "pm_sums", "st_sums"):
+                assert g[k].tobytes() == want[k].tobytes(), k
+    om, ot = oracle.Model(r73t, IDENT), oracle.Transitions(0.3, 0.1)
+    for (cm, sd, ls), (st, lp, rc) in zip(strands, got_s):
+        s, mv, olp = oracle.viterbi(om, ot, cm, sd, ls)
+        assert rc == 0 and np.array_equal(st, s) and np.float32(lp).tobytes() == np.float32(olp).tobytes()
