@@ -547,7 +547,8 @@ def main():
                     "kernel_ms_note": f"mean of {len(kernel_ms)} launches queued one behind the other right after the timed region (hipEvents "
                                       "on the launch stream): sweep + the traceback every block does when its read ends, nothing running "
                                       "beside it; in the timed region consecutive launches overlap at their edges, so a step costs "
-                                      "ms_per_step, less than a launch lasts",
+                                      "ms_per_step, less than a launch lasts.  (Rounds 1-3 had a separate traceback kernel, ~0.45 ms per "
+                                      "launch, which their kernel_ms / frac did not include.)",
                     "steps_overlap": not args.serial_launches,
                     # the same bytes against the rate the timed region sustained (launches overlapping at their edges): what a
                     # caller with more than one batch gets per launch; `frac` above stays the conservative kernel-alone figure
