@@ -440,6 +440,8 @@ def main():
         settle.append(ctx.last_kernel_ms()[0])
         if len(settle) >= 8 and max(settle[-4:]) <= 1.01 * min(settle[-4:]):
             break
+        if len(settle) >= 3 and sum(settle) > 2500.0:      # (launches of a whole shard: 2.5 s of load is settled enough)
+            break
     c_settle = [int(x) for x in ctx.counters()]      # (the reported counters cover warm-up + timed steps, as before)
     for _ in range(args.warmup):
         step()
