@@ -65,6 +65,10 @@ def test_three_batches_in_flight_equal_one_call_each(gpu_ctx, r73t):
         gpu_ctx.viterbi_begin(batches[3][0], *batches[3][4:])
     with pytest.raises(na.NchmmError):       # and the one-call form would have to jump the queue
         gpu_ctx.viterbi(batches[3][0], *batches[3][4:])
+    # the device-pointer forms share the lanes with the batches in flight: refused too (the pointers are never looked at)
+    from nanocall_amd._lib import lib
+    fake = 4096
+    assert lib().nchmm_viterbi_dev_enqueue(gpu_ctx._h, 1, 10, 10, fake, fake, fake, fake, None, None, None, fake, fake, None) == -1
     r0 = gpu_ctx.viterbi_end(t0)
     t3 = gpu_ctx.viterbi_begin(batches[3][0], *batches[3][4:])
     r1 = gpu_ctx.viterbi_end(t1)
