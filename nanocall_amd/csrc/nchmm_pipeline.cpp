@@ -32,6 +32,7 @@
 #include "nchmm_device.h"
 #include "nchmm_internal.hpp"
 #include "nchmm_pipe.hpp"
+#include "nchmm_plan.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -43,13 +44,6 @@
 using namespace nchmm;
 
 namespace nchmm {
-
-struct PipeRange {
-    size_t r0, r1;       // reads [r0, r1)
-    uint64_t e0, e1;     // their events [e0, e1) of the packed arrays
-    uint64_t raw_hi;     // raw form: raw events [0, raw_hi) must be on the device before this range is gathered
-    size_t max_events;
-};
 
 constexpr int kPipeDepth = kVitLanes;   // batches in flight: one per compute lane
 
@@ -124,46 +118,6 @@ int pipe_event(nchmm_ctx* c, PipeCall& K, hipEvent_t* out)
     return NCHMM_OK;
 }
 
-// Contiguous read ranges.  The first range's copy-in is overlapped with nothing, so a batch that goes up alone starts with a
-// short head -- one grid-full of reads -- and everything else follows as ONE range whose copy-in runs under the head's kernel:
-// its launch rolls into the head's on the next lane, and its longest reads, wherever they sit in the batch, are handed out
-// first (a launch lasts as long as its longest read: 4096 log-normally long reads in one call 296 -> 309 Mevents/s, config-3
-// decode 305 -> 333 against ranges that double, profiles/r04b_range_policy_ab.txt).
-//   * streaming form, up to two grid-fulls of reads (the 1024-read batches a streaming caller sends): one range -- its
-//     copy-in overlaps the previous BATCH instead
-//   * one-call form (`alone`) from 1.5 grid-fulls up, and every larger batch: head + rest
-// NCHMM_PIPE_READS (test hook) forces ranges of that many reads.
-int cut_ranges(const uint64_t* off, size_t n, size_t slots, bool alone, std::vector<PipeRange>* out)
-{
-    slots = std::max<size_t>(slots, 1);
-    size_t forced = 0;
-    if (const char* e = std::getenv("NCHMM_PIPE_READS")) {
-        const long v = std::atol(e);
-        if (v > 0) forced = (size_t)v;
-    }
-    auto range_of = [&](size_t r0, size_t r1) {
-        size_t mx = 0;
-        for (size_t r = r0; r < r1; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
-        return PipeRange{r0, r1, off[r0], off[r1], 0, mx};
-    };
-    out->clear();
-    if (forced) {
-        for (size_t r0 = 0; r0 < n; r0 += forced) out->push_back(range_of(r0, std::min(n, r0 + forced)));
-        return NCHMM_OK;
-    }
-    if (n <= (alone ? slots + slots / 2 : 2 * slots)) {
-        out->push_back(range_of(0, n));
-        return NCHMM_OK;
-    }
-    // the head: one grid-full of reads, and at least 1 M events (short reads: too little work to cover the copy-in of the rest)
-    size_t r1 = slots;
-    while (r1 < n && off[r1] - off[0] < ((uint64_t)1 << 20)) ++r1;
-    if (n - r1 < slots / 2) r1 = n;      // (a remainder not worth a launch)
-    out->push_back(range_of(0, r1));
-    if (r1 < n) out->push_back(range_of(r1, n));
-    return NCHMM_OK;
-}
-
 struct PreparedIn { const float* cmean; const float* stdv; const float* lstdv; };
 struct RawIn { size_t n_raw; const float* mean; const float* stdv; const float* start; const uint64_t* src; const float* drift; };
 
@@ -184,50 +138,32 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     uint64_t longest = 1;
     for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
     // (the back-pointer workspace is one region per resident block: it does not bound a range)
-    if ((rc = cut_ranges(off, n, (size_t)c->vit_slots, direct, &K.ranges))) return rc;
+    {
+        size_t forced = 0;
+        if (const char* e = std::getenv("NCHMM_PIPE_READS")) {      // test hook: ranges of that many reads
+            const long v = std::atol(e);
+            if (v > 0) forced = (size_t)v;
+        }
+        cut_ranges(off, n, (size_t)c->vit_slots, direct, forced, &K.ranges);
+    }
     const size_t n_ranges = K.ranges.size();
 
     // longest-first processing order inside each range (the device work queue hands reads out in this order)
     K.h_off.assign(off, off + n + 1);
     off = K.h_off.data();
     std::vector<uint32_t>& order = K.h_order;
-    order.resize(n);
-    std::iota(order.begin(), order.end(), 0u);
-    for (const PipeRange& g : K.ranges)
-        std::stable_sort(order.begin() + g.r0, order.begin() + g.r1,
-                         [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
-    // Outliers.  When the longest read is too long for a full pool of regions within the budget, but only a few reads are that
-    // long, those few go through regions of their own as one more launch (launch_viterbi_outliers) and the pool is sized for
-    // the rest; otherwise (most reads long, or none too long) everything goes the usual way.
+    order_ranges(off, n, K.ranges, &order);
+    // Outliers (nchmm_plan.hpp): a few reads too long for a full pool of regions within the budget go through regions of their
+    // own as one more launch (launch_viterbi_outliers), and the pool is sized for the rest.
     size_t biggest = 1;
     for (const PipeRange& g : K.ranges) biggest = std::max(biggest, g.r1 - g.r0);
-    uint64_t pool_longest = longest;          // what the pool's regions must hold
-    std::vector<uint32_t> outliers;           // read indices, longest first
-    std::vector<size_t> n_out(n_ranges, 0);   // per range: how many of its (sorted) reads are outliers -- a prefix of its order
-    {
-        size_t budget = 0;
-        if ((rc = viterbi_ws_budget(c, &budget))) return rc;
-        const size_t pool = (size_t)kXcds * std::min<size_t>(c->slots_per_xcd, biggest * kVitLanes);
-        if ((size_t)longest * kBpRowBytes > budget / pool) {
-            const uint64_t small_cap = (uint64_t)(budget / 10 * 7 / pool / kBpRowBytes);   // events a pooled region may hold
-            size_t n_long = 0;
-            uint64_t longest_short = 1;
-            for (size_t r = 0; r < n; ++r) {
-                const uint64_t len = off[r + 1] - off[r];
-                if (len > small_cap) ++n_long; else longest_short = std::max(longest_short, len);
-            }
-            if (small_cap >= 256 && n_long * 8 <= n) {
-                pool_longest = longest_short;
-                for (size_t k = 0; k < n_ranges; ++k) {
-                    const PipeRange& g = K.ranges[k];
-                    while (g.r0 + n_out[k] < g.r1 && off[order[g.r0 + n_out[k]] + 1] - off[order[g.r0 + n_out[k]]] > small_cap) ++n_out[k];
-                    outliers.insert(outliers.end(), order.begin() + g.r0, order.begin() + g.r0 + n_out[k]);
-                }
-                std::stable_sort(outliers.begin(), outliers.end(), [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
-                if ((rc = viterbi_big_prepare(c, longest, outliers.size(), budget / 10 * 3))) return rc;
-            }
-        }
-    }
+    size_t budget = 0;
+    if ((rc = viterbi_ws_budget(c, &budget))) return rc;
+    OutlierPlan plan = plan_outliers(off, n, K.ranges, order, (size_t)kXcds * std::min<size_t>(c->slots_per_xcd, biggest * kVitLanes), budget, kBpRowBytes);
+    const uint64_t pool_longest = plan.pool_longest;          // what the pool's regions must hold
+    const std::vector<uint32_t>& outliers = plan.outliers;    // read indices, longest first
+    const std::vector<size_t>& n_out = plan.n_out;            // per range: how many of its (sorted) reads are outliers -- a prefix of its order
+    if (!outliers.empty() && (rc = viterbi_big_prepare(c, longest, outliers.size(), plan.budget_big))) return rc;
     if (raw) {
         uint64_t hi = 0;
         for (PipeRange& g : K.ranges) {

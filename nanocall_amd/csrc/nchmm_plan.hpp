@@ -1,0 +1,109 @@
+// nchmm_plan.hpp -- how a host-pointer batch is cut up (nchmm_pipeline.cpp): the ranges it goes up in, the processing order
+// inside them, and which of its reads are outliers that get back-pointer regions of their own.  Plain host arithmetic over the
+// batch's offsets, kept apart from the HIP code so that it runs under the sanitizers on every shape (tools/asan_host.cpp).
+#ifndef NCHMM_PLAN_HPP
+#define NCHMM_PLAN_HPP
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace nchmm {
+
+struct PipeRange {
+    size_t r0, r1;       // reads [r0, r1)
+    uint64_t e0, e1;     // their events [e0, e1) of the packed arrays
+    uint64_t raw_hi;     // raw form: raw events [0, raw_hi) must be on the device before this range is gathered
+    size_t max_events;
+};
+
+// Contiguous read ranges.  The first range's copy-in is overlapped with nothing, so a batch that goes up alone starts with a
+// short head -- one grid-full of reads -- and everything else follows as ONE range whose copy-in runs under the head's kernel:
+// its launch rolls into the head's on the next lane, and its longest reads, wherever they sit in the batch, are handed out
+// first (a launch lasts as long as its longest read: 4096 log-normally long reads in one call 296 -> 309 Mevents/s, config-3
+// decode 305 -> 333 against ranges that double, profiles/r04b_range_policy_ab.txt).
+//   * streaming form, up to two grid-fulls of reads (the 1024-read batches a streaming caller sends): one range -- its
+//     copy-in overlaps the previous BATCH instead
+//   * one-call form (`alone`) from 1.5 grid-fulls up, and every larger batch: head + rest
+// forced > 0 (NCHMM_PIPE_READS, test hook): ranges of that many reads.
+inline void cut_ranges(const uint64_t* off, size_t n, size_t slots, bool alone, size_t forced, std::vector<PipeRange>* out)
+{
+    slots = std::max<size_t>(slots, 1);
+    auto range_of = [&](size_t r0, size_t r1) {
+        size_t mx = 0;
+        for (size_t r = r0; r < r1; ++r) mx = std::max<size_t>(mx, (size_t)(off[r + 1] - off[r]));
+        return PipeRange{r0, r1, off[r0], off[r1], 0, mx};
+    };
+    out->clear();
+    if (forced) {
+        for (size_t r0 = 0; r0 < n; r0 += forced) out->push_back(range_of(r0, std::min(n, r0 + forced)));
+        return;
+    }
+    if (n <= (alone ? slots + slots / 2 : 2 * slots)) {
+        out->push_back(range_of(0, n));
+        return;
+    }
+    // the head: one grid-full of reads, and at least 1 M events (short reads: too little work to cover the copy-in of the rest)
+    size_t r1 = slots;
+    while (r1 < n && off[r1] - off[0] < ((uint64_t)1 << 20)) ++r1;
+    if (n - r1 < slots / 2) r1 = n;      // (a remainder not worth a launch)
+    out->push_back(range_of(0, r1));
+    if (r1 < n) out->push_back(range_of(r1, n));
+}
+
+// Longest-first processing order inside each range (the device work queue hands reads out in this order; equal lengths keep
+// their input order).
+inline void order_ranges(const uint64_t* off, size_t n, const std::vector<PipeRange>& ranges, std::vector<uint32_t>* order)
+{
+    order->resize(n);
+    std::iota(order->begin(), order->end(), 0u);
+    for (const PipeRange& g : ranges)
+        std::stable_sort(order->begin() + g.r0, order->begin() + g.r1,
+                         [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+}
+
+// Outliers.  pool = back-pointer regions the pooled launches share, budget = bytes the workspace may take, row = bytes per event.
+// When the longest read is too long for `pool` regions within the budget but only a few reads are that long (at most one in
+// eight), those few -- every read longer than what 70 % of the budget gives a pooled region -- go through regions of their own
+// (the other 30 %) as one more launch, and the pool is sized for the rest.  Otherwise: no outliers, pool_longest = longest.
+//   n_out[k]   how many reads of range k are outliers: a PREFIX of its (longest-first) order
+//   outliers   their read indices, longest first
+struct OutlierPlan {
+    uint64_t pool_longest = 1;
+    std::vector<uint32_t> outliers;
+    std::vector<size_t> n_out;
+    size_t budget_big = 0;
+};
+inline OutlierPlan plan_outliers(const uint64_t* off, size_t n, const std::vector<PipeRange>& ranges, const std::vector<uint32_t>& order,
+                                 size_t pool, size_t budget, size_t row)
+{
+    OutlierPlan P;
+    P.n_out.assign(ranges.size(), 0);
+    uint64_t longest = 1;
+    for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
+    P.pool_longest = longest;
+    pool = std::max<size_t>(pool, 1);
+    if ((size_t)longest * row <= budget / pool) return P;
+    const uint64_t small_cap = (uint64_t)(budget / 10 * 7 / pool / row);   // events a pooled region may hold
+    size_t n_long = 0;
+    uint64_t longest_short = 1;
+    for (size_t r = 0; r < n; ++r) {
+        const uint64_t len = off[r + 1] - off[r];
+        if (len > small_cap) ++n_long; else longest_short = std::max(longest_short, len);
+    }
+    if (small_cap < 256 || n_long * 8 > n) return P;      // (most reads are long: everything the usual way, on fewer blocks)
+    P.pool_longest = longest_short;
+    for (size_t k = 0; k < ranges.size(); ++k) {
+        const PipeRange& g = ranges[k];
+        while (g.r0 + P.n_out[k] < g.r1 && off[order[g.r0 + P.n_out[k]] + 1] - off[order[g.r0 + P.n_out[k]]] > small_cap) ++P.n_out[k];
+        P.outliers.insert(P.outliers.end(), order.begin() + g.r0, order.begin() + g.r0 + P.n_out[k]);
+    }
+    std::stable_sort(P.outliers.begin(), P.outliers.end(), [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    P.budget_big = budget / 10 * 3;
+    return P;
+}
+
+}  // namespace nchmm
+#endif

@@ -11,6 +11,7 @@
 #include <vector>
 #include "nchmm_internal.hpp"
 #include "nchmm_combine.hpp"
+#include "nchmm_plan.hpp"
 #include <random>
 #include "nanocall_hip.h"
 int main(){
@@ -106,4 +107,39 @@ int main(){
     }
     printf("combiner: %ld strands in %ld batches\n", strands.load(), runs.load());
     if (bad.load() || strands.load() != 24 * 150 || runs.load() >= strands.load()) return 31; }
+  { // the batch plan (nchmm_plan.hpp) on every shape: ranges partition the reads, the order is a permutation that is longest-first
+    // inside each range, outliers are exactly the reads longer than a pooled region may hold, a prefix of every range's order
+    std::mt19937 r(99);
+    for (int trial = 0; trial < 400; ++trial) {
+      const size_t n = 1 + r() % (trial % 7 == 0 ? 5000 : 300), slots = 1 + r() % 600;
+      std::vector<uint64_t> off(n + 1, 0);
+      for (size_t i = 0; i < n; ++i) { uint64_t len = r() % 5 == 0 ? 0 : 1 + r() % 4000; if (r() % 97 == 0) len = 20000 + r() % 200000; off[i + 1] = off[i] + len; }
+      for (int alone = 0; alone < 2; ++alone) for (size_t forced : {(size_t)0, (size_t)1, (size_t)7}) {
+        std::vector<nchmm::PipeRange> rg; nchmm::cut_ranges(off.data(), n, slots, alone != 0, forced, &rg);
+        if (rg.empty() || rg.front().r0 != 0 || rg.back().r1 != n) return 40;
+        for (size_t k = 0; k < rg.size(); ++k) { if (rg[k].r1 <= rg[k].r0 || (k && rg[k].r0 != rg[k - 1].r1) || rg[k].e0 != off[rg[k].r0] || rg[k].e1 != off[rg[k].r1]) return 41;
+          size_t mx = 0; for (size_t i = rg[k].r0; i < rg[k].r1; ++i) mx = std::max<size_t>(mx, (size_t)(off[i + 1] - off[i])); if (mx != rg[k].max_events) return 42; }
+        if (!forced && rg.size() > 2) return 43;
+        std::vector<uint32_t> order; nchmm::order_ranges(off.data(), n, rg, &order);
+        std::vector<char> seen(n, 0); for (uint32_t v : order) { if (v >= n || seen[v]) return 44; seen[v] = 1; }
+        for (const auto& g : rg) for (size_t i = g.r0; i < g.r1; ++i) { if (order[i] < g.r0 || order[i] >= g.r1) return 45;
+          if (i > g.r0 && off[order[i] + 1] - off[order[i]] > off[order[i - 1] + 1] - off[order[i - 1]]) return 46; }
+        const size_t pool = 8 * (1 + r() % 72), row = 4096, budget = ((size_t)1 << 20) * (16 + r() % 200000);
+        nchmm::OutlierPlan P = nchmm::plan_outliers(off.data(), n, rg, order, pool, budget, row);
+        uint64_t longest = 1; for (size_t i = 0; i < n; ++i) longest = std::max<uint64_t>(longest, off[i + 1] - off[i]);
+        if (P.n_out.size() != rg.size()) return 47;
+        size_t tot = 0; for (size_t k = 0; k < rg.size(); ++k) tot += P.n_out[k];
+        if (tot != P.outliers.size() || tot * 8 > n) return 48;
+        if (P.outliers.empty()) { if (P.pool_longest != longest) return 49; }
+        else {
+          const uint64_t cap = (uint64_t)(budget / 10 * 7 / pool / row);
+          if (P.pool_longest > cap || P.pool_longest * row > budget / pool || P.budget_big == 0) return 50;
+          std::vector<char> is_out(n, 0); for (uint32_t v : P.outliers) { if (off[v + 1] - off[v] <= cap || is_out[v]) return 51; is_out[v] = 1; }
+          for (size_t i = 0; i < n; ++i) if (!is_out[i] && off[i + 1] - off[i] > cap) return 52;
+          for (size_t k = 0; k < rg.size(); ++k) for (size_t i = 0; i < rg[k].r1 - rg[k].r0; ++i) if ((i < P.n_out[k]) != (is_out[order[rg[k].r0 + i]] != 0)) return 53;
+          for (size_t i = 1; i < P.outliers.size(); ++i) if (off[P.outliers[i] + 1] - off[P.outliers[i]] > off[P.outliers[i - 1] + 1] - off[P.outliers[i - 1]]) return 54;
+        }
+      }
+    }
+    puts("batch plans: ok"); }
   puts("host ABI under ASan/UBSan: ok"); return 0; }
