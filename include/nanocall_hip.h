@@ -493,6 +493,19 @@ int nchmm_profile_blocks(nchmm_ctx* ctx, uint64_t* out_2x2048);
 /* number of resident thread-block slots (persistent grid size) the Viterbi kernel launches */
 int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
 
+/* Which form of the Viterbi sweep launches take.  A read is sequential (Viterbi.hpp:72-96 is a column-by-column
+ * recurrence), so there are two ways to put reads on a CU: two reads side by side on 8 waves each (NCHMM_SWEEP_WIDE: the most
+ * events per second) or one read on 16 waves (NCHMM_SWEEP_LL: about half the time per event for that read) -- what a batch
+ * with few or very unequal reads, and the reference's one-strand-per-call shape (nanocall.cpp:687-689), need.  Results are
+ * bit-identical.  NCHMM_SWEEP_AUTO (default; environment NCHMM_VIT_SWEEP=auto|wide|ll at nchmm_create) decides per launch from
+ * the read lengths.  No reference counterpart (the reference's parallelism is pfor over reads, nanocall.cpp:611). */
+#define NCHMM_SWEEP_AUTO 0
+#define NCHMM_SWEEP_WIDE 1
+#define NCHMM_SWEEP_LL 2
+int nchmm_set_sweep(nchmm_ctx* ctx, int mode);
+/* out[0] = launches of the wide form so far, [1] = of the low-latency form, [2] / [3] = reads they decoded */
+int nchmm_sweep_stats(const nchmm_ctx* ctx, uint64_t out[4]);
+
 /* Device memory the context holds now (out[0]) and at its high-water mark (out[1]), in bytes: tables, staging and the
  * back-pointer workspace -- one region of 4 KiB per event of the LONGEST read for every thread block that can be resident
  * (2 per CU, a few to spare), independent of the number of reads: a block walks its read back as soon as it has swept

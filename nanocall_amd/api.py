@@ -587,6 +587,17 @@ class Context:
         check(lib().nchmm_grid_slots(self._h, C.byref(v)), "nchmm_grid_slots")
         return v.value
 
+    def set_sweep(self, mode):
+        """which form of the Viterbi sweep launches take: "auto" (per launch, from the read lengths), "wide" (two reads per
+        CU on 8 waves each), "ll" (one read per CU on 16 waves) -- bit-identical results"""
+        check(lib().nchmm_set_sweep(self._h, {"auto": 0, "wide": 1, "ll": 2}[mode]), "nchmm_set_sweep")
+
+    def sweep_stats(self):
+        """(launches wide, launches ll, reads wide, reads ll) so far"""
+        out = (C.c_uint64 * 4)()
+        check(lib().nchmm_sweep_stats(self._h, out), "nchmm_sweep_stats")
+        return tuple(int(v) for v in out)
+
 
 # ------------------------------------------------------------------------------------------------
 # device pool (one context + host thread per GPU, reads sharded by event count)

@@ -5,6 +5,7 @@
 #include "nchmm_device.h"
 #include "nchmm_internal.hpp"
 #include "nchmm_kmer.hpp"
+#include "nchmm_plan.hpp"
 #include "nchmm_probe.h"
 
 #include <algorithm>
@@ -312,6 +313,8 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         if (m) c->tb_margin = std::max(0, std::atoi(m));
         const char* f = std::getenv("NCHMM_FB_FORCE_LOG");
         c->fb_force_log = f && f[0] == '1';
+        if (const char* w = std::getenv("NCHMM_VIT_SWEEP"))     // wide | ll | auto: which form of the sweep launches take
+            c->sweep_mode = !std::strcmp(w, "wide") ? kSweepWide : !std::strcmp(w, "ll") ? kSweepLl : kSweepAuto;
         const char* b = std::getenv("NCHMM_FB_BUDGET_MB");
         if (b) c->fb_budget = std::max<size_t>((size_t)std::strtoull(b, nullptr, 10) << 20, (size_t)16 << 20);
     }
@@ -648,9 +651,10 @@ namespace {
 int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_bytes, size_t regions, hipEvent_t after, hipEvent_t serial_after,
                         size_t first, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean, const float* d_stdv,
                         const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
-                        uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int li, int* lane_out)
+                        uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int li, int* lane_out, int sweep)
 {
     VitLaneState& L = c->lane[li];
+    const bool ll = (c->sweep_mode == kSweepAuto ? sweep : c->sweep_mode) == kSweepLl;
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
@@ -667,15 +671,18 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     a.tb_margin = c->tb_margin;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
-    const size_t slots = pooled ? (size_t)c->vit_slots : regions;
+    // the wide sweep: two blocks per CU; the low-latency sweep: one
+    const size_t slots = std::min<size_t>(pooled ? (size_t)c->vit_slots : regions, ll ? (size_t)c->n_cu : (size_t)-1);
     const int grid = (int)std::min<size_t>(slots, count);
     a.queue_base = L.vq_base;
     L.vq_base += (unsigned)count + (unsigned)grid;   // every read takes a ticket, every block one more to find the queue empty
     if (after) HIP_TRY(c, hipStreamWaitEvent(L.stream, after, 0));
     if (serial_after) HIP_TRY(c, hipStreamWaitEvent(L.stream, serial_after, 0));
     HIP_TRY(c, hipEventRecord(L.ev0, L.stream));
-    launch_viterbi(a, grid, L.stream);
+    if (ll) launch_viterbi_ll(a, grid, L.stream); else launch_viterbi(a, grid, L.stream);
     HIP_TRY(c, hipGetLastError());
+    c->sweep_stats[ll ? 1 : 0] += 1;
+    c->sweep_stats[ll ? 3 : 2] += count;
     HIP_TRY(c, hipEventRecord(L.ev1, L.stream));
     HIP_TRY(c, hipEventRecord(L.done, L.stream));
     L.pending = true;
@@ -693,26 +700,26 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
 int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
                          const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status, int* lane_out)
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep)
 {
     if (!c->d_ws) return NCHMM_E_INVALID;
     // without a pool every launch owns regions 0 .. grid-1: one lane, strictly one launch after the other
     const int li = c->ws_pooled ? c->next_lane : 0;
     hipEvent_t serial = (!c->ws_pooled && c->last_lane >= 0 && c->last_lane != li) ? c->lane[c->last_lane].done : nullptr;
     return launch_on_next_lane(c, c->ws_pooled, c->d_ws, c->slot_bytes, c->ws_regions, after, serial, first, count, ev_count, d_off, d_cmean, d_stdv,
-                               d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status, li, lane_out);
+                               d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status, li, lane_out, sweep);
 }
 
 // The outliers of a batch (d_order lists them): one block per region of d_ws_big, behind the previous launch of outliers.
 int launch_viterbi_outliers(nchmm_ctx* c, hipEvent_t after, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean,
                             const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
-                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out)
+                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep)
 {
     if (!c->d_ws_big || !d_order || !c->ws_pooled) return NCHMM_E_INVALID;
     int li = 0;
     const int rc = launch_on_next_lane(c, false, c->d_ws_big, c->big_slot_bytes, c->big_regions, after, c->big_pending ? c->ev_big : nullptr, 0, count, ev_count,
                                        d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status,
-                                       c->next_lane, &li);
+                                       c->next_lane, &li, sweep);
     if (rc != NCHMM_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_big, c->lane[li].stream));
     c->big_pending = true;
@@ -770,8 +777,13 @@ int nchmm_viterbi_dev_enqueue(nchmm_ctx* c, size_t n_reads, size_t max_events, s
         HIP_TRY(c, hipEventRecord(c->ev_entry, c->stream));
         after = c->ev_entry;
     }
+    // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total).  A batch
+    // queued while another is in flight is a stream of launches: its tail is covered by the next one
+    bool busy = false;
+    for (int l = 0; l < kVitLanes; ++l) busy = busy || (c->lane[l].pending && hipEventQuery(c->lane[l].done) == hipErrorNotReady);
+    const int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, busy);
     return launch_viterbi_range(c, after, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
-                                d_order, d_out_state, d_out_logp, d_out_status, nullptr);
+                                d_order, d_out_state, d_out_logp, d_out_status, nullptr, sweep);
 }
 
 // Put every batch queued by nchmm_viterbi_dev_enqueue in front of whatever comes next on the context's stream.
@@ -1200,6 +1212,20 @@ int nchmm_mem_stats(const nchmm_ctx* c, uint64_t out[2])
     if (!c || !out) return NCHMM_E_INVALID;
     out[0] = c->counters[6];
     out[1] = c->peak_bytes;
+    return NCHMM_OK;
+}
+
+int nchmm_set_sweep(nchmm_ctx* c, int mode)
+{
+    if (!c || mode < kSweepAuto || mode > kSweepLl) return NCHMM_E_INVALID;
+    c->sweep_mode = mode;
+    return NCHMM_OK;
+}
+
+int nchmm_sweep_stats(const nchmm_ctx* c, uint64_t out[4])
+{
+    if (!c || !out) return NCHMM_E_INVALID;
+    for (int i = 0; i < 4; ++i) out[i] = c->sweep_stats[i];
     return NCHMM_OK;
 }
 

@@ -42,7 +42,9 @@ struct nchmm_ctx {
     bool external_stream = false;   // stream was set by the caller (0 is then the legacy default stream)
     int last_hip = 0;
     int n_cu = 0;
-    int vit_slots = 0;
+    int vit_slots = 0;              // block slots of the wide sweep (viterbi_kernel.hip: two per CU)
+    int sweep_mode = 0;             // nchmm::Sweep: 0 = per launch by nchmm_plan.hpp choose_sweep, 1 = wide always, 2 = ll always (NCHMM_VIT_SWEEP, nchmm_set_sweep)
+    uint64_t sweep_stats[4] = {0, 0, 0, 0};   // launches wide, launches ll, reads wide, reads ll
     int fb_slots = 0;
     float* d_models = nullptr;      // [kMaxSlots][kModelFloats]
     float* d_trans = nullptr;       // [kMaxSlots][kTransFloats]   log-space w0|w1|w2
@@ -117,14 +119,15 @@ int pipe_in_flight(const nchmm_ctx* c);
 int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count);
 // Queue one launch (sweep + in-block traceback) for reads [first, first + count) on the next lane; *lane_out = that lane.
 // The launch starts after `after` (an event, may be null) and after the lane's previous launch.  viterbi_ws_prepare first.
+// sweep: nchmm::kSweepWide / kSweepLl (the caller has decided, nchmm_plan.hpp); the context's sweep_mode overrides it when forced.
 int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
                          const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status, int* lane_out);
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep);
 int viterbi_big_prepare(nchmm_ctx* c, uint64_t longest, size_t n_long, size_t budget_big);
 int launch_viterbi_outliers(nchmm_ctx* c, hipEvent_t after, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean,
                             const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
-                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out);
+                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep);
 // The stream of the lane the NEXT launch_viterbi_range will use (for kernels that must run in front of it).
 hipStream_t viterbi_next_lane_stream(nchmm_ctx* c);
 // Make `s` wait for everything queued on the lanes; then 1 if a block reported a pool failure.

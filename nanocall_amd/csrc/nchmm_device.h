@@ -10,6 +10,7 @@ namespace nchmm {
 constexpr int kStates = 4096;
 constexpr int kThreads = 512;         // 8 waves; thread 2t+h owns 8 of the 16 states whose low 8 bits == t
 constexpr int kStatesPerThread = 8;
+constexpr int kLlThreads = 1024;      // the low-latency sweep (viterbi_ll_kernel.hip): 16 waves, thread 4t+y owns the 4 states t + 256(4x+y)
 constexpr int kModelFloats = 8 * kStates;               // SoA [field][state]
 constexpr int kTransFloats = kStates + 1024 + 256;      // w0[4096] | w1[1024] | w2[256]
 constexpr int kMaxSlots = 64;
@@ -64,6 +65,8 @@ struct ViterbiArgs {
 
 void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream);
 int viterbi_blocks_per_cu();
+// the low-latency form: one read per CU on 16 waves (viterbi_ll_kernel.hip); same arguments, same results, cu_progress unused
+void launch_viterbi_ll(const ViterbiArgs& a, int grid, hipStream_t stream);
 
 constexpr int kFbTransFloats = 6 * kStates;   // forward c0|c1|c2 then backward c0b|c1b|c2b, per state, log space
 

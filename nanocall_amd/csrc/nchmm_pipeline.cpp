@@ -138,13 +138,25 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     uint64_t longest = 1;
     for (size_t r = 0; r < n; ++r) longest = std::max<uint64_t>(longest, off[r + 1] - off[r]);
     // (the back-pointer workspace is one region per resident block: it does not bound a range)
+    // Which form of the sweep (nchmm_plan.hpp).  A batch that goes up alone and whose duration its longest reads would set
+    // takes the low-latency form, one read per CU: in one range (one launch hands out the longest reads of the whole batch
+    // first) unless it is large.  A streaming caller's batches and the ranges of a large batch run beside each other: those
+    // are decided range by range, with the tail of a launch covered by its neighbours.
+    const bool alone = (direct || tab) && P->in_flight == 0;
+    int batch_sweep = kSweepWide;
     {
         size_t forced = 0;
         if (const char* e = std::getenv("NCHMM_PIPE_READS")) {      // test hook: ranges of that many reads
             const long v = std::atol(e);
             if (v > 0) forced = (size_t)v;
         }
-        cut_ranges(off, n, (size_t)c->vit_slots, direct, forced, &K.ranges);
+        if (alone && c->sweep_mode != kSweepWide) {
+            std::vector<uint64_t> lens(n);
+            for (size_t r = 0; r < n; ++r) lens[r] = off[r + 1] - off[r];
+            batch_sweep = c->sweep_mode == kSweepLl ? kSweepLl : choose_sweep(lens, (size_t)c->n_cu, (size_t)c->vit_slots, false);
+        }
+        if (batch_sweep == kSweepLl && !forced && n <= 2 * (size_t)c->vit_slots) forced = n;
+        cut_ranges(off, n, batch_sweep == kSweepLl ? (size_t)c->n_cu : (size_t)c->vit_slots, direct, forced, &K.ranges);
     }
     const size_t n_ranges = K.ranges.size();
 
@@ -330,11 +342,17 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         }
         int lane = (int)(k % kVitLanes);
         if (g.r1 - g.r0 > n_out[k]) {
+            int sweep = batch_sweep;
+            if (!alone && c->sweep_mode == kSweepAuto) {
+                std::vector<uint64_t> lens(g.r1 - g.r0 - n_out[k]);
+                for (size_t i = 0; i < lens.size(); ++i) { const uint32_t r = order[g.r0 + n_out[k] + i]; lens[i] = off[r + 1] - off[r]; }
+                sweep = choose_sweep(lens, (size_t)c->n_cu, (size_t)c->vit_slots, true);
+            }
             rc = launch_viterbi_range(c, nullptr, g.r0, g.r1 - g.r0 - n_out[k], g.e1 - g.e0,
                                       (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
                                       (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
                                       trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or) + g.r0 + n_out[k], k_state, k_logp,
-                                      k_status, &lane);
+                                      k_status, &lane, sweep);
             if (rc != NCHMM_OK) return rc;
         } else {
             // (a range of outliers only: what was queued in front of its launch -- tables, gather -- is on stream sl)
@@ -356,7 +374,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         for (uint32_t r : outliers) ev_out += off[r + 1] - off[r];
         rc = launch_viterbi_outliers(c, nullptr, outliers.size(), ev_out, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
                                      (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
-                                     trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_ol), k_state, k_logp, k_status, &lane_o);
+                                     trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_ol), k_state, k_logp, k_status, &lane_o, batch_sweep);
         if (rc != NCHMM_OK) return rc;
         hipEvent_t ev_o;
         if ((rc = pipe_event(c, K, &ev_o))) return rc;

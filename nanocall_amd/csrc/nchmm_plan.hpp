@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <numeric>
 #include <vector>
 
@@ -103,6 +104,70 @@ inline OutlierPlan plan_outliers(const uint64_t* off, size_t n, const std::vecto
     std::stable_sort(P.outliers.begin(), P.outliers.end(), [&](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
     P.budget_big = budget / 10 * 3;
     return P;
+}
+
+// ---- which form of the sweep a launch takes ----
+// viterbi_kernel.hip (`wide`: 8 waves per read, two reads per CU) decodes the most events per second and CU; viterbi_ll_kernel.hip
+// (`ll`: 16 waves per read, one read per CU) halves the time of a read.  A launch hands its reads out longest first to
+// persistent blocks, so it lasts about as long as a longest-processing-time schedule of its reads on its block slots: that is
+// simulated for both forms (exactly up to kSimReads reads, by its two lower bounds beyond) and the shorter one wins.
+// Microseconds per event, measured (profiles/r05_ll_sweep.md): a wide block with a busy neighbour on its CU, a wide block
+// alone on its CU, an ll block.
+enum Sweep : int { kSweepAuto = 0, kSweepWide = 1, kSweepLl = 2 };
+struct SweepRates { double wide_shared = 1.48, wide_alone = 1.38, ll = 0.80; double per_read_us = 60.0; };
+
+// makespan (us) of `lens` (events per read, any order) handed out longest first to `slots` blocks at `us_per_event`
+inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double us_per_event, double per_read_us)
+{
+    constexpr size_t kSimReads = 16384;
+    slots = std::max<size_t>(slots, 1);
+    if (lens.empty()) return 0.0;
+    uint64_t longest = 0, total = 0;
+    for (uint64_t l : lens) { longest = std::max(longest, l); total += l; }
+    if (lens.size() <= slots) return (double)longest * us_per_event + per_read_us;
+    if (lens.size() > kSimReads)
+        return std::max((double)longest * us_per_event + per_read_us,
+                        ((double)total * us_per_event + (double)lens.size() * per_read_us) / (double)slots);
+    std::sort(lens.begin(), lens.end(), std::greater<uint64_t>());
+    // a heap of block finish times (min first)
+    std::vector<double> heap(slots, 0.0);
+    auto cmp = [](double a, double b) { return a > b; };
+    double last = 0.0;
+    for (uint64_t l : lens) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        heap.back() += (double)l * us_per_event + per_read_us;
+        last = std::max(last, heap.back());
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    return last;
+}
+
+// lens = the launch's reads.  busy: other launches run beside this one (a streaming caller's batches in flight, three lanes):
+// the tail of this launch is then covered by the next one and only throughput counts -- unless the launches are so small
+// that three of them do not fill the wide sweep's block slots.
+inline Sweep choose_sweep(const std::vector<uint64_t>& lens, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates())
+{
+    if (lens.empty() || n_cu == 0) return kSweepWide;
+    if (busy && lens.size() * 3 >= wide_slots) return kSweepWide;
+    const double t_ll = lpt_makespan_us(lens, n_cu, R.ll, R.per_read_us);
+    const double t_wide = lens.size() <= n_cu ? lpt_makespan_us(lens, n_cu, R.wide_alone, R.per_read_us)
+                                              : lpt_makespan_us(lens, wide_slots, R.wide_shared, R.per_read_us);
+    return t_ll < t_wide ? kSweepLl : kSweepWide;
+}
+
+// the same decision from what a device-pointer caller states: number of reads, longest read, total events
+inline Sweep choose_sweep_bounds(size_t n_reads, uint64_t longest, uint64_t total, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates())
+{
+    if (n_reads == 0 || n_cu == 0) return kSweepWide;
+    if (busy && n_reads * 3 >= wide_slots) return kSweepWide;
+    if (longest == 0 || longest > total) longest = total / n_reads + 1;
+    auto bound = [&](size_t slots, double us) {
+        const double par = n_reads <= slots ? 0.0 : (double)total * us / (double)slots;
+        return std::max((double)longest * us, par) + R.per_read_us;
+    };
+    const double t_ll = bound(n_cu, R.ll);
+    const double t_wide = n_reads <= n_cu ? bound(n_cu, R.wide_alone) : bound(wide_slots, R.wide_shared);
+    return t_ll < t_wide ? kSweepLl : kSweepWide;
 }
 
 }  // namespace nchmm
