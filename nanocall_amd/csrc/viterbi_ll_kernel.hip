@@ -12,7 +12,7 @@
 // Same arithmetic, other ownership map:
 //   * 1024 threads.  Thread tau = 4t + y owns the 4 states j = t + 256*(4x + y), x = 0..3: exactly one step group (the four
 //     states that share their low 10 bits (y<<8)|t, Kmer.hpp:128-142 inverted) and a quarter of the skip group of low 8 bits t,
-//     whose other quarters sit in the other three lanes of the quad: two DPP swaps merge them.
+//     whose other quarters sit in the other three lanes of the quad: v_max_f32 / v_min_u32 with a DPP operand merge them.
 //   * every per-state constant lives in VGPRs (40 per thread); LDS carries only the group winners.  Producer tau's step-group
 //     winner is stored at index tau (+ a skew of 8 entries per 256 so that the readers' 16-byte lane groups fall on distinct
 //     banks): the four winners a thread needs for its four cells are then CONSECUTIVE entries -- two ds_read_b128 -- and the
@@ -57,17 +57,22 @@ __device__ __forceinline__ unsigned selm_subrev_v(mask_t mk, unsigned if_set, un
     return d;
 }
 
-// swap a (value, code) pair with the lane one / two over in the quad: both sources were written before the statement, so one
-// pair of wait states covers the two DPP reads
-__device__ __forceinline__ void swap1_pair(float v, unsigned k, float& pv, unsigned& pk)
+// maximum / minimum over the four lanes of a quad, every lane gets the result: DPP as an operand modifier -- max(lane ^ 1, own),
+// then max(lane ^ 2, own) -- two instructions where swap + compare + select would be six.  A DPP read needs two wait states
+// after the VALU write of its source (the value comes out of the statements before, and out of the first step).
+__device__ __forceinline__ float quad_max(float v)
 {
-    asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_mov_b32_dpp %1, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(pv), "=v"(pk) : "v"(v), "v"(k));
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(r) : "v"(v));
+    return r;
 }
-__device__ __forceinline__ void swap2_pair(float v, unsigned k, float& pv, unsigned& pk)
+__device__ __forceinline__ unsigned quad_min(unsigned v)
 {
-    asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_mov_b32_dpp %1, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(pv), "=v"(pk) : "v"(v), "v"(k));
+    unsigned r;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(r) : "v"(v));
+    return r;
 }
 
 struct StateLL {
@@ -107,33 +112,18 @@ __device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* 
         m4 = selm(m, v, m4);
         x4 = selm(m, (unsigned)xx + 1u, x4);
     }
-    // skip group k = 4x + y: the own quarter's winner is the step group's; the other quarters come from the other three lanes
-    // of the quad.  Strict > decides; an exact tie between quarters (the lower index would win) goes to the exact rescan
-    float m16 = m4; unsigned k16 = 4u * x4 + (yy + 1u);     // 5 + 4x + y with x = x4 - 1
-    mask_t tie_q;
-    {
-        float pm; unsigned pk;
-        swap1_pair(m16, k16, pm, pk);
-        tie_q = ballot(pm == m16);
-        const mask_t g = ballot(pm > m16);
-        m16 = selm(g, pm, m16);
-        k16 = selm(g, pk, k16);
-    }
-    {
-        float pm; unsigned pk;
-        swap2_pair(m16, k16, pm, pk);
-        tie_q |= ballot(pm == m16);
-        const mask_t g = ballot(pm > m16);
-        m16 = selm(g, pm, m16);
-        k16 = selm(g, pk, k16);
-    }
+    // skip group k = 4x + y: the own quarter's winner is the step group's; the other quarters sit in the other three lanes of the
+    // quad.  Value: the quad's maximum.  Winner: the lowest code 5 + 4x + y among the lanes that hold the maximum -- lower code
+    // = lower k, which is the reference's rule for equal values (ascending strict >, Viterbi.hpp:84)
+    const float m16 = quad_max(m4);
+    const unsigned k16 = quad_min(selm(ballot(m4 == m16), 4u * x4 + (yy + 1u), 255u));     // 5 + 4x + y with x = x4 - 1
     float s1 = S.w1 + m4, s2 = S.w2 + m16;
     unsigned sl1 = x4, sl2 = k16;
     // Is any smaller alpha rounded to the same sum?  probe the next float below the maximum (viterbi_kernel.hip)
     {
         const float c = 0x1.8p-24f;
         const float p0 = __builtin_fmaf(m4, c, m4), p2 = __builtin_fmaf(m16, c, m16);
-        const mask_t unsafe = ballot(S.w1 + p0 >= s1) | ballot(S.w2 + p2 >= s2) | tie_q;
+        const mask_t unsafe = ballot(S.w1 + p0 >= s1) | ballot(S.w2 + p2 >= s2);
         if (__builtin_expect(unsafe != 0, 0)) {
             ++S.n_rescan;
             // exact scan on the sums themselves (Viterbi.hpp:79-89 restricted to one class)
