@@ -114,7 +114,7 @@ inline OutlierPlan plan_outliers(const uint64_t* off, size_t n, const std::vecto
 // Microseconds per event, measured (profiles/r05_ll_sweep.md): a wide block with a busy neighbour on its CU, a wide block
 // alone on its CU, an ll block.
 enum Sweep : int { kSweepAuto = 0, kSweepWide = 1, kSweepLl = 2 };
-struct SweepRates { double wide_shared = 1.48, wide_alone = 1.38, ll = 0.80; double per_read_us = 60.0; };
+struct SweepRates { double wide_shared = 1.55, wide_alone = 1.15, ll = 0.85; double per_read_us = 60.0; };
 
 // makespan (us) of `lens` (events per read, any order) handed out longest first to `slots` blocks at `us_per_event`
 inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double us_per_event, double per_read_us)
@@ -143,8 +143,9 @@ inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double u
 }
 
 // lens = the launch's reads.  busy: other launches run beside this one (a streaming caller's batches in flight, three lanes):
-// the tail of this launch is then covered by the next one and only throughput counts -- unless the launches are so small
-// that three of them do not fill the wide sweep's block slots.
+// the tail of a launch is then covered by its neighbours and only throughput counts -- unless the launches are so small that
+// three of them do not fill the wide sweep's block slots.  (Three launches of 256 x 50 000-event reads in turn: 316 Mevents/s
+// wide, 288 low-latency, same box -- profiles/r05_ll_sweep.md.)
 inline Sweep choose_sweep(const std::vector<uint64_t>& lens, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates())
 {
     if (lens.empty() || n_cu == 0) return kSweepWide;

@@ -104,14 +104,9 @@ __device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* 
     // ---------------- group scans over the previous column ----------------
     // the step group is this thread's own four states: raw maximum, strict >, ascending x => first maximum; the winner is
     // carried as its back-pointer code 1 + x straight away
-    float m4 = S.alpha[0]; unsigned x4 = 1;
-#pragma unroll
-    for (int xx = 1; xx < 4; ++xx) {
-        const float v = S.alpha[xx];
-        const mask_t m = ballot(v > m4);
-        m4 = selm(m, v, m4);
-        x4 = selm(m, (unsigned)xx + 1u, x4);
-    }
+    // (maximum first -- v_max3 + v_max -- then the FIRST member that equals it: the same winner as the ascending strict-> scan)
+    const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(S.alpha[0], S.alpha[1]), S.alpha[2]), S.alpha[3]);
+    const unsigned x4 = selm(ballot(S.alpha[0] == m4), 1u, selm(ballot(S.alpha[1] == m4), 2u, selm(ballot(S.alpha[2] == m4), 3u, 4u)));
     // skip group k = 4x + y: the own quarter's winner is the step group's; the other quarters sit in the other three lanes of the
     // quad.  Value: the quad's maximum.  Winner: the lowest code 5 + 4x + y among the lanes that hold the maximum -- lower code
     // = lower k, which is the reference's rule for equal values (ascending strict >, Viterbi.hpp:84)

@@ -95,7 +95,7 @@ def test_error_codes_not_exceptions():
 
 def test_host_abi_under_sanitizers():
     """tools/asan_host.cpp: the batch plan of the host-pointer pipeline (ranges, longest-first order, outliers: nchmm_plan.hpp, 400
-    random shapes x forms), the call combiner with a host stand-in for the device (24 threads, nchmm_combine.hpp), and
+    random shapes x forms), the choice between the two forms of the sweep (schedule bounds and the decisions that must hold, 300 shapes), the call combiner with a host stand-in for the device (24 threads, nchmm_combine.hpp), and
     every device-free ABI function (model load/scale/pack, transitions, event prep incl. the
     threaded path, base sequence, FASTA, train finishes) compiled with -fsanitize=address,undefined and run on edge sizes."""
     import shutil
@@ -108,3 +108,4 @@ def test_host_abi_under_sanitizers():
         pytest.skip("libasan not installed")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "host ABI under ASan/UBSan: ok" in r.stdout and "batch plans: ok" in r.stdout and "combiner:" in r.stdout
+    assert "sweep choice: ok" in r.stdout

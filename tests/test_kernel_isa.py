@@ -1,4 +1,4 @@
-"""Structure of the compiled Viterbi forward kernel that its speed depends on and that no parity test would notice losing
+"""Structure of the compiled Viterbi forward kernels (the 8-wave form and the 16-wave low-latency form) that their speed depends on and that no parity test would notice losing
 (profiles/r03_viterbi_isa_budget.md section 2c): cross-compiles viterbi_kernel.hip to gfx950 assembly
 (no GPU needed) and checks the fast path's column loop for
   * no scratch (spill) traffic inside the loop,
@@ -26,7 +26,7 @@ def _hipflags():
             for f in p.stdout.split()]
 
 
-KERNEL_FILES = ("viterbi_kernel", "fwbw_scaled_kernel", "fwbw_kernel", "em_kernel")
+KERNEL_FILES = ("viterbi_kernel", "viterbi_ll_kernel", "fwbw_scaled_kernel", "fwbw_kernel", "em_kernel")
 
 
 @pytest.fixture(scope="module")
@@ -94,6 +94,59 @@ def test_tie_paths_are_out_of_line(fast_loop):
     assert sum(x.startswith("v_max3_f32") for x in fast_loop) == 8
     assert len(fast_loop) < 560, len(fast_loop)                      # 470 today; 740 with the tie paths inline
     assert sum(x.startswith("s_barrier") for x in fast_loop) == 1
+
+
+# ---- the low-latency form (viterbi_ll_kernel.hip): two columns per trip of its fast loop ----
+@pytest.fixture(scope="module")
+def ll_fast_loop(asm):
+    lines = asm["viterbi_ll_kernel"].split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^\S*viterbi_ll_kernel\S*:", l))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    loops = []
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m:
+            continue
+        # (the trip ends in an unconditional branch to the header; conditional branches further down that target labels inside it
+        # come back from the out-of-line rescan / tie blocks, which are not part of the fast path)
+        back = [k for k in range(i + 1, len(body)) if re.search(r"s_branch\s+" + re.escape(m.group(1)) + r"\b", body[k])]
+        if back:
+            seg = [x.split(";")[0].strip() for x in body[i:back[0] + 1]]
+            seg = [x for x in seg if x and not x.startswith(".")]
+            # two columns: per column four 3-way combines (v_max3) and the step group's maximum (one more v_max3)
+            if sum(x.startswith("s_barrier") for x in seg) == 2 and sum("v_max3_f32" in x for x in seg) == 10 and not any("v_div_scale" in x for x in seg):
+                loops.append(seg)
+    assert loops, "no fast two-column loop found in the low-latency kernel's assembly"
+    return min(loops, key=len)
+
+
+def test_ll_no_spills_in_the_column_loop(ll_fast_loop):
+    assert not [x for x in ll_fast_loop if x.startswith(("scratch_", "buffer_load", "buffer_store"))]
+    assert not [x for x in ll_fast_loop if "accvgpr" in x]
+
+
+def test_ll_hand_written_pairs_stay_adjacent(ll_fast_loop):
+    n = lambda first, second: sum(1 for i, x in enumerate(ll_fast_loop) if x.startswith(first) and ll_fast_loop[i + 1].startswith(second))
+    assert n("v_max3_f32", "v_sub_f32") >= 8                 # four cells x two columns
+    assert n("v_cndmask_b32_e64", "v_subrev_f32") >= 8
+    assert n("v_cndmask_b32_e64", "v_fma_f32") >= 8
+    assert n("v_lshl_or_b32", "v_add_f32") >= 6
+
+
+def test_ll_exchange_is_five_lds_instructions_per_column(ll_fast_loop):
+    """the group winners a thread needs are consecutive entries: two 16-byte reads per exchange array, one write per thread
+    (+ one per quad), the event record -- against 25 LDS instructions per column in the 8-wave form"""
+    lds = [x.split()[0] for x in ll_fast_loop if x.startswith("ds_")]
+    assert lds.count("ds_read_b128") == 10 and lds.count("ds_write_b64") == 4 and len(lds) == 14, lds
+    # the quad merge of the skip group: DPP as an operand modifier of v_max_f32 / v_min_u32, no lane-swap moves
+    assert sum(x.startswith("v_max_f32_dpp") for x in ll_fast_loop) == 4 and sum(x.startswith("v_min_u32_dpp") for x in ll_fast_loop) == 4
+    assert not [x for x in ll_fast_loop if x.startswith("v_mov_b32_dpp")]
+    assert not [x for x in ll_fast_loop if x.startswith("v_readfirstlane")]
+
+
+def test_ll_tie_and_rescan_paths_are_out_of_line(ll_fast_loop):
+    assert len(ll_fast_loop) < 460, len(ll_fast_loop)       # 400 today for two columns
 
 
 # ---- data hazards the compiler cannot see (tools/isa_lint.py) ----

@@ -142,4 +142,37 @@ int main(){
       }
     }
     puts("batch plans: ok"); }
+  { // which form of the sweep a launch takes (nchmm_plan.hpp: lpt_makespan_us, choose_sweep, choose_sweep_bounds)
+    std::mt19937 r(7);
+    const nchmm::SweepRates R;
+    for (int trial = 0; trial < 300; ++trial) {
+      const size_t n = 1 + r() % (trial % 9 == 0 ? 20000 : 1500), slots = 1 + r() % 600;
+      std::vector<uint64_t> lens(n);
+      uint64_t longest = 0, total = 0;
+      for (auto& l : lens) { l = r() % 7 == 0 ? 0 : 1 + r() % 6000; if (r() % 211 == 0) l = 30000 + r() % 100000; longest = std::max(longest, l); total += l; }
+      // a schedule is never shorter than its longest read nor than its share of the work, and never longer than both together
+      const double us = 0.5 + (r() % 100) / 50.0, per_read = r() % 2 ? 0.0 : 40.0;
+      const double t = nchmm::lpt_makespan_us(lens, slots, us, per_read);
+      const double lo = std::max((double)longest * us + per_read, ((double)total * us + (double)n * per_read) / (double)std::max(slots, std::min(n, slots)));
+      if (t < lo * (1 - 1e-9) - 1e-6 && n > slots) return 60;
+      if (t > (double)longest * us + per_read + ((double)total * us + (double)n * per_read) / (double)slots + 1e-6) return 61;
+      if (nchmm::lpt_makespan_us(lens, slots + 1, us, per_read) > t * (1 + 1e-9) + 1e-6 && n <= 16384) return 62;   // more blocks never hurt
+      // the decision: a launch that fits one read per CU takes the low-latency form; equal reads that fill the wide sweep's
+      // slots twice over take the wide form; a streaming caller's full launches stay wide whatever their shape
+      const size_t n_cu = 256, wide = 512;
+      const nchmm::Sweep c = nchmm::choose_sweep(lens, n_cu, wide, false, R);
+      if (c != nchmm::kSweepWide && c != nchmm::kSweepLl) return 63;
+      if (n <= n_cu && longest > 1000 && c != nchmm::kSweepLl) return 64;
+      if (n * 3 >= wide && nchmm::choose_sweep(lens, n_cu, wide, true, R) != nchmm::kSweepWide) return 65;
+      std::vector<uint64_t> equal(4 * wide, 5000);
+      if (nchmm::choose_sweep(equal, n_cu, wide, false, R) != nchmm::kSweepWide) return 66;
+      equal.resize(n_cu);
+      if (nchmm::choose_sweep(equal, n_cu, wide, false, R) != nchmm::kSweepLl || nchmm::choose_sweep_bounds(n_cu, 5000, n_cu * 5000, n_cu, wide, false, R) != nchmm::kSweepLl) return 67;
+      if (nchmm::choose_sweep_bounds(4 * wide, 5000, 4 * wide * 5000, n_cu, wide, false, R) != nchmm::kSweepWide) return 68;
+      // one read that is longer than everything else together sets the duration either way: the form that halves it wins
+      std::vector<uint64_t> skew(1000, 2000); skew[17] = 400000;
+      if (nchmm::choose_sweep(skew, n_cu, wide, false, R) != nchmm::kSweepLl || nchmm::choose_sweep_bounds(1000, 400000, 1000 * 2000 + 398000, n_cu, wide, false, R) != nchmm::kSweepLl) return 69;
+      if (nchmm::choose_sweep(std::vector<uint64_t>(), n_cu, wide, false, R) != nchmm::kSweepWide || nchmm::choose_sweep_bounds(0, 0, 0, n_cu, wide, false, R) != nchmm::kSweepWide) return 70;
+    }
+    puts("sweep choice: ok"); }
   puts("host ABI under ASan/UBSan: ok"); return 0; }

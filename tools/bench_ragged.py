@@ -26,6 +26,7 @@ del ev
 cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
 total = int(off[-1])
 ctx = na.Context(0)
+ctx.set_sweep(os.environ.get("SWEEP", "auto"))     # auto | wide | ll: which form of the sweep launches take
 ctx.put_model(0, na.scaled_model_table(t)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
 out = {"reads": R, "events": total, "len_min": int(lens.min()), "len_median": int(np.median(lens)), "len_max": int(lens.max()),
        "slots": ctx.grid_slots()}
@@ -86,4 +87,6 @@ if CHECK:
         s, mv, p = oracle.viterbi(om, ot, cm[a:b], sd[a:b], ls[a:b])
         ok &= bool(np.array_equal(s, st[a:b])) and np.float32(p).tobytes() == np.float32(lp[r]).tobytes()
     out["oracle_checked_reads"] = int(CHECK); out["oracle_equal"] = bool(ok)
+out["sweep"] = os.environ.get("SWEEP", "auto")
+out["launches_wide_ll_reads_wide_ll"] = list(ctx.sweep_stats())
 print(json.dumps(out))

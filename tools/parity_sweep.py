@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised bit-parity sweep of the Viterbi path against the CPU oracle: random builtin model, random (valid) scaling
 parameters and transition probabilities per configuration, ragged reads.  Every read must match the oracle's k-mer path
-and path log-probability bit for bit.   CONFIGS=40 READS=6 python tools/parity_sweep.py   (run on the GPU box)"""
+and path log-probability bit for bit.   CONFIGS=40 READS=6 SWEEP=auto|wide|ll python tools/parity_sweep.py   (run on the GPU box;
+READS > the number of CUs makes the plan pick the wide form for some configurations)"""
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ n_cfg, n_reads = int(os.environ.get("CONFIGS", 40)), int(os.environ.get("READS",
 rng = np.random.default_rng(int(os.environ.get("SEED", 20260101)))
 meta, tables = models._load()
 ctx = na.Context(0)
+ctx.set_sweep(os.environ.get("SWEEP", "auto"))     # auto | wide | ll: which form of the sweep is checked (nchmm_set_sweep)
 t0 = time.time()
 events = mismatches = 0
 for c in range(n_cfg):
@@ -47,5 +49,6 @@ for c in range(n_cfg):
             print(f"MISMATCH config {c} model {meta['names'][m]} params {params} trans {(p_skip, p_stay)} read {r} len {n}", flush=True)
         events += n
 print(json.dumps({"configs": n_cfg, "reads": n_cfg * n_reads, "events": events, "mismatches": mismatches,
-                  "seconds": round(time.time() - t0, 1)}))
+                  "seconds": round(time.time() - t0, 1), "sweep": os.environ.get("SWEEP", "auto"),
+                  "launches_wide_ll_reads_wide_ll": list(ctx.sweep_stats())}))
 sys.exit(1 if mismatches else 0)
