@@ -305,6 +305,105 @@ def fwbw_leg(ctx, dev, steps):
             "log_pr_data_mean": float(lpd.mean())}
 
 
+def same_shard_leg(ctx, table, dev, n_events, host_threads, steps, warmup):
+    """BASELINE config-4's per-GPU shard (12 500 reads x n_events) on this one GPU, timed exactly like the headline: W warm-up
+    steps, K steps queued on the lanes and joined once, inputs resident."""
+    import torch
+    import nanocall_amd as na
+    n = C4_READS_PER_GPU
+    off, mean, stdv, start = generate_shard(table, np.arange(n), n_events, host_threads)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    del mean, stdv, start
+    total = n * n_events
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_cm, d_sd, d_ls = (torch.from_numpy(x).to(dev) for x in (cm, sd, ls))
+    outs = [(torch.empty(total, dtype=torch.int16, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
+             torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(3)]
+    k = [0]
+
+    def step():
+        ctx.viterbi_dev_enqueue(n, n_events, total, d_off, d_cm, d_sd, d_ls, *outs[k[0] % 3])
+        k[0] += 1
+
+    for _ in range(max(1, warmup)):
+        step()
+    ctx.viterbi_dev_join()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.viterbi_dev_join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    try:
+        mhz = round(ctx.shader_clock_mhz())
+    except Exception:
+        mhz = None
+    assert (outs[0][2].cpu().numpy() == 0).all()
+    return {"value": round(total * steps / dt / 1e6, 3), "unit": "Mevents/s", "reads": n, "events_per_read": n_events, "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "shader_clock_mhz": mhz,
+            "note": "the shard one rank of the N > 1 (weak-scaling) run decodes, on one GPU: divide the N-GPU value by THIS for the scaling ratio"}
+
+
+def pool_leg(args):
+    """--pool: one process, one nchmm_pool over --gpus devices, the decode stage of the command line from host arrays
+    (nchmm_pool_basecall_reads: LPT partition by events, per-device raw copy-in + device-side event prep + tables + Viterbi +
+    winner choice, results back in input order), every host stage inside the clock.  NCHMM_BENCH_SHARE_GPU0=1 (test hook): all
+    pool members on GPU 0.  Prints one JSON line; the pool's counters come back through its one RCCL all-reduce when the
+    devices are distinct."""
+    import nanocall_amd as na
+    from nanocall_amd import api
+    share = os.environ.get("NCHMM_BENCH_SHARE_GPU0") == "1"
+    have = na.device_count()
+    if have < (1 if share else args.gpus):
+        sys.stderr.write(f"bench.py --pool: --gpus {args.gpus} requested but only {have} GPU(s) are visible\n")
+        return 2
+    ids = [0] * args.gpus if share else list(range(args.gpus))
+    n_events = args.events
+    n_reads = args.reads or (1024 if args.gpus == 1 else C4_READS_PER_GPU) * (1 if args.scaling == "strong" else args.gpus)
+    table = na.builtin_model(args.model)
+    states = np.stack([na.model_load(table)])
+    t_gen = time.perf_counter()
+    off, mean, stdv, start = generate_shard(table, np.arange(n_reads), n_events, max(1, min(32, os.cpu_count() or 1)))
+    t_gen = time.perf_counter() - t_gen
+    # template-only reads: strand 0 = the events, strand 1 empty (Fast5_Summary's strand bounds)
+    so = np.zeros(2 * n_reads + 1, np.uint64)
+    so[1::2] = off[1:]
+    so[2::2] = off[1:]
+    opts = api.train_opts()
+    jr, j0, j1 = api.train_enumerate(opts, [0], so, np.zeros(n_reads, np.uint8))
+    nj = len(jr)
+    pm = np.tile(np.float32([1, 0, 0, 1, 1, 1]), (nj, 1))
+    st = np.tile(np.float32([opts.default_p_stay, opts.default_p_skip] * 2), (nj, 1))
+    total = n_reads * n_events
+    with api.Pool(ids) as pool:
+        walls = []
+        out = None
+        for _ in range(args.warmup + args.steps):
+            t0 = time.perf_counter()
+            out = pool.basecall_reads(opts, states, so, mean, stdv, start, jr, j0, j1, pm, st)
+            walls.append(time.perf_counter() - t0)
+        counters, used_rccl = pool.counters()
+    timed = walls[args.warmup:]
+    assert (out["best_job"][:, 0] >= 0).all(), "a read was not decoded"
+    st_chk = out["states"][: min(n_reads, 64) * n_events].reshape(-1, n_events).astype(np.int64)
+    a, b = st_chk[:, :-1], st_chk[:, 1:]
+    assert ((a == b) | ((a & 1023) == (b >> 2)) | ((a & 255) == (b >> 4))).all(), "decoded path leaves the stay/step/skip graph"
+    print(json.dumps({
+        "metric": "Mevents/s Viterbi, device pool from host arrays (PCIe and host stages inclusive)", "value": round(total / float(np.mean(timed)) / 1e6, 3),
+        "unit": "Mevents/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+        "ms_per_step": round(float(np.mean(timed)) * 1e3, 3),
+        "step_ms": {"min": round(min(timed) * 1e3, 3), "median": round(float(np.median(timed)) * 1e3, 3), "max": round(max(timed) * 1e3, 3)},
+        "data": "synthetic", "dtype": "f32",
+        "config": {"workload": f"{n_reads} template-only reads x {n_events} events, builtin {args.model}, one candidate per read, through "
+                               f"nchmm_pool_basecall_reads over devices {ids}", "reads_total": n_reads, "events_per_read": n_events,
+                   "pool_devices": ids, "shared_gpu0_test_hook": share, "host_generation_s": round(t_gen, 1)},
+        "counters": {"reads": int(counters[0]), "events": int(counters[1]), "launches": int(counters[3])},
+        "counters_through_rccl": bool(used_rccl),
+        "output_sha256_16": hashlib.sha256(out["states"].tobytes() + out["best_logp"].tobytes()).hexdigest()[:16]}), flush=True)
+    return 0
+
+
 def launch_ranks(args):
     """--gpus N without a launcher: start N ranks as a child process group.  Nothing here initialises the GPU
     (torch.cuda.device_count() only counts), and the child is spawned, never exec'ed over this process."""
@@ -345,10 +444,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwbw", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-shard-leg", action="store_true",
+                    help="N = 1 only: skip `n1_same_shard` (the 12 500-read shard every rank of an N > 1 run decodes, timed on this GPU, so "
+                         "that the 1 -> N ratio of a weak-scaling series compares like with like)")
+    ap.add_argument("--pool", action="store_true",
+                    help="instead of the rank-per-GPU run: ONE process drives nchmm_pool_basecall_reads over --gpus devices from host arrays "
+                         "(what the nanocall command line does) and reports Mevents/s including every host stage")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
+    if args.pool:
+        sys.exit(pool_leg(args))
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
 
@@ -412,9 +519,11 @@ def main():
 
     d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
     d_cm, d_sd, d_ls = (torch.from_numpy(x).to(dev) for x in (cm, sd, ls))
-    # two sets of outputs: consecutive steps overlap (see below) and must not write into the same arrays
+    # one set of outputs per compute lane of the library (kVitLanes = 3): steps k and k + 3 share a lane, which orders them;
+    # steps on different lanes may be resident together and must not be handed the same arrays (include/nanocall_hip.h)
+    N_LANES = 3
     outs = [(torch.empty(total, dtype=torch.int16, device=dev), torch.empty(n_reads, dtype=torch.float32, device=dev),
-             torch.zeros(n_reads, dtype=torch.int32, device=dev)) for _ in range(1 if args.serial_launches else 2)]
+             torch.zeros(n_reads, dtype=torch.int32, device=dev)) for _ in range(1 if args.serial_launches else N_LANES)]
     d_state, d_logp, d_status = outs[0]
 
     # A step = one batch through the hot path: viterbi_kernel sweeps every read and each block walks its read back as soon as
@@ -461,23 +570,40 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ctx.synchronize()            # (reports a block that found no back-pointer region; cannot happen)
-    local_counters = np.array([int(a) - b for a, b in zip(ctx.counters(), c_settle)], dtype=np.int64)
+    local_counters = np.array([int(a) - b for a, b in zip(ctx.counters(), c_settle)] + [1], dtype=np.int64)   # last slot: "a rank was here"
+
+    # the hot kernels are VALU-issue bound, so their duration follows the shader clock -- and the boxes of one pool do not
+    # all sustain the same clock (the same binary: 15.8 ms and 23.2 ms per launch on two boxes), nor does one box hold one clock
+    # through a run.  One ~3 ms probe per leg, while that leg's load is still on the chip.
+    def clock():
+        try:
+            return ctx.shader_clock_mhz()
+        except Exception as e:          # a diagnostic must not cost the run its line
+            sys.stderr.write(f"bench.py: shader clock probe failed: {e}\n")
+            return float("nan")
+
+    sclk_mhz = clock()           # right behind the timed region
+    # every output set of the timed region: the same bits (the steps decode the same batch)
+    ref_state, ref_logp = outs[0][0].cpu().numpy().tobytes(), outs[0][1].cpu().numpy().tobytes()
+    for o in outs[1:min(len(outs), n_step[0])]:
+        assert o[0].cpu().numpy().tobytes() == ref_state and o[1].cpu().numpy().tobytes() == ref_logp, "overlapping steps returned different bits"
     # the kernel's own duration: launches one behind the other (nothing beside them), HIP events recorded by the library around
-    # each on the stream it runs on; reading them waits for that launch only.  Right behind the timed region, clocks still up.
+    # each on the stream it runs on; reading them waits for that launch only.  Wall-clocked as a whole too: the serial figure.
     kernel_ms = []
-    for _ in range(max(3, min(args.steps, 8)) if rank == 0 else 0):
+    n_serial = max(3, min(args.steps, 8))
+    torch.cuda.synchronize()
+    t_serial = time.perf_counter()
+    for _ in range(n_serial):
         ctx.viterbi_dev(n_reads, n_events, total, d_off, d_cm, d_sd, d_ls, *outs[0])
         kernel_ms.append(ctx.last_kernel_ms()[:2])
     torch.cuda.synchronize()
-    # the hot kernels are VALU-issue bound, so their duration follows the shader clock -- and the boxes of one pool do not
-    # all sustain the same clock (the same binary: 15.8 ms and 23.2 ms per launch on two boxes).  Probe it while still hot.
-    try:
-        sclk_mhz = ctx.shader_clock_mhz()
-    except Exception as e:          # a diagnostic must not cost the run its line
-        sys.stderr.write(f"bench.py: shader clock probe failed: {e}\n")
-        sclk_mhz = float("nan")
+    t_serial = time.perf_counter() - t_serial
+    sclk_serial_mhz = clock()    # right behind the serial launches
     red_dev = dev if (world > 1 and not share_gpu0) else None      # gloo reduces host tensors
-    dt = shard.max_over_ranks(dt, red_dev)
+    # per rank: wall of the timed region, shader clock behind it, the kernel alone -- one all-gather; the step time of the line is
+    # the maximum over ranks, as the contract says
+    per_rank = shard.gather_per_rank([dt, sclk_mhz, float(np.mean([k[0] for k in kernel_ms])), float(n_reads)], red_dev)
+    dt = float(per_rank[:, 0].max())
     launches_per_step = (int(local_counters[3]) - launches0) // max(1, args.steps)
     counters = shard.gather_counters(local_counters, red_dev)
 
@@ -495,10 +621,23 @@ def main():
     arc_ok = (a == b) | ((a & 1023) == (b >> 2)) | ((a & 255) == (b >> 4))
     assert arc_ok.all(), "decoded path leaves the stay/step/skip graph"
 
+    sw = ctx.sweep_stats()        # launches wide, launches ll (since the context was created: settling + warm-up + timed + serial)
+    # N = 1, config 2: the shard every rank of an N > 1 run decodes (12 500 reads), on this GPU -- the like-for-like N = 1 point
+    # of a weak-scaling series (a 12 500-read launch is 3-5 % faster per GPU than a 1024-read one: longer queue, same tail)
+    same_shard = None
+    if rank == 0 and world == 1 and not strong and not args.no_shard_leg and reads_per_gpu == 1024 and n_events == 5000:
+        try:
+            same_shard = same_shard_leg(ctx, table, dev, n_events, host_threads, args.steps, args.warmup)
+        except Exception as e:      # a secondary leg must not cost the run its headline line
+            sys.stderr.write(f"bench.py: same-shard leg failed: {e}\n")
+            same_shard = {"error": str(e)}
+
     if rank == 0:
         value = global_reads * n_events * args.steps / dt / 1e6
         k_ms = float(np.mean([k[0] for k in kernel_ms]))
         events_per_launch = total if launches_per_step <= 1 else None
+        events_per_block = total / max(1, min(ctx.grid_slots(), n_reads))
+        cyc = lambda mhz, ms: (round(mhz * ms * 1e3 / events_per_block, 1) if mhz == mhz else None)
         if strong:
             which = "config 4 as written" if (global_reads == C4_TOTAL_READS and n_events == 5000) else "custom (strong scaling)"
             workload = (f"BASELINE {which}: {global_reads} reads x {n_events} events in total, split over {world} GPU(s) by lpt_partition "
@@ -515,8 +654,8 @@ def main():
         elif share_gpu0:
             collective = f"gloo, communicator of {dist.get_world_size()} ranks all on GPU 0 (test hook)"
         else:
-            collective = (f"rccl: one all-reduce of 8 counters + one max of the step time over a communicator of "
-                          f"{dist.get_world_size()} ranks (one per GPU); nothing on the data path")
+            collective = (f"rccl: one all-reduce of 9 counters + one all-gather of 4 numbers per rank (step time, clock, kernel time, "
+                          f"reads) over a communicator of {dist.get_world_size()} ranks (one per GPU); nothing on the data path")
         result = {
             "metric": "Mevents/s Viterbi (4096-state HMM)", "value": round(value, 3), "unit": "Mevents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -530,6 +669,22 @@ def main():
                        "settling_launches_before_warmup": len(settle),
                        "host_generation_s": round(t_gen, 1)},
             "counters": {"reads": int(counters[0]), "events": int(counters[1]), "bp_bytes": int(counters[2])},
+            # taken from the all-reduced counters (every rank adds 1), not from the communicator's size
+            "ranks_in_collective": int(counters[8]),
+            # the same steps queued one behind the other (nchmm_viterbi_dev), wall-clocked right after the timed region: the
+            # figure rounds 1-3 reported as `value`, kept beside the overlapping one for comparison across rounds
+            "serial_launches": {"value": round(total * world * n_serial / t_serial / 1e6, 3) if world == 1 else None,
+                                "ms_per_step": round(t_serial / n_serial * 1e3, 3), "steps": n_serial,
+                                "launch_ms": {"min": round(float(np.min([k[0] for k in kernel_ms])), 3),
+                                              "median": round(float(np.median([k[0] for k in kernel_ms])), 3),
+                                              "max": round(float(np.max([k[0] for k in kernel_ms])), 3)},
+                                "note": "rank 0; launch_ms = hipEvents around each launch on its stream"},
+            # shader cycles a thread block spends per event of its reads (clock of the leg x time of the leg / events per block):
+            # comparable across boxes and legs where Mevents/s and ms are not
+            "cycles_per_event": {"timed_region": cyc(sclk_mhz, dt / args.steps * 1e3), "serial_launches": cyc(sclk_serial_mhz, k_ms),
+                                 "events_per_block": round(events_per_block, 1),
+                                 "note": "timed_region: overlapping steps (ms_per_step); serial_launches: a launch alone (kernel_ms); "
+                                         "each with the clock probed right behind that leg"},
             "output_sha256_16": hashlib.sha256(d_state.cpu().numpy().tobytes() + d_logp.cpu().numpy().tobytes()).hexdigest()[:16],
             "device": {"peak_mem_bytes": int(mem_free_before - mem_free_after), "library_peak_bytes": int(lib_peak),
                        "workspace_budget_mb": (int(os.environ["NCHMM_WS_BUDGET_MB"]) if os.environ.get("NCHMM_WS_BUDGET_MB") else None),
@@ -538,14 +693,26 @@ def main():
                                    "region (inputs + outputs of the batch, the library's tables, staging and back-pointer workspace); "
                                    "library_peak_bytes = the library's own share at its high-water mark (nchmm_mem_stats)",
                        "shader_clock_mhz_under_load": (round(sclk_mhz, 0) if sclk_mhz == sclk_mhz else None), "peak_shader_clock_mhz": round(SCLK_GHZ * 1e3, 0),
-                       "note": "rank 0, ~3 ms full-chip VALU probe right after the timed region (nchmm_shader_clock_mhz)"},
+                       "shader_clock_mhz_by_leg": {"timed_region": (round(sclk_mhz, 0) if sclk_mhz == sclk_mhz else None),
+                                                   "serial_launches": (round(sclk_serial_mhz, 0) if sclk_serial_mhz == sclk_serial_mhz else None)},
+                       "note": "rank 0, ~3 ms full-chip VALU probe right behind each leg (nchmm_shader_clock_mhz)"},
         }
+        if world > 1:
+            stat = lambda v: {"min": round(float(np.min(v)), 3), "median": round(float(np.median(v)), 3), "max": round(float(np.max(v)), 3)}
+            result["ranks"] = {"ms_per_step": stat(per_rank[:, 0] / args.steps * 1e3), "kernel_ms": stat(per_rank[:, 2]),
+                               "shader_clock_mhz": [round(float(x)) if x == x else None for x in per_rank[:, 1]],
+                               "reads": [int(x) for x in per_rank[:, 3]],
+                               "note": "one all-gather of four numbers per rank; `ms_per_step` of the line is the maximum"}
+        if same_shard is not None:
+            result["n1_same_shard"] = same_shard
+        kernel_name = "nchmm::viterbi_kernel" if sw[1] == 0 else ("nchmm::viterbi_ll_kernel" if sw[0] == 0 else "nchmm::viterbi_kernel + nchmm::viterbi_ll_kernel")
+        result["config"]["sweep_launches_wide_ll"] = [int(sw[0]), int(sw[1])]
         if events_per_launch:
             achieved = BYTES_PER_EVENT * events_per_launch / (k_ms * 1e-3) / 1e9
             pmc = committed_pmc(n_reads, n_events)
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "nchmm::viterbi_kernel", "kernel_ms": round(k_ms, 3),
+                    "kernel": kernel_name, "kernel_ms": round(k_ms, 3),
                     "kernel_ms_note": f"mean of {len(kernel_ms)} launches queued one behind the other right after the timed region (hipEvents "
                                       "on the launch stream): sweep + the traceback every block does when its read ends, nothing running "
                                       "beside it; in the timed region consecutive launches overlap at their edges, so a step costs "
@@ -574,12 +741,14 @@ def main():
             achieved = BYTES_PER_EVENT * total / (dt / args.steps) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                                  "kernel": f"nchmm::viterbi_kernel x{launches_per_step} per step (wall)",
+                                  "kernel": f"{kernel_name} x{launches_per_step} per step (wall)",
                                   "bytes_per_event": BYTES_PER_EVENT, "events_per_step": total,
                                   "last_launch_kernel_ms": round(k_ms, 3)}
         if world == 1 and not args.no_end_to_end and total <= 64 * 1024 * 1024:
             try:
                 result["end_to_end"] = end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, max(6, min(args.steps, 16)))
+                c_e2e = clock()
+                result["device"]["shader_clock_mhz_by_leg"]["end_to_end"] = round(c_e2e, 0) if c_e2e == c_e2e else None
             except Exception as e:      # a secondary leg must not cost the run its headline line
                 sys.stderr.write(f"bench.py: end-to-end leg failed: {e}\n")
                 result["end_to_end"] = {"error": str(e)}

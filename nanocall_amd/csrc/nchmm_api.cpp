@@ -750,14 +750,14 @@ int viterbi_check_err(nchmm_ctx* c)
 
 }  // namespace nchmm
 
-extern "C" {
+namespace {
 
-// The batch starts behind whatever is on the context's stream now and may run beside the batch queued before it (the blocks
-// of one launch start where the previous launch's blocks run out of reads).  Nothing is waited for here.
-int nchmm_viterbi_dev_enqueue(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
-                              const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
-                              const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
-                              uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
+// streaming: the caller queues batch after batch (nchmm_viterbi_dev_enqueue) -- launches run beside each other and the tail of
+// one is covered by the next; else the batch is on its own (nchmm_viterbi_dev) and its duration is what counts.
+int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max_events, size_t total_events,
+                        const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                        const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
+                        uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
 {
     if (!c) return NCHMM_E_INVALID;
     if (n_reads == 0) return NCHMM_OK;
@@ -777,13 +777,25 @@ int nchmm_viterbi_dev_enqueue(nchmm_ctx* c, size_t n_reads, size_t max_events, s
         HIP_TRY(c, hipEventRecord(c->ev_entry, c->stream));
         after = c->ev_entry;
     }
-    // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total).  A batch
-    // queued while another is in flight is a stream of launches: its tail is covered by the next one
-    bool busy = false;
-    for (int l = 0; l < kVitLanes; ++l) busy = busy || (c->lane[l].pending && hipEventQuery(c->lane[l].done) == hipErrorNotReady);
-    const int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, busy);
+    // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total)
+    const int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming);
     return launch_viterbi_range(c, after, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
                                 d_order, d_out_state, d_out_logp, d_out_status, nullptr, sweep);
+}
+
+}  // namespace
+
+extern "C" {
+
+// The batch starts behind whatever is on the context's stream now and may run beside the batch queued before it (the blocks
+// of one launch start where the previous launch's blocks run out of reads).  Nothing is waited for here.
+int nchmm_viterbi_dev_enqueue(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t total_events,
+                              const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
+                              const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
+                              uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
+{
+    return viterbi_dev_enqueue(c, true, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_order,
+                               d_out_state, d_out_logp, d_out_status);
 }
 
 // Put every batch queued by nchmm_viterbi_dev_enqueue in front of whatever comes next on the context's stream.
@@ -799,8 +811,8 @@ int nchmm_viterbi_dev(nchmm_ctx* c, size_t n_reads, size_t max_events, size_t to
                       const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
                       uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status)
 {
-    const int rc = nchmm_viterbi_dev_enqueue(c, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot,
-                                             d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status);
+    const int rc = viterbi_dev_enqueue(c, false, n_reads, max_events, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot,
+                                       d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status);
     return rc == NCHMM_OK && n_reads ? nchmm_viterbi_dev_join(c) : rc;
 }
 

@@ -91,9 +91,15 @@ struct Rccl {
         // RCCL writes its version banner / warnings to stdout unless told otherwise; a host program may be streaming
         // FASTA there (nanocall without -o), so send them to stderr -- unless the user chose a file
         setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
-        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
+        // NCHMM_RCCL_LIB names the library to load instead of the usual places (a site's own build; the tests point it at a
+        // missing file and at a library whose ncclCommInitAll fails, to walk the fall-back below)
+        if (const char* e = std::getenv("NCHMM_RCCL_LIB")) {
+            handle = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (handle) break;
+            }
         }
         if (!handle) return;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(handle, "ncclCommInitAll"));

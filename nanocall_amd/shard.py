@@ -51,3 +51,19 @@ def max_over_ranks(value, device=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_per_rank(values, device=None):
+    """One all-gather of a short float64 vector per rank -> array [world, len(values)] on every rank (row r = rank r's
+    values).  Without an initialised process group: one row."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return t.numpy().reshape(1, -1)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()

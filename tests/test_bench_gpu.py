@@ -38,6 +38,14 @@ def test_ranks_share_gpu0_and_report_whole_job_throughput(ranks):
     assert abs(d["value"] - ranks * 300 * 800 * 2 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) <= 0.01 * d["value"]
     assert "cpu_baseline" not in d and "fwbw" not in d and "end_to_end" not in d   # N = 1 only
     assert 400 <= d["device"]["shader_clock_mhz_under_load"] <= 2600
+    # what a first 8-GPU run must be readable from: the rank count as the all-reduce saw it, and every rank's own time,
+    # clock, kernel time and shard
+    assert d["ranks_in_collective"] == ranks
+    rk = d["ranks"]
+    assert rk["reads"] == [300] * ranks and len(rk["shader_clock_mhz"]) == ranks and all(400 <= c <= 2600 for c in rk["shader_clock_mhz"])
+    assert rk["ms_per_step"]["min"] <= rk["ms_per_step"]["median"] <= rk["ms_per_step"]["max"]
+    assert abs(rk["ms_per_step"]["max"] - d["ms_per_step"]) <= 0.01 * d["ms_per_step"] + 0.002
+    assert rk["kernel_ms"]["min"] > 0 and "n1_same_shard" not in d
 
 
 @pytest.mark.parametrize("ranks", [1, 2, 4])
@@ -68,3 +76,36 @@ def test_default_line_carries_every_object_of_the_contract():
     assert 0 < e["one_call"]["value"] < e["value"] * 1.05 and e["batches"] >= 5
     assert d["device"]["peak_mem_bytes"] > 0 and d["device"]["library_peak_bytes"] > 0 and len(d["output_sha256_16"]) == 16
     assert d["fwbw"]["roofline"]["frac"] > 0
+    # comparability across boxes and legs: cycles per block-event and a clock sample per leg; the serial figure beside the
+    # overlapping one; one output set per lane
+    cy = d["cycles_per_event"]
+    assert 500 < cy["timed_region"] < 6000 and 500 < cy["serial_launches"] < 6000 and cy["events_per_block"] == 5000.0
+    legs = d["device"]["shader_clock_mhz_by_leg"]
+    assert set(legs) == {"timed_region", "serial_launches", "end_to_end"} and all(400 <= v <= 2600 for v in legs.values())
+    sl = d["serial_launches"]
+    assert sl["launch_ms"]["min"] <= sl["launch_ms"]["median"] <= sl["launch_ms"]["max"] and sl["value"] > 0
+    assert d["ranks_in_collective"] == 1 and "ranks" not in d
+    assert sum(d["config"]["sweep_launches_wide_ll"]) > 0
+
+
+def test_config2_line_carries_the_shard_of_a_scaling_series():
+    """the driver's N = 1 command (config 2): `n1_same_shard` = the 12 500-read shard every rank of its N = 2 / 4 / 8 runs
+    decodes, timed on this GPU the same way -- the like-for-like denominator of the weak-scaling ratio"""
+    d = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end"], env_extra={"NCHMM_BENCH_SHARE_GPU0": "0"})
+    assert "config 2" in d["config"]["workload"] and d["config"]["sweep_launches_wide_ll"][1] == 0      # 1024 equal reads: the wide form
+    s = d["n1_same_shard"]
+    assert s["reads"] == 12500 and s["events_per_read"] == 5000 and s["steps"] == 2
+    assert abs(s["value"] - 12500 * 5000 / (s["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * s["value"]
+    assert 0.8 * d["value"] < s["value"] < 1.3 * d["value"]
+
+
+def test_pool_leg_drives_every_device_from_host_arrays():
+    """--pool: one process, nchmm_pool_basecall_reads over the devices (two members on GPU 0 here), host stages inside the clock"""
+    env = dict(os.environ, NCHMM_BENCH_SHARE_GPU0="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pool", "--gpus", "2", "--reads", "600", "--events", "800", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["pool_devices"] == [0, 0] and d["config"]["reads_total"] == 600
+    assert d["counters"]["reads"] == 600 * 3 and d["counters"]["events"] == 600 * 800 * 3 and d["counters_through_rccl"] is False
+    assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"] and d["value"] > 0

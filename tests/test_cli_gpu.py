@@ -212,6 +212,34 @@ def test_two_contexts_shard_the_reads_and_gather_counters(tmp_path):
     assert "gathered_by=rccl_allreduce" in c4 and pick(c4, "events_decoded") == pick(c1, "events_decoded")
 
 
+def test_counter_gather_falls_back_to_the_host_sum_when_rccl_cannot_be_used(tmp_path):
+    """nchmm_pool_counters' RCCL path (csrc/nchmm_pool.cpp: rccl_sum) must never cost a run its counters: librccl missing
+    (dlopen fails), librccl without the entry points, and a library whose ncclCommInitAll returns an error all end in the
+    host sum, with the same numbers and the same FASTA as the run that never tried.  NCHMM_RCCL_LIB names the library to load."""
+    files = [os.path.join(G, n + ".fast5") for n in ("r73_2d_a", "r73_1d_b")]
+    base = ["--pore", "r73", "--no-train", "--log", "info"] + files
+    pick = lambda line, key: [w for w in line.split() if w.startswith(key + "=")][0]
+    ref = run_cli(base)
+    c_ref = [l for l in ref.stderr.splitlines() if "counters reads=" in l][0]
+    assert "gathered_by=host_sum" in c_ref
+    stub = tmp_path / "stub.c"
+    stub.write_text("int ncclCommInitAll(void* c, int n, const int* d) { (void)c; (void)n; (void)d; return 2; }\n"      # ncclSystemError
+                    "int ncclCommDestroy(void* c) { (void)c; return 0; }\n"
+                    "int ncclAllReduce(const void* a, void* b, unsigned long n, int t, int o, void* c, void* s) { (void)a; (void)b; (void)n; (void)t; (void)o; (void)c; (void)s; return 2; }\n"
+                    "int ncclGroupStart(void) { return 0; }\nint ncclGroupEnd(void) { return 0; }\n")
+    empty = tmp_path / "empty.c"
+    empty.write_text("int nothing_here(void) { return 0; }\n")
+    for src in (stub, empty):
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(src.with_suffix(".so")), str(src)], check=True)
+    for lib in (str(tmp_path / "no_such_librccl.so"), str(empty.with_suffix(".so")), str(stub.with_suffix(".so"))):
+        got = run_cli(base, env={"NCHMM_POOL_FORCE_RCCL": "1", "NCHMM_RCCL_LIB": lib})
+        assert got.stdout == ref.stdout, lib
+        c = [l for l in got.stderr.splitlines() if "counters reads=" in l][0]
+        assert "gathered_by=host_sum" in c, (lib, c)
+        for k in ("reads", "events_decoded", "strands_decoded"):
+            assert pick(c, k) == pick(c_ref, k), (lib, k)
+
+
 def test_reader_processes_give_the_same_output(tmp_path):
     """--reader-procs K: K forked children read the event tables (file i from child i mod K) and stream them to the
     summary pass.  Same FASTA and --stats as the in-process reader, with more children than some have files, an
