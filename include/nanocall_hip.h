@@ -275,7 +275,11 @@ int nchmm_viterbi_dev_join(nchmm_ctx* ctx);
  * sleep in this call cost nothing); one caller alone gets a launch to itself.
  *   table_Sx6   the scaled model as nchmm_put_model takes it;  (p_skip, p_stay): transitions = compute_transitions_fast of them
  *   returns 0, NCHMM_E_NUMERIC for this strand (every state -INF/NaN in the last column), or the error of its batch.
- * While threads are inside this call the context must not be used through any other entry point.
+ * While threads are inside this call the context must not be used through any other entry point -- and every combined batch
+ * OVERWRITES the context's model and transition slots 0 .. n-1 (strand k of a batch decodes with slot k; the slot tables may
+ * grow and move): tables the caller uploaded with nchmm_put_model / nchmm_put_transitions* before are not there afterwards.
+ * The same holds for nchmm_viterbi_strand_scaled and nchmm_fwbw_windows.  Staging (pinned host memory: 128 KiB + 14 B per
+ * event a strand) follows demand: it starts at 1/64 of a full batch and doubles when batches fill up.
  * nchmm_model_image / nchmm_put_model_images are its building blocks (the device image of a model built on the caller's
  * thread; many images uploaded into consecutive slots with one copy). */
 int nchmm_viterbi_strand(nchmm_ctx* ctx, const float* table_Sx6, float p_skip, float p_stay, size_t n_events,

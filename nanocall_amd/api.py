@@ -546,6 +546,12 @@ class Context:
                                         _p(pref), _p(states), _p(bj), _p(bl))
         if rc not in (0, -6):
             check(rc, "nchmm_basecall_reads")
+        if out is not None:
+            # the library writes the states of strands that HAVE a winner; a reused array still holds the previous chunk's
+            # decode under the others (fresh arrays are zero there): clear those strands, so that the result does not depend
+            # on what the array was used for before
+            for r, s in zip(*np.nonzero(bj < 0)):
+                states[int(so[2 * r + s]):int(so[2 * r + s + 1])] = 0
         return dict(states=states, best_job=bj, best_logp=bl)
 
     # -- introspection --

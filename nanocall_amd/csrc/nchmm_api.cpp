@@ -402,7 +402,7 @@ int nchmm_synchronize(nchmm_ctx* c)
     HIP_TRY(c, hipSetDevice(c->device));
     for (int l = 0; l < kVitLanes; ++l) {
         if (c->lane[l].pending) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
-        c->lane[l].pending = false;
+        c->lane[l].pending = false; c->lane[l].joined = true;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return viterbi_check_err(c);
@@ -582,19 +582,24 @@ int viterbi_ws_budget(nchmm_ctx* c, size_t* out)
 // blocks take and return regions themselves and launches may overlap.  Reads so long that the pool would not fit: as many
 // regions as the budget holds (at least one: a read longer than the budget still runs, alone), one block per region,
 // region = block index, launches one after the other.
-int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count)
+int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count, size_t budget_share)
 {
     size_t budget = 0;
     int rc = viterbi_ws_budget(c, &budget);
     if (rc != NCHMM_OK) return rc;
+    // (a batch with outliers keeps 30 % of the budget for their regions: the pool and its head-room get the rest, nchmm_plan.hpp)
+    if (budget_share && budget_share < budget) budget = budget_share;
     const size_t need = (size_t)std::max<uint64_t>(longest, 1) * kBpRowBytes;
     // blocks of up to kVitLanes launches can sit on one XCD at a time
     const unsigned per_xcd = (unsigned)std::min<size_t>(c->slots_per_xcd, std::max<size_t>(count, 1) * kVitLanes);
     const bool want_pooled = need <= budget / ((size_t)kXcds * per_xcd);
     if (c->d_ws && need <= c->slot_bytes && ((c->ws_pooled && per_xcd <= c->ws_per_xcd) || (!c->ws_pooled && !want_pooled))) return NCHMM_OK;
-    // (re)allocate: nothing may be using the regions
-    for (int l = 0; l < kVitLanes; ++l)
-        if (c->lane[l].pending) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+    // (re)allocate: nothing may be using the regions.  Unconditionally: a join only queues a stream wait, the kernels of a
+    // joined batch may still be running
+    for (int l = 0; l < kVitLanes; ++l) {
+        HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+        c->lane[l].pending = false; c->lane[l].joined = true;
+    }
     const unsigned per_xcd_new = c->ws_pooled ? std::max(per_xcd, c->ws_per_xcd) : per_xcd;
     const size_t keep_slot = c->ws_pooled ? c->slot_bytes : 0;
     if (c->d_ws) {
@@ -630,8 +635,10 @@ int viterbi_big_prepare(nchmm_ctx* c, uint64_t longest, size_t n_long, size_t bu
     const size_t need = ((size_t)std::max<uint64_t>(longest, 1) * kBpRowBytes + 4095) & ~(size_t)4095;
     const size_t regions = std::min<size_t>(std::min<size_t>(std::max<size_t>(n_long, 1), (size_t)std::max(c->vit_slots, 1)), std::max<size_t>(budget_big / need, 1));
     if (c->d_ws_big && need <= c->big_slot_bytes && regions <= c->big_regions) return NCHMM_OK;
-    for (int l = 0; l < kVitLanes; ++l)      // (re)allocate: a launch of outliers may be using the regions
-        if (c->lane[l].pending) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+    for (int l = 0; l < kVitLanes; ++l) {    // (re)allocate: a launch of outliers may be using the regions
+        HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
+        c->lane[l].pending = false; c->lane[l].joined = true;
+    }
     if (c->d_ws_big) {
         HIP_TRY(c, hipFree(c->d_ws_big));
         c->counters[6] -= c->big_slot_bytes * c->big_regions;
@@ -675,17 +682,19 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     const size_t slots = std::min<size_t>(pooled ? (size_t)c->vit_slots : regions, ll ? (size_t)c->n_cu : (size_t)-1);
     const int grid = (int)std::min<size_t>(slots, count);
     a.queue_base = L.vq_base;
-    L.vq_base += (unsigned)count + (unsigned)grid;   // every read takes a ticket, every block one more to find the queue empty
     if (after) HIP_TRY(c, hipStreamWaitEvent(L.stream, after, 0));
     if (serial_after) HIP_TRY(c, hipStreamWaitEvent(L.stream, serial_after, 0));
     HIP_TRY(c, hipEventRecord(L.ev0, L.stream));
     if (ll) launch_viterbi_ll(a, grid, L.stream); else launch_viterbi(a, grid, L.stream);
     HIP_TRY(c, hipGetLastError());
+    // every read takes a ticket, every block one more to find the queue empty -- counted only once the launch is in the queue
+    // (a failure above must leave the lane's ticket base where the device's queue head will be)
+    L.vq_base += (unsigned)count + (unsigned)grid;
     c->sweep_stats[ll ? 1 : 0] += 1;
     c->sweep_stats[ll ? 3 : 2] += count;
     HIP_TRY(c, hipEventRecord(L.ev1, L.stream));
     HIP_TRY(c, hipEventRecord(L.done, L.stream));
-    L.pending = true;
+    L.pending = true; L.joined = false;
     c->last_lane = li;
     c->next_lane = (li + 1) % kVitLanes;
     c->vit_timed = true;
@@ -731,9 +740,9 @@ int viterbi_join(nchmm_ctx* c, hipStream_t s)
 {
     for (int l = 0; l < kVitLanes; ++l) {
         VitLaneState& L = c->lane[l];
-        if (!L.pending) continue;
+        if (!L.pending || (L.joined && L.joined_to == s)) continue;
         if (L.stream != s) HIP_TRY(c, hipStreamWaitEvent(s, L.done, 0));
-        L.pending = false;
+        L.joined = true; L.joined_to = s;      // (pending stays set: no host-side wait has seen the launch finish -- nchmm_synchronize and the reallocations do)
     }
     return NCHMM_OK;
 }

@@ -35,6 +35,7 @@ struct CombineCore {
     size_t callers = 0;
     std::atomic<size_t> ready{0}, consumed{0};                // written outside m_
     bool has_leader = false, closed = false;                  // closed: from the leader's close until its last caller has left
+    bool resizing = false;                                    // its staging is being re-allocated by one caller, m_ released
     // completion has its own lock: the hundreds of callers that wake up when a batch is done do not queue on m_, where the
     // next batch is being joined and led
     std::mutex dm;
@@ -54,7 +55,7 @@ class BatchCombiner {
 public:
     BatchCombiner(Runner r, const size_t max_cap[kCombineDims], unsigned linger_us) : runner_(r), linger_us_(linger_us)
     {
-        for (int d = 0; d < kCombineDims; ++d) max_[d] = max_cap[d] ? max_cap[d] : 1;
+        for (int d = 0; d < kCombineDims; ++d) { max_[d] = max_cap[d] ? max_cap[d] : 1; want_[d] = std::max<size_t>(max_[d] / 64, 1); }
     }
     ~BatchCombiner() { for (Batch& B : b_) runner_.release(B); }
     BatchCombiner(const BatchCombiner&) = delete;
@@ -70,20 +71,32 @@ public:
         Batch* B = nullptr;
         for (;;) {
             B = &b_[open_];
+            if (B->resizing) { cv_.wait(lk); continue; }     // (another caller is re-allocating its staging, outside the lock)
             if (!B->closed) {
+                // the staging of a batch follows demand: it starts at 1/64 of the capacity (one caller decoding one strand at a
+                // time never needs more) and doubles whenever a batch was found full, up to max_
                 bool small = false;
-                for (int d = 0; d < kCombineDims; ++d) small = small || B->cap[d] < std::max(max_[d], need[d]);
+                for (int d = 0; d < kCombineDims; ++d) small = small || B->cap[d] < std::max(want_[d], need[d]);
                 if (B->callers == 0 && small) {
-                    // an empty batch: nobody reads its staging, (re)size it here (a piece larger than a batch still goes: alone)
+                    // an empty batch: nobody reads its staging, (re)size it -- with the lock released (pinned allocations of this
+                    // size take milliseconds; callers that arrive meanwhile wait above).  A piece larger than a batch still goes: alone
                     size_t cap[kCombineDims];
-                    for (int d = 0; d < kCombineDims; ++d) cap[d] = std::max(max_[d], need[d]);
+                    for (int d = 0; d < kCombineDims; ++d) cap[d] = std::max(want_[d], need[d]);
+                    B->resizing = true;
+                    lk.unlock();
                     const int rc = runner_.alloc(*B, cap);
+                    lk.lock();
+                    B->resizing = false;
+                    cv_.notify_all();
                     if (rc != 0) return rc;
+                    continue;
                 }
                 bool fits = true;
                 for (int d = 0; d < kCombineDims; ++d) fits = fits && B->used[d] + need[d] <= B->cap[d];
                 if (fits) break;
                 if (B->callers == 0) return -1;          // (cannot happen: an empty batch was just sized for this piece)
+                for (int d = 0; d < kCombineDims; ++d)   // the next empty batch is sized for more
+                    if (B->used[d] + need[d] > B->cap[d]) want_[d] = std::min(max_[d], std::max(want_[d] * 2, B->used[d] + need[d]));
                 full_batch_ = B;                         // no room: its leader need not linger any longer
                 full_.notify_all();
             }
@@ -102,7 +115,9 @@ public:
         if (lead) {
             std::unique_lock<std::mutex> run(run_m_);      // the batch before this one is on the device: meanwhile callers join
             lk.lock();
-            if (full_batch_ != B && linger_us_)             // nothing to wait behind (or it was quick): give concurrent callers a moment
+            // nothing to wait behind (or it was quick): give concurrent callers a moment -- unless the batch before this one had a
+            // single caller too (one thread decoding strand after strand, the reference's default -t 1: nobody else will come)
+            if (full_batch_ != B && linger_us_ && (last_callers_ > 1 || B->callers > 1))
                 // (system_clock: pthread_cond_timedwait, which ThreadSanitizer can follow -- steady_clock waits go through
                 // pthread_cond_clockwait, which gcc 11's does not intercept; a clock step only lengthens or shortens one linger)
                 full_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(linger_us_), [&] { return full_batch_ == B; });
@@ -110,6 +125,7 @@ public:
             B->closed = true;
             open_ ^= 1;
             const size_t n = B->callers;
+            last_callers_ = n;
             lk.unlock();
             cv_.notify_all();                               // callers waiting for an open batch
             while (B->ready.load(std::memory_order_acquire) < n) std::this_thread::yield();
@@ -141,12 +157,14 @@ public:
 private:
     Runner runner_;
     size_t max_[kCombineDims];
+    size_t want_[kCombineDims];      // what an empty batch is sized for now (<= max_; under m_)
     const unsigned linger_us_;
     std::mutex m_, run_m_;
     std::condition_variable cv_, full_;
     Batch b_[2];
     Batch* full_batch_ = nullptr;    // the open batch somebody found no room in (its leader stops lingering)
     unsigned open_ = 0;
+    size_t last_callers_ = 2;        // callers of the batch closed last (the first batch lingers)
 };
 
 // ---- payload of nchmm_viterbi_strand: one strand = one item, its events, one model image ----

@@ -31,7 +31,9 @@ struct VitLaneState {
     unsigned vq_base = 0;            // what this lane's queue head will read when its next launch starts (never reset)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the lane's most recent launch (timing)
     hipEvent_t done = nullptr;       // behind the lane's most recent launch (ordering)
-    bool pending = false;            // work queued since the last join
+    bool pending = false;            // work queued that no HOST-side wait has seen finish (cleared by a stream / event synchronise only)
+    bool joined = true;              // ... and a stream already waits for it (viterbi_join queued the stream wait on joined_to)
+    hipStream_t joined_to = nullptr;
 };
 }  // namespace nchmm
 
@@ -115,8 +117,8 @@ void pipe_destroy(nchmm_ctx* c);
 void combine_destroy(nchmm_ctx* c);
 int pipe_in_flight(const nchmm_ctx* c);
 // Size the back-pointer regions for launches of up to `count` reads of up to `longest` events (reallocates only when every
-// lane is idle).
-int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count);
+// lane is idle).  budget_share > 0: the part of the workspace budget the pool may take (the rest belongs to the outliers' regions).
+int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count, size_t budget_share = 0);
 // Queue one launch (sweep + in-block traceback) for reads [first, first + count) on the next lane; *lane_out = that lane.
 // The launch starts after `after` (an event, may be null) and after the lane's previous launch.  viterbi_ws_prepare first.
 // sweep: nchmm::kSweepWide / kSweepLl (the caller has decided, nchmm_plan.hpp); the context's sweep_mode overrides it when forced.

@@ -220,7 +220,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         HIP_TRY(c, hipHostMalloc(&hp, h_need + h_need / 8, hipHostMallocDefault));
         K.h = (char*)hp; K.h_bytes = h_need + h_need / 8;
     }
-    if ((rc = viterbi_ws_prepare(c, pool_longest, biggest))) return rc;   // (waits for the batch in flight if the regions must grow)
+    if ((rc = viterbi_ws_prepare(c, pool_longest, biggest, outliers.empty() ? 0 : budget - plan.budget_big))) return rc;   // (waits for the batch in flight if the regions must grow)
     char* const d = (char*)P->d_stage[slot];
     K.direct = direct; K.n = n; K.total = total; K.d = d;
     K.o_state = o_st; K.o_logp = o_lp; K.o_status = o_ss;
@@ -435,7 +435,7 @@ int pipe_release(nchmm_ctx* c)
     P->next_end = (P->next_end + 1u) % (unsigned)kPipeDepth;
     P->in_flight -= 1;
     HIP_TRY(c, e);
-    return NCHMM_OK;
+    return viterbi_check_err(c);      // a block that found no back-pointer region: NCHMM_E_HIP here, not a stale flag for the next call
 }
 
 }  // namespace nchmm
@@ -532,7 +532,7 @@ int begin_raw(nchmm_ctx* c, size_t n_raw, const float* mean, const float* stdv, 
     if (!src || !len || !drift || !out_logp || (n_raw && (!mean || !stdv || !start))) return NCHMM_E_INVALID;
     std::vector<uint64_t> off(n_cand + 1, 0);
     for (size_t v = 0; v < n_cand; ++v) {
-        if (src[v] + len[v] > n_raw) return NCHMM_E_INVALID;
+        if (src[v] > n_raw || len[v] > n_raw - src[v]) return NCHMM_E_INVALID;
         off[v + 1] = off[v] + len[v];
     }
     const size_t total = (size_t)off[n_cand];
@@ -555,7 +555,7 @@ int nchmm::pipe_raw_tables_begin(nchmm_ctx* c, size_t n_raw, const float* mean, 
     if (!tab.states_Sx10 || !tab.table_idx || !tab.params_nx6 || !tab.p_skip || !tab.p_stay || tab.n_tables == 0) return NCHMM_E_INVALID;
     std::vector<uint64_t> off(n_cand + 1, 0);
     for (size_t v = 0; v < n_cand; ++v) {
-        if (src[v] + len[v] > n_raw || tab.table_idx[v] < 0 || (size_t)tab.table_idx[v] >= tab.n_tables) return NCHMM_E_INVALID;
+        if (src[v] > n_raw || len[v] > n_raw - src[v] || tab.table_idx[v] < 0 || (size_t)tab.table_idx[v] >= tab.n_tables) return NCHMM_E_INVALID;
         off[v + 1] = off[v] + len[v];
     }
     HIP_TRY(c, hipSetDevice(c->device));
