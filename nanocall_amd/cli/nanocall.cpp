@@ -291,58 +291,66 @@ static std::string read_text_or_gzip(const std::string& fn, const char* what)
     return text;
 }
 
-static void init_models(Pore_Model_Dict_Type& models)
+// One "<strand>:<file>" model argument (strand 0, 1, or 2 = both) -- the reference's syntax and message (nanocall.cpp:99-109).
+struct Model_Arg { unsigned strand; std::string file; };
+static Model_Arg model_arg(const std::string& spec)
 {
-    auto parse_model_name = [](const std::string& s) {
-        if (s.size() < 3 || (s[0] != '0' && s[0] != '1' && s[0] != '2') || s[1] != ':') {
-            LOG(error) << "could not parse model name: \"" << s << "\"; format should be \"[0|1|2]:<file>\"" << std::endl;
-            std::exit(EXIT_FAILURE);
-        }
-        return std::make_pair((unsigned)(s[0] - '0'), s.substr(2));
-    };
-    std::map<unsigned, std::list<std::string>> model_list;
-    for (const auto& s : opts::model_fn.get()) {
-        auto p = parse_model_name(s);
-        model_list[p.first].push_back(p.second);
-    }
-    if (!opts::model_fofn.get().empty()) {
-        std::istringstream ifs(read_text_or_gzip(opts::model_fofn.get(), "model fofn"));
-        std::string s;
-        while (std::getline(ifs, s)) {
-            auto p = parse_model_name(s);
-            model_list[p.first].push_back(p.second);
-        }
-    }
-    if (model_list[2].empty() && (model_list[0].empty() != model_list[1].empty())) {
-        LOG(error) << "models were specified only for strand " << (int)model_list[0].empty() << "! give models for both strands, or for neither." << std::endl;
+    const bool well_formed = spec.size() >= 3 && spec[1] == ':' && spec[0] >= '0' && spec[0] <= '2';
+    if (!well_formed) {
+        LOG(error) << "could not parse model name: \"" << spec << "\"; format should be \"[0|1|2]:<file>\"" << std::endl;
         std::exit(EXIT_FAILURE);
     }
-    if (!(model_list[0].empty() && model_list[1].empty() && model_list[2].empty())) {
-        for (unsigned st = 0; st < 3; ++st)
-            for (const auto& e : model_list[st]) {
-                Pore_Model_Type pm;
-                const std::string text = read_text_or_gzip(e, "model file");
-                std::istringstream ifs(text);
-                try { ifs >> pm; } catch (const std::exception& x) { LOG(error) << e << ": " << x.what() << std::endl; std::exit(EXIT_FAILURE); }
-                pm.strand() = st;
-                LOG(info) << "loaded module [" << e << "] for strand [" << st << "] statistics [mean=" << pm.mean() << ", stdv=" << pm.stdv() << "]" << std::endl;
-                models[e] = std::move(pm);
-            }
-    } else {
+    return Model_Arg{(unsigned)(spec[0] - '0'), spec.substr(2)};
+}
+
+static void log_loaded(const char* kind, const std::string& name, unsigned strand, const Pore_Model_Type& pm)
+{
+    LOG(info) << "loaded " << kind << " [" << name << "] for strand [" << strand << "] statistics [mean=" << pm.mean() << ", stdv=" << pm.stdv() << "]" << std::endl;
+}
+
+// Which pore models the run uses (what init_models does, nanocall.cpp:97-176): the files named by --model / --model-fofn when
+// there are any -- for both strands or for neither -- else the builtin tables of the chosen pore.
+static void init_models(Pore_Model_Dict_Type& models)
+{
+    std::vector<Model_Arg> args;
+    for (const std::string& spec : opts::model_fn.get()) args.push_back(model_arg(spec));
+    if (!opts::model_fofn.get().empty()) {
+        std::istringstream lines(read_text_or_gzip(opts::model_fofn.get(), "model fofn"));
+        for (std::string spec; std::getline(lines, spec);) args.push_back(model_arg(spec));
+    }
+    if (args.empty()) {
+        const std::string prefix = opts::pore.get() + ".";
         for (unsigned i = 0; i < Builtin_Model::num(); ++i) {
-            const std::string pm_name = Builtin_Model::names(i);
-            if (pm_name.compare(0, opts::pore.get().size() + 1, opts::pore.get() + ".")) continue;
-            Pore_Model_Type pm;
+            const std::string name = Builtin_Model::names(i);
+            if (name.compare(0, prefix.size(), prefix) != 0) continue;
+            Pore_Model_Type& pm = models[name];
             pm.load_from_vector(Builtin_Model::init_lists(i));
             pm.strand() = Builtin_Model::strands(i);
-            LOG(info) << "loaded builtin module [" << pm_name << "] for strand [" << pm.strand() << "] statistics [mean=" << pm.mean() << ", stdv=" << pm.stdv() << "]" << std::endl;
-            models[pm_name] = std::move(pm);
+            log_loaded("builtin module", name, pm.strand(), pm);
         }
         if (models.empty()) {
             LOG(error) << "no builtin models found for pore [" << opts::pore.get() << "]" << std::endl;
             std::exit(EXIT_FAILURE);
         }
+        return;
     }
+    size_t per_strand[3] = {0, 0, 0};
+    for (const Model_Arg& a : args) ++per_strand[a.strand];
+    if (per_strand[2] == 0 && (per_strand[0] == 0) != (per_strand[1] == 0)) {
+        LOG(error) << "models were specified only for strand " << (int)(per_strand[0] == 0) << "! give models for both strands, or for neither." << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    // strand by strand, each strand's files in the order they were given (the reference's map of lists)
+    for (unsigned strand = 0; strand < 3; ++strand)
+        for (const Model_Arg& a : args) {
+            if (a.strand != strand) continue;
+            std::istringstream text(read_text_or_gzip(a.file, "model file"));
+            Pore_Model_Type pm;
+            try { text >> pm; } catch (const std::exception& x) { LOG(error) << a.file << ": " << x.what() << std::endl; std::exit(EXIT_FAILURE); }
+            pm.strand() = strand;
+            log_loaded("module", a.file, strand, pm);
+            models[a.file] = std::move(pm);
+        }
 }
 
 static void init_transitions(State_Transitions_Type& transitions)

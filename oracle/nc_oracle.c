@@ -427,6 +427,37 @@ float nco_viterbi_fill(const nco_model* pm, const nco_transitions* st, nco_event
     return path_probability;
 }
 
+/* How many cells (i >= 1, j) of Viterbi::fill's matrix have their maximum attained by TWO OR MORE predecessors with exactly
+ * equal floats (Viterbi.hpp:79-89: the ascending strict-> scan then keeps the lowest index).  SURVEY.md section 0.7 records this
+ * count from a probe of the real reference (866 of 12.3 M cells on a 3 000-event read); tests/test_reference_pins.py compares.
+ * Two rows of alpha only: the count needs no back-pointers. */
+uint64_t nco_viterbi_tie_cells(const nco_model* pm, const nco_transitions* st, size_t n, const float* corrected_mean,
+                               const float* stdv, const float* log_stdv)
+{
+    if (n == 0) return 0;
+    float* prev = (float*)malloc(sizeof(float) * NCO_N_STATES);
+    float* cur = (float*)malloc(sizeof(float) * NCO_N_STATES);
+    if (!prev || !cur) { free(prev); free(cur); return (uint64_t)-1; }
+    const float log_n_states = logf((float)NCO_N_STATES);
+    for (unsigned j = 0; j < NCO_N_STATES; ++j)
+        prev[j] = nco_log_pr_corrected_emission(&pm->st[j], corrected_mean[0], stdv[0], log_stdv[0]) - log_n_states;
+    uint64_t ties = 0;
+    for (size_t i = 1; i < n; ++i) {
+        for (unsigned j = 0; j < NCO_N_STATES; ++j) {
+            float a = -INFINITY; unsigned at_max = 0;
+            for (uint32_t k = st->from_ptr[j]; k < st->from_ptr[j + 1]; ++k) {
+                const float v = st->from_logw[k] + prev[st->from_idx[k]];
+                if (v > a) { a = v; at_max = 1; } else if (v == a) ++at_max;
+            }
+            ties += at_max > 1;
+            cur[j] = a + nco_log_pr_corrected_emission(&pm->st[j], corrected_mean[i], stdv[i], log_stdv[i]);
+        }
+        float* t = prev; prev = cur; cur = t;
+    }
+    free(prev); free(cur);
+    return ties;
+}
+
 float nco_viterbi_soa(const nco_model* pm, const nco_transitions* st, size_t n,
                       const float* corrected_mean, const float* stdv, const float* log_stdv,
                       uint16_t* out_state, int32_t* out_move)

@@ -102,6 +102,8 @@ size_t nco_write_fasta(char* out, size_t cap, const char* name, const char* seq,
  * leaves events untouched when n == 0 or allocation fails. */
 float nco_viterbi_fill(const nco_model* pm, const nco_transitions* st, nco_event* ev, size_t n);
 /* convenience for ctypes: SoA in, arrays out */
+uint64_t nco_viterbi_tie_cells(const nco_model* pm, const nco_transitions* st, size_t n, const float* corrected_mean,
+                               const float* stdv, const float* log_stdv);
 float nco_viterbi_soa(const nco_model* pm, const nco_transitions* st, size_t n,
                       const float* corrected_mean, const float* stdv, const float* log_stdv,
                       uint16_t* out_state, int32_t* out_move);

@@ -7,8 +7,9 @@
 //                                            compute_transitions_fast, apply_drift_correction, Viterbi::fill, path_probability)
 //
 // If this file compiles and its output matches the oracle (tests/test_cpp_layer_gpu.py), a maintainer who swaps the
-// reference headers for this one keeps those call sites as they are.  Only what the reference takes from elsewhere is
-// stubbed here: `opts::` values, LOG, and a read_summary holding the members those lines touch.
+// reference headers for this one keeps those call sites as they are.  The member calls and their argument lists are the
+// reference's; the control flow around them, the locals and the output are this file's own.  What the reference takes from
+// elsewhere is stubbed: `opts::` values and a read_summary holding the members those calls touch.
 //
 //   reference_call_sites <template.events> <complement.events> <model_0> <model_1> <num_events> <max_rounds> <train_drift>
 //   (event files: "mean stdv start length" per line, Event operator>>, Event.hpp:59-68)
@@ -23,20 +24,18 @@
 using namespace std;
 using namespace nanocall_amd;
 
-#define FLOAT_TYPE float
+// (the reference fixes these two with -D on its command line)
+#define FLOAT_TYPE float   /* fp32 throughout */
 #define KMER_SIZE 6
-typedef State_Transitions<FLOAT_TYPE, KMER_SIZE> State_Transitions_Type;
-typedef State_Transition_Parameters<FLOAT_TYPE> State_Transition_Parameters_Type;
-typedef Pore_Model<FLOAT_TYPE, KMER_SIZE> Pore_Model_Type;
-typedef Pore_Model_Dict<FLOAT_TYPE, KMER_SIZE> Pore_Model_Dict_Type;
-typedef Pore_Model_Parameters<FLOAT_TYPE> Pore_Model_Parameters_Type;
-typedef Event<FLOAT_TYPE, KMER_SIZE> Event_Type;
-typedef Event_Sequence<FLOAT_TYPE, KMER_SIZE> Event_Sequence_Type;
-typedef Parameter_Trainer<FLOAT_TYPE, KMER_SIZE> Parameter_Trainer_Type;
-typedef Viterbi<FLOAT_TYPE, KMER_SIZE> Viterbi_Type;
-
-#define LOG(...) if (true) {} else std::clog
-enum { debug, info, warning };
+using State_Transitions_Type = State_Transitions<FLOAT_TYPE, KMER_SIZE>;
+using State_Transition_Parameters_Type = State_Transition_Parameters<FLOAT_TYPE>;
+using Pore_Model_Type = Pore_Model<FLOAT_TYPE, KMER_SIZE>;
+using Pore_Model_Dict_Type = Pore_Model_Dict<FLOAT_TYPE, KMER_SIZE>;
+using Pore_Model_Parameters_Type = Pore_Model_Parameters<FLOAT_TYPE>;
+using Event_Type = Event<FLOAT_TYPE, KMER_SIZE>;
+using Event_Sequence_Type = Event_Sequence<FLOAT_TYPE, KMER_SIZE>;
+using Parameter_Trainer_Type = Parameter_Trainer<FLOAT_TYPE, KMER_SIZE>;
+using Viterbi_Type = Viterbi<FLOAT_TYPE, KMER_SIZE>;
 
 namespace opts {
 bool no_train_scaling = false, no_train_transitions = false;
@@ -48,8 +47,9 @@ float scaling_min_progress = 1.0;
 struct Read_Summary {
     string read_id = "read";
     array<Event_Sequence_Type, 2> ev;
-    map<array<string, 2>, Pore_Model_Parameters_Type> pm_params_m;
-    map<array<string, 2>, array<State_Transition_Parameters_Type, 2>> st_params_m;
+    typedef array<string, 2> Model_Pair;     // (template model, complement model)
+    map<Model_Pair, Pore_Model_Parameters_Type> pm_params_m;
+    map<Model_Pair, array<State_Transition_Parameters_Type, 2>> st_params_m;
     const Event_Sequence_Type& events(unsigned st) const { return ev[st]; }
 };
 
@@ -59,7 +59,7 @@ static void print_hex(const char* tag, const Pore_Model_Parameters_Type& p, cons
          << s[0].p_stay << " " << s[0].p_skip << " " << s[1].p_stay << " " << s[1].p_skip << defaultfloat;
 }
 
-int main(int argc, char* argv[])
+int main(int argc, char** argv)
 {
     if (argc != 8) { cerr << "usage: reference_call_sites ev0 ev1 model0 model1 num_events max_rounds train_drift" << endl; return 2; }
     Read_Summary read_summary;
@@ -76,7 +76,7 @@ int main(int argc, char* argv[])
     State_Transition_Parameters_Type::default_p_skip() = .3f;
 
     // init_models, nanocall.cpp:157-170
-    Pore_Model_Dict_Type models;
+    Pore_Model_Dict_Type models = Pore_Model_Dict_Type();
     for (unsigned i = 0; i < Builtin_Model::num(); ++i) {
         Pore_Model_Type pm;
         pm.load_from_vector(Builtin_Model::init_lists(i));
@@ -84,39 +84,40 @@ int main(int argc, char* argv[])
         models[Builtin_Model::names(i)] = move(pm);
     }
     // init_transitions, :189
-    State_Transitions_Type default_transitions;
+    State_Transitions_Type default_transitions = State_Transitions_Type();
     default_transitions.compute_transitions_fast(.3f, .1f);
     Parameter_Trainer_Type::init();   // :280
 
-    // train_event_seqs, :327-338
-    array<vector<Event_Sequence_Type>, 2> train_event_seqs;
-    for (unsigned st = 0; st < 2; ++st) {
-        unsigned num_train_events = min((size_t)opts::scaling_num_events, read_summary.events(st).size());
-        train_event_seqs[st].emplace_back(read_summary.events(st).begin(), read_summary.events(st).begin() + num_train_events / 2);
-        train_event_seqs[st].emplace_back(read_summary.events(st).end() - num_train_events / 2, read_summary.events(st).end());
+    // the training windows of the read: the first and the last scaling_num_events / 2 events of either strand (what
+    // nanocall.cpp:327-352 builds), as (sequence, strand) pairs
+    array<vector<Event_Sequence_Type>, 2> windows_of_strand;
+    for (unsigned st : {0u, 1u}) {
+        const Event_Sequence_Type& all = read_summary.events(st);
+        const size_t half = min((size_t)opts::scaling_num_events, all.size()) / 2;
+        windows_of_strand[st].emplace_back(all.begin(), all.begin() + half);
+        windows_of_strand[st].emplace_back(all.end() - half, all.end());
     }
-    vector<pair<const Event_Sequence_Type*, unsigned>> train_event_seq_ptrs;   // :345-352
-    for (unsigned st = 0; st < 2; ++st)
-        for (const auto& events : train_event_seqs[st]) train_event_seq_ptrs.push_back(make_pair(&events, st));
-    array<string, 2> m_name_key = {{m_name_0, m_name_1}};
+    vector<pair<const Event_Sequence_Type*, unsigned>> train_event_seq_ptrs = {};
+    for (unsigned st : {0u, 1u})
+        for (const Event_Sequence_Type& w : windows_of_strand[st]) train_event_seq_ptrs.emplace_back(&w, st);
+    const array<string, 2> m_name_key = {{m_name_0, m_name_1}};
     read_summary.pm_params_m[m_name_key] = Pore_Model_Parameters_Type();
-    read_summary.st_params_m[m_name_key][0] = State_Transition_Parameters_Type();
-    read_summary.st_params_m[m_name_key][1] = State_Transition_Parameters_Type();
-    map<array<string, 2>, FLOAT_TYPE> model_fit;
+    read_summary.st_params_m[m_name_key] = {{State_Transition_Parameters_Type(), State_Transition_Parameters_Type()}};
 
-    // ---------------- the 2D round loop, nanocall.cpp:360-426 ----------------
+    // ---- call site 1: Parameter_Trainer::train_one_round inside the round loop of train_reads ----
+    // The CALL below is the reference's statement (nanocall.cpp:374-381), argument for argument; the loop around it states the
+    // reference's three exits (singular system; fit got worse: roll back; round budget or too little progress, :398-420) in
+    // this file's own words.
     {
-        string m_name = m_name_0 + "+" + m_name_1;
-        unsigned round = 0;
-        auto& crt_pm_params = read_summary.pm_params_m.at(m_name_key);
-        auto& crt_st_params = read_summary.st_params_m.at(m_name_key);
-        auto& crt_fit = model_fit[m_name_key];
-        crt_fit = -INFINITY;
-        while (true) {
-            Pore_Model_Parameters_Type old_pm_params(crt_pm_params);
-            std::array<State_Transition_Parameters_Type, 2> old_st_params(crt_st_params);
-            auto old_fit = crt_fit;
-            bool done;
+        Pore_Model_Parameters_Type& crt_pm_params = read_summary.pm_params_m.at(m_name_key);
+        array<State_Transition_Parameters_Type, 2>& crt_st_params = read_summary.st_params_m.at(m_name_key);
+        FLOAT_TYPE crt_fit = -INFINITY;
+        unsigned rounds_done = 0;
+        for (bool more = true; more;) {
+            const Pore_Model_Parameters_Type old_pm_params = crt_pm_params;
+            const array<State_Transition_Parameters_Type, 2> old_st_params = crt_st_params;
+            const FLOAT_TYPE old_fit = crt_fit;
+            bool done = false;
 
             Parameter_Trainer_Type::train_one_round(
                 train_event_seq_ptrs,
@@ -126,65 +127,42 @@ int main(int argc, char* argv[])
                 crt_pm_params, crt_st_params, crt_fit, done,
                 not opts::no_train_scaling, not opts::no_train_transitions);
 
-            LOG(debug)
-                << "scaling_round read [" << read_summary.read_id << "] strand [" << 2 << "] model [" << m_name
-                << "] old_pm_params [" << old_pm_params << "] old_st_params [" << old_st_params[0] << "," << old_st_params[1]
-                << "] old_fit [" << old_fit << "] crt_pm_params [" << crt_pm_params
-                << "] crt_st_params [" << crt_st_params[0] << "," << crt_st_params[1]
-                << "] crt_fit [" << crt_fit << "] round [" << round << "]" << endl;
             print_hex("round", crt_pm_params, crt_st_params);
             cout << " " << hexfloat << crt_fit << defaultfloat << " " << done << endl;
-
             if (done) {
-                // singularity detected; stop
-                break;
+                more = false;
+            } else if (crt_fit < old_fit) {
+                crt_pm_params = old_pm_params; crt_st_params = old_st_params; crt_fit = old_fit;
+                more = false;
+            } else {
+                ++rounds_done;
+                more = rounds_done < 2u * opts::scaling_max_rounds and not (rounds_done > 1 and crt_fit < old_fit + opts::scaling_min_progress);
             }
-
-            if (crt_fit < old_fit) {
-                crt_pm_params = old_pm_params;
-                crt_st_params = old_st_params;
-                crt_fit = old_fit;
-                break;
-            }
-
-            ++round;
-            // stop condition
-            if (round >= 2u * opts::scaling_max_rounds or (round > 1 and crt_fit < old_fit + opts::scaling_min_progress)) {
-                break;
-            }
-        };   // while true
+        }
         print_hex("result", crt_pm_params, crt_st_params);
-        cout << " " << hexfloat << crt_fit << defaultfloat << " " << round << endl;
+        cout << " " << hexfloat << crt_fit << defaultfloat << " " << rounds_done << endl;
     }
 
-    // ---------------- basecall_strand, nanocall.cpp:645-690 ----------------
-    auto basecall_strand = [&](unsigned st, string m_name, const Pore_Model_Parameters_Type& pm_params,
-                               const State_Transition_Parameters_Type& st_params) {
-        // scale model
-        Pore_Model_Type pm(models.at(m_name));
+    // ---- call site 2: the body of basecall_strand (nanocall.cpp:645-690) ----
+    // Scale a copy of the model, custom transitions only when the trained ones differ from the default, drift-correct a copy of
+    // the events, decode: the five member calls are the reference's, in its order.
+    for (unsigned st = 0; st < 2; ++st) {
+        const string& m_name = m_name_key[st];
+        const Pore_Model_Parameters_Type& pm_params = read_summary.pm_params_m.at(m_name_key);
+        const State_Transition_Parameters_Type& st_params = read_summary.st_params_m.at(m_name_key)[st];
+        Pore_Model_Type pm = models.at(m_name);
         pm.scale(pm_params);
-        State_Transitions_Type custom_transitions;
-        const State_Transitions_Type* transitions_ptr;
+        State_Transitions_Type custom_transitions = State_Transitions_Type();
+        const State_Transitions_Type* transitions_ptr = &default_transitions;
         if (not st_params.is_default()) {
             custom_transitions.compute_transitions_fast(st_params);
-            transitions_ptr = &custom_transitions;
-        } else {
-            transitions_ptr = &default_transitions;
+            transitions_ptr = &custom_transitions;    // (else the default ones, computed once above)
         }
-        LOG(info) << "basecalling read [" << read_summary.read_id << "] strand [" << st << "] model [" << m_name << "] pm_params ["
-                  << pm_params << "] st_params [" << st_params << "]" << endl;
-        LOG(debug) << "mean_stdv read [" << read_summary.read_id << "] strand [" << st << "] model_mean [" << pm.mean()
-                   << "] model_stdv [" << pm.stdv() << "]" << endl;
-        // correct drift
-        Event_Sequence_Type corrected_events = read_summary.events(st);
+        Event_Sequence_Type corrected_events(read_summary.events(st));
         corrected_events.apply_drift_correction(pm_params.drift);
         Viterbi_Type vit;
         vit.fill(pm, *transitions_ptr, corrected_events);
-        return std::make_tuple(vit.path_probability(), std::move(corrected_events));
-    };
-    for (unsigned st = 0; st < 2; ++st) {   // :718-724
-        auto r = basecall_strand(st, m_name_key[st], read_summary.pm_params_m.at(m_name_key), read_summary.st_params_m.at(m_name_key)[st]);
-        cout << "strand " << st << " " << hexfloat << get<0>(r) << defaultfloat << " " << get<1>(r).get_base_seq() << endl;
+        cout << "strand " << st << " " << hexfloat << vit.path_probability() << defaultfloat << " " << corrected_events.get_base_seq() << endl;
     }
     return 0;
 }
