@@ -354,6 +354,9 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_slot_owner) (void)hipFree(c->d_slot_owner);
     if (c->d_ws_big) (void)hipFree(c->d_ws_big);
+    for (int l = 0; l <= kVitLanes; ++l) if (c->d_plan[l]) (void)hipFree(c->d_plan[l]);
+    if (c->d_plan_counts) (void)hipFree(c->d_plan_counts);
+    if (c->h_plan_counts) (void)hipHostFree(c->h_plan_counts);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->d_fb_ws) (void)hipFree(c->d_fb_ws);
     if (c->d_fb_aux) (void)hipFree(c->d_fb_aux);
@@ -774,10 +777,6 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
     if (total_events && (!d_cmean || !d_stdv || !d_lstdv || !d_out_state)) return NCHMM_E_INVALID;
     if (pipe_in_flight(c)) return NCHMM_E_INVALID;   // the host-pointer pipeline owns the lanes (nchmm_viterbi_begin)
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = viterbi_ws_prepare(c, max_events, n_reads);
-    if (rc != NCHMM_OK) return rc;
-    c->counters[0] += n_reads;
-    c->counters[1] += total_events;
     // behind what the CALLER has on its stream.  The context's own stream is lane 0: what is on it are this context's earlier
     // launches (every other entry point that uses it returns synchronised), and waiting for those is what the lanes are there
     // to avoid.
@@ -786,10 +785,104 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
         HIP_TRY(c, hipEventRecord(c->ev_entry, c->stream));
         after = c->ev_entry;
     }
+    int rc;
+    // ---- the plan, made on the device when the lengths are only there (plan_kernel.hip) ----
+    // ragged: the caller states a longest read well above the mean -- a launch lasts as long as its longest read, so the reads
+    // are handed out longest first.  tight: reads so long that a full pool of regions of that length does not fit the budget --
+    // if only a few reads are that long they get regions of their own and the pool is sized for the rest (what the host-pointer
+    // forms do from the host's copy of the offsets, nchmm_plan.hpp: plan_outliers); the counts come back with one small copy.
+    size_t budget = 0;
+    if ((rc = viterbi_ws_budget(c, &budget))) return rc;
+    const size_t pool = (size_t)kXcds * std::min<size_t>(c->slots_per_xcd, n_reads * kVitLanes);
+    const bool tight = !d_order && n_reads >= 8 && (size_t)max_events * kBpRowBytes > budget / pool;
+    const bool ragged = !d_order && n_reads > 1 && total_events && (double)max_events * (double)n_reads > 1.25 * (double)total_events;
+    auto plan_buffer = [&](int slot) -> int {           // [order n | outliers n] for lane `slot` (kVitLanes: the tight path's own)
+        if (c->plan_cap[slot] >= 2 * n_reads) return NCHMM_OK;
+        for (int l = 0; l < kVitLanes; ++l) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));    // (a sweep may be reading the old one)
+        if (c->d_plan[slot]) { HIP_TRY(c, hipFree(c->d_plan[slot])); c->counters[6] -= 4 * c->plan_cap[slot]; c->d_plan[slot] = nullptr; c->plan_cap[slot] = 0; }
+        const size_t cap = 2 * n_reads + n_reads / 4;
+        void* p = nullptr;
+        const int r = dev_alloc(c, &p, 4 * cap);
+        if (r != NCHMM_OK) return r;
+        c->d_plan[slot] = (uint32_t*)p; c->plan_cap[slot] = cap;
+        return NCHMM_OK;
+    };
+    if (!c->d_plan_counts && (tight || ragged)) {
+        void* p = nullptr;
+        if ((rc = dev_alloc(c, &p, sizeof(unsigned long long) * 4 * (kVitLanes + 1)))) return rc;
+        c->d_plan_counts = (unsigned long long*)p;
+        HIP_TRY(c, hipHostMalloc(&p, sizeof(unsigned long long) * 4, hipHostMallocDefault));
+        c->h_plan_counts = (unsigned long long*)p;
+    }
+    if (tight) {
+        // every lane idle first: the tight path's buffer is read by whichever lanes the launches below land on
+        for (int l = 0; l < kVitLanes; ++l) { HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream)); c->lane[l].pending = false; c->lane[l].joined = true; }
+        if ((rc = plan_buffer(kVitLanes))) return rc;
+        const uint64_t small_cap = (uint64_t)(budget / 10 * 7 / pool / kBpRowBytes);     // events a pooled region may hold (plan_outliers)
+        hipStream_t s0 = c->lane[0].stream;
+        if (after) HIP_TRY(c, hipStreamWaitEvent(s0, after, 0));
+        uint32_t* const d_in = c->d_plan[kVitLanes];
+        uint32_t* const d_out = d_in + n_reads;
+        unsigned long long* const d_cnt = c->d_plan_counts + 4 * kVitLanes;
+        launch_plan_order(d_off, (unsigned)n_reads, max_events, small_cap, d_in, d_out, d_cnt, s0);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(c->h_plan_counts, d_cnt, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, s0));
+        HIP_TRY(c, hipStreamSynchronize(s0));
+        const size_t n_in = (size_t)c->h_plan_counts[0], n_out = (size_t)c->h_plan_counts[1];
+        const uint64_t longest_in = c->h_plan_counts[2], longest = c->h_plan_counts[3];
+        if (n_in + n_out != n_reads || longest > max_events) return NCHMM_E_INVALID;      // (the offsets do not match what the caller stated)
+        c->counters[0] += n_reads;
+        c->counters[1] += total_events;
+        if (small_cap >= 256 && n_out * 8 <= n_reads && n_out > 0) {
+            // a few long reads: the pool for the rest, regions of their own for them, one more launch beside the pooled one
+            if ((rc = viterbi_ws_prepare(c, std::max<uint64_t>(longest_in, 1), std::max<size_t>(n_in, 1), budget - budget / 10 * 3))) return rc;
+            if ((rc = viterbi_big_prepare(c, longest, n_out, budget / 10 * 3))) return rc;
+            if (c->ws_pooled) {
+                // (the outliers first: they are the longest reads of the batch and set its duration -- one per CU in the low-latency
+                // form while there are no more of them than CUs; every lane is idle here, so their blocks are placed before the
+                // pooled launch's)
+                if ((rc = launch_viterbi_outliers(c, nullptr, n_out, 0, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_out, d_out_state,
+                                                  d_out_logp, d_out_status, nullptr, n_out <= (size_t)c->n_cu ? kSweepLl : kSweepWide))) return rc;
+                if (n_in)
+                    rc = launch_viterbi_range(c, nullptr, 0, n_in, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_in,
+                                              d_out_state, d_out_logp, d_out_status, nullptr,
+                                              choose_sweep_bounds(n_in, longest_in, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, true));
+                return rc;
+            }
+        }
+        // most reads are long (or the budget is tiny): everything the usual way on as many blocks as the budget has regions for --
+        // longest first all the same (the two lists one after the other: outliers, then the rest)
+        if ((rc = viterbi_ws_prepare(c, max_events, n_reads))) return rc;
+        if (n_out && n_in) {
+            // [outliers | rest] contiguous: the outliers' list sits behind the order; rotate through the spare quarter is not worth a
+            // kernel -- two launches in the order outliers, rest
+            if ((rc = launch_viterbi_range(c, nullptr, 0, n_out, 0, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_out, d_out_state,
+                                           d_out_logp, d_out_status, nullptr, kSweepWide))) return rc;
+            return launch_viterbi_range(c, nullptr, 0, n_in, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_in, d_out_state,
+                                        d_out_logp, d_out_status, nullptr, kSweepWide);
+        }
+        return launch_viterbi_range(c, nullptr, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, n_out ? d_out : d_in,
+                                    d_out_state, d_out_logp, d_out_status, nullptr,
+                                    choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming));
+    }
+    if ((rc = viterbi_ws_prepare(c, max_events, n_reads))) return rc;
+    c->counters[0] += n_reads;
+    c->counters[1] += total_events;
+    const uint32_t* order = d_order;
+    if (ragged) {
+        // longest first, by a kernel on the lane the sweep will run on, in front of it: nothing is waited for
+        const int li = c->ws_pooled ? c->next_lane : 0;
+        if ((rc = plan_buffer(li))) return rc;
+        hipStream_t sl = c->lane[li].stream;
+        if (after) HIP_TRY(c, hipStreamWaitEvent(sl, after, 0));
+        launch_plan_order(d_off, (unsigned)n_reads, max_events, ~0ull, c->d_plan[li], c->d_plan[li] + n_reads, c->d_plan_counts + 4 * li, sl);
+        HIP_TRY(c, hipGetLastError());
+        order = c->d_plan[li];
+    }
     // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total)
     const int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming);
     return launch_viterbi_range(c, after, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
-                                d_order, d_out_state, d_out_logp, d_out_status, nullptr, sweep);
+                                order, d_out_state, d_out_logp, d_out_status, nullptr, sweep);
 }
 
 }  // namespace

@@ -78,6 +78,11 @@ struct nchmm_ctx {
     unsigned* d_slot_owner = nullptr;   // [kXcds][slots_per_xcd]
     unsigned slots_per_xcd = 0;     // capacity of the owner table per XCD
     unsigned ws_per_xcd = 0;        // regions per XCD the workspace holds now (<= slots_per_xcd)
+    // device-side plan of the device-pointer forms (plan_kernel.hip): per lane [order n | outliers n] and four counts
+    uint32_t* d_plan[nchmm::kVitLanes + 1] = {nullptr, nullptr, nullptr, nullptr};     // (the last: the tight path's, used with every lane idle)
+    size_t plan_cap[nchmm::kVitLanes + 1] = {0, 0, 0, 0};
+    unsigned long long* d_plan_counts = nullptr;   // [kVitLanes][4]
+    unsigned long long* h_plan_counts = nullptr;   // pinned [4]: read back only when the pool does not fit the longest read
     hipStream_t s_in = nullptr;     // copy-in stream of the host-pointer pipeline (nchmm_pipeline.cpp); it computes on own_stream
     nchmm::PipeState* pipe = nullptr;   // batches in flight (nchmm_pipeline.cpp)
     void* combiner = nullptr;           // nchmm_viterbi_strand's batcher (nchmm_combine.cpp), created on first use

@@ -68,6 +68,10 @@ int viterbi_blocks_per_cu();
 // the low-latency form: one read per CU on 16 waves (viterbi_ll_kernel.hip); same arguments, same results, cu_progress unused
 void launch_viterbi_ll(const ViterbiArgs& a, int grid, hipStream_t stream);
 
+// plan_kernel.hip: longest-first order (and the reads longer than `outlier_above`) of a batch whose offsets are on the device
+void launch_plan_order(const uint64_t* d_off, unsigned n, uint64_t span, uint64_t outlier_above, uint32_t* d_order, uint32_t* d_outlier,
+                       unsigned long long* d_counts, hipStream_t stream);
+
 constexpr int kFbTransFloats = 6 * kStates;   // forward c0|c1|c2 then backward c0b|c1b|c2b, per state, log space
 
 struct FwbwArgs {

@@ -219,3 +219,51 @@ def test_device_pointer_form_picks_the_form_from_the_stated_shape(r73t):
     finally:
         ctx.use_own_stream()
         ctx.close()
+
+
+def test_device_pointer_form_plans_on_the_device(r73t):
+    """nchmm_viterbi_dev with the offsets only on the device (plan_kernel.hip): (a) a ragged batch is handed out longest first
+    without anything being waited for; (b) one 200 000-event read among 2 000 short ones -- too long for a full pool of
+    back-pointer regions within the budget -- gets a region of its own beside the pooled launch instead of putting the whole
+    batch on as many blocks as the budget has regions of that length for (DESIGN.md section 10 of round 4: 216 of 512).
+    Same bits as the host-pointer form, which plans on the host; (b) within 10 % of its time."""
+    import time
+    torch = pytest.importorskip("torch")
+    ctx = na.Context(0)
+    try:
+        ctx.put_model(0, na.scaled_model_table(r73t, IDENT))
+        ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        rng = np.random.default_rng(5)
+        cases = {"ragged": np.clip(np.round(np.exp(rng.normal(np.log(900), 0.8, 700))), 50, 9000).astype(np.int64),
+                 "one long read": np.concatenate([rng.integers(200, 400, 1000), [200000], rng.integers(200, 400, 1000)]).astype(np.int64)}
+        for name, lens in cases.items():
+            n_reads, longest = len(lens), int(lens.max())
+            ev = synth.generate(r73t, 1, longest)            # one long stream, cut into the reads (any events do: both forms see the same)
+            pick = np.concatenate([np.arange(n) + (int(i) * 7919) % max(1, longest - n) for i, n in enumerate(lens)])
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            cm, sd, ls = na.events_prepare(ev["mean"][0][pick], ev["stdv"][0][pick], ev["start"][0][pick], 0.0)
+            ctx.use_own_stream()
+            ctx.viterbi(off, cm, sd, ls)                         # (sizes the host form's staging)
+            t0 = time.perf_counter()
+            h_state, h_logp, h_status = ctx.viterbi(off, cm, sd, ls)
+            t_host = time.perf_counter() - t0
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            d_off, d_cm, d_sd, d_ls = t(off.astype(np.int64)), t(cm), t(sd), t(ls)
+            d_state = torch.zeros(int(off[-1]), dtype=torch.int16, device=dev)
+            d_logp = torch.zeros(n_reads, dtype=torch.float32, device=dev)
+            d_status = torch.ones(n_reads, dtype=torch.int32, device=dev)
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.viterbi_dev(n_reads, longest, int(off[-1]), d_off, d_cm, d_sd, d_ls, d_state, d_logp, d_status)
+                torch.cuda.synchronize()
+                t_dev = time.perf_counter() - t0
+            assert np.array_equal(d_state.cpu().numpy().view(np.uint16), h_state), name
+            assert d_logp.cpu().numpy().tobytes() == h_logp.tobytes() and (d_status.cpu().numpy() == 0).all(), name
+            if name == "one long read":
+                assert t_dev <= 1.10 * t_host + 0.005, (t_dev, t_host)
+    finally:
+        ctx.use_own_stream()
+        ctx.close()
