@@ -33,23 +33,6 @@ print(t, "FB (M event-rounds/s, kernel ms)", last(f"gpurun_out/exp_fb_{t}.json",
 PY
 }
 case "${1:-}" in
-stalls)
-  # the experiment switches live in patches, not in the kernel sources (they build wrong-result kernels)
-  # The patches were cut against the round-2 kernels (commit e6fdcec).  Nothing is touched unless BOTH still apply cleanly,
-  # the originals are kept aside, and they come back on any exit (an interrupted run must not leave a half-patched kernel
-  # behind: bench.py keys its PMC files on the kernel source hash).
-  (cd nanocall_amd/csrc && patch --dry-run -s -p0 < ../../tools/ubench/exp_switches_viterbi.patch > /dev/null &&
-     patch --dry-run -s -p0 < ../../tools/ubench/exp_switches_fwbw_scaled.patch > /dev/null) || {
-    echo "the experiment-switch patches no longer apply to the shipped kernels: rebuild them from commit e6fdcec (tools/ubench/variants/README.md)" >&2; exit 1; }
-  cp nanocall_amd/csrc/viterbi_kernel.hip /tmp/viterbi_kernel.hip.orig; cp nanocall_amd/csrc/fwbw_scaled_kernel.hip /tmp/fwbw_scaled_kernel.hip.orig
-  restore() { cp /tmp/viterbi_kernel.hip.orig nanocall_amd/csrc/viterbi_kernel.hip; cp /tmp/fwbw_scaled_kernel.hip.orig nanocall_amd/csrc/fwbw_scaled_kernel.hip
-              rm -f nanocall_amd/csrc/*.rej nanocall_amd/csrc/*.orig; make -C nanocall_amd/csrc -j16 > /dev/null 2>&1; }
-  trap restore EXIT
-  (cd nanocall_amd/csrc && patch -s -p0 < ../../tools/ubench/exp_switches_viterbi.patch && patch -s -p0 < ../../tools/ubench/exp_switches_fwbw_scaled.patch)
-  variant base ""
-  variant noload "-DNCHMM_EXP_NOLOAD"
-  variant nobarrier "-DNCHMM_EXP_NOBARRIER"
-  variant nostore "-DNCHMM_EXP_NOSTORE" ;;
 budgets)
   for mb in 0 65536 32768 16384 8192; do
     if [ $mb = 0 ]; then unset NCHMM_WS_BUDGET_MB; else export NCHMM_WS_BUDGET_MB=$mb; fi
@@ -67,5 +50,5 @@ hostpath)
 cli)
   READS=${READS:-8000} EVENTS=${EVENTS:-5000} THREADS=${THREADS:-32} python tools/bench_cli.py | tee gpurun_out/bench_cli.json ;;
 *)
-  echo "usage: bash tools/gpu_experiments.sh stalls|budgets|rates|hbm|hostpath|cli" ; exit 2 ;;
+  echo "usage: bash tools/gpu_experiments.sh budgets|rates|hbm|hostpath|cli" ; exit 2 ;;
 esac
