@@ -1,11 +1,7 @@
 #!/bin/bash
 # tools/gpu_experiments.sh <which> -- the round-2 measurement recipes, run on the GPU box from the repo root
-# (gpurun -- 'bash tools/gpu_experiments.sh stalls').  Results go to gpurun_out/; what was kept is under profiles/.
+# (gpurun -- 'bash tools/gpu_experiments.sh budgets').  Results go to gpurun_out/; what was kept is under profiles/.
 #
-#   stalls    where do the two hot kernels wait?  Rebuilds the library with the experiment switches of the kernels
-#             (-DNCHMM_EXP_NOLOAD: alpha-row loads of the backward sweep replaced by constants; -DNCHMM_EXP_NOBARRIER: the
-#             per-event barrier removed; -DNCHMM_EXP_NOSTORE: back-pointer stores compiled out; results are garbage by
-#             construction) and times bench.py / tools/bench_fwbw.py for each.            -> DESIGN.md sections 4.1 / 4.3
 #   budgets   config-4 shard throughput against the back-pointer workspace budget (tail of a launch vs launch count)
 #   rates     tools/ubench/valu_rate.hip: ns per wave-instruction per SIMD by instruction class and occupancy
 #   hbm       torch fill / sum / copy rates of the device (calibration of "achievable" for the roofline fractions)
@@ -15,23 +11,6 @@ set -u
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-variant() {  # tag, extra hipcc flags
-  make -C nanocall_amd/csrc clean > /dev/null
-  make -C nanocall_amd/csrc -j16 HIPFLAGS="--offload-arch=gfx950 \$(CXXFLAGS) -fno-slp-vectorize $2" > gpurun_out/exp_build_$1.log 2>&1
-  python tools/bench_fwbw.py > gpurun_out/exp_fb_$1.json 2>/dev/null
-  timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fwbw > gpurun_out/exp_vit_$1.json 2>/dev/null
-  python - "$1" <<'PY'
-import json, sys
-t = sys.argv[1]
-def last(f, pick):
-    try:
-        return pick(json.loads(open(f).read().strip().splitlines()[-1]))
-    except Exception as e:
-        return ("ERR", str(e)[:60])
-print(t, "FB (M event-rounds/s, kernel ms)", last(f"gpurun_out/exp_fb_{t}.json", lambda d: (d["value"], d["kernel_ms"])),
-      " Viterbi (Mevents/s, kernel ms)", last(f"gpurun_out/exp_vit_{t}.json", lambda d: (d["value"], d["roofline"]["kernel_ms"])))
-PY
-}
 case "${1:-}" in
 budgets)
   for mb in 0 65536 32768 16384 8192; do
