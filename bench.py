@@ -51,7 +51,7 @@ def kernel_source_hash():
     """sha256 (first 16 hex) of the Viterbi kernel source: profiles are keyed on it so that replayed PMC figures
     cannot outlive the kernel they were measured on."""
     h = hashlib.sha256()
-    for f in ("viterbi_kernel.hip", "nchmm_device.h"):
+    for f in ("viterbi_kernel.hip", "viterbi_common.hpp", "nchmm_device.h"):
         h.update(open(os.path.join(ROOT, "nanocall_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -501,14 +501,23 @@ int nchmm_grid_slots(const nchmm_ctx* ctx, int* viterbi_slots);
  * recurrence), so there are two ways to put reads on a CU: two reads side by side on 8 waves each (NCHMM_SWEEP_WIDE: the most
  * events per second) or one read on 16 waves (NCHMM_SWEEP_LL: about half the time per event for that read) -- what a batch
  * with few or very unequal reads, and the reference's one-strand-per-call shape (nanocall.cpp:687-689), need.  Results are
- * bit-identical.  NCHMM_SWEEP_AUTO (default; environment NCHMM_VIT_SWEEP=auto|wide|ll at nchmm_create) decides per launch from
+ * bit-identical.  NCHMM_SWEEP_AUTO (default; environment NCHMM_VIT_SWEEP=auto|wide|ll|ahead at nchmm_create) decides per launch from
  * the read lengths.  No reference counterpart (the reference's parallelism is pfor over reads, nanocall.cpp:611). */
 #define NCHMM_SWEEP_AUTO 0
 #define NCHMM_SWEEP_WIDE 1
 #define NCHMM_SWEEP_LL 2
+/* NCHMM_SWEEP_AHEAD: the low-latency form with the emission log-densities (Pore_Model.hpp:145-149: 60 % of a column's arithmetic,
+ * independent of the recurrence) of the launch's longest reads computed AHEAD by every CU of the device, 16 KiB per event in a
+ * buffer of NCHMM_EM_BUDGET_MB (default 256: what stays in the memory-side cache): those reads' columns carry the max-plus
+ * recurrence only -- 0.59 us per event against 0.80 for a strand decoded on its own.  Forced, it applies to one-call batches (as many of their longest reads as the buffer holds) and to
+ * nchmm_viterbi_dev batches that fit the buffer whole; AUTO takes it where the plan prices it cheaper (nchmm_plan.hpp). */
+#define NCHMM_SWEEP_AHEAD 3
 int nchmm_set_sweep(nchmm_ctx* ctx, int mode);
-/* out[0] = launches of the wide form so far, [1] = of the low-latency form, [2] / [3] = reads they decoded */
+/* out[0] = launches of the wide form so far, [1] = of the low-latency form (with or without emissions ahead), [2] / [3] = reads
+ * they decoded */
 int nchmm_sweep_stats(const nchmm_ctx* ctx, uint64_t out[4]);
+/* out[0] = low-latency launches that had emissions computed ahead, [1] = reads, [2] = events (rows of the buffer) ahead */
+int nchmm_ahead_stats(const nchmm_ctx* ctx, uint64_t out[3]);
 
 /* Device memory the context holds now (out[0]) and at its high-water mark (out[1]), in bytes: tables, staging and the
  * back-pointer workspace -- one region of 4 KiB per event of the LONGEST read for every thread block that can be resident

@@ -89,6 +89,7 @@ SIGNATURES = {
     "nchmm_grid_slots": (C.c_int, [vp, vp]),
     "nchmm_set_sweep": (C.c_int, [vp, C.c_int]),
     "nchmm_sweep_stats": (C.c_int, [vp, vp]),
+    "nchmm_ahead_stats": (C.c_int, [vp, vp]),
     "nchmm_mem_stats": (C.c_int, [vp, vp]),
     "nchmm_device_count": (C.c_int, [vp]),
     "nchmm_device_mem_info": (C.c_int, [C.c_int, vp, vp]),

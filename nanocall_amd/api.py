@@ -595,8 +595,15 @@ class Context:
 
     def set_sweep(self, mode):
         """which form of the Viterbi sweep launches take: "auto" (per launch, from the read lengths), "wide" (two reads per
-        CU on 8 waves each), "ll" (one read per CU on 16 waves) -- bit-identical results"""
-        check(lib().nchmm_set_sweep(self._h, {"auto": 0, "wide": 1, "ll": 2}[mode]), "nchmm_set_sweep")
+        CU on 8 waves each), "ll" (one read per CU on 16 waves), "ahead" (ll with the emissions of the longest reads computed
+        ahead by the whole device) -- bit-identical results"""
+        check(lib().nchmm_set_sweep(self._h, {"auto": 0, "wide": 1, "ll": 2, "ahead": 3}[mode]), "nchmm_set_sweep")
+
+    def ahead_stats(self):
+        """(low-latency launches with emissions ahead, reads ahead, events ahead) so far"""
+        out = (C.c_uint64 * 3)()
+        check(lib().nchmm_ahead_stats(self._h, out), "nchmm_ahead_stats")
+        return tuple(int(v) for v in out)
 
     def sweep_stats(self):
         """(launches wide, launches ll, reads wide, reads ll) so far"""

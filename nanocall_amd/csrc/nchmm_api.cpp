@@ -275,6 +275,7 @@ int nchmm_create(nchmm_ctx** out, int device_id)
             return fail(NCHMM_E_HIP);
     if (hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming) != hipSuccess) return fail(NCHMM_E_HIP);
     if (hipEventCreateWithFlags(&c->ev_big, hipEventDisableTiming) != hipSuccess) return fail(NCHMM_E_HIP);
+    if (hipEventCreateWithFlags(&c->ev_em, hipEventDisableTiming) != hipSuccess) return fail(NCHMM_E_HIP);
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocDefault) != hipSuccess) return fail(NCHMM_E_HIP);
@@ -314,7 +315,7 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         const char* f = std::getenv("NCHMM_FB_FORCE_LOG");
         c->fb_force_log = f && f[0] == '1';
         if (const char* w = std::getenv("NCHMM_VIT_SWEEP"))     // wide | ll | auto: which form of the sweep launches take
-            c->sweep_mode = !std::strcmp(w, "wide") ? kSweepWide : !std::strcmp(w, "ll") ? kSweepLl : kSweepAuto;
+            c->sweep_mode = !std::strcmp(w, "wide") ? kSweepWide : !std::strcmp(w, "ll") ? kSweepLl : !std::strcmp(w, "ahead") ? kSweepAhead : kSweepAuto;
         const char* b = std::getenv("NCHMM_FB_BUDGET_MB");
         if (b) c->fb_budget = std::max<size_t>((size_t)std::strtoull(b, nullptr, 10) << 20, (size_t)16 << 20);
     }
@@ -354,6 +355,7 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_slot_owner) (void)hipFree(c->d_slot_owner);
     if (c->d_ws_big) (void)hipFree(c->d_ws_big);
+    if (c->d_em) (void)hipFree(c->d_em);
     for (int l = 0; l <= kVitLanes; ++l) if (c->d_plan[l]) (void)hipFree(c->d_plan[l]);
     if (c->d_plan_counts) (void)hipFree(c->d_plan_counts);
     if (c->h_plan_counts) (void)hipHostFree(c->h_plan_counts);
@@ -374,6 +376,7 @@ int nchmm_destroy(nchmm_ctx* c)
     }
     if (c->ev_entry) (void)hipEventDestroy(c->ev_entry);
     if (c->ev_big) (void)hipEventDestroy(c->ev_big);
+    if (c->ev_em) (void)hipEventDestroy(c->ev_em);
     if (c->ev_fb0) (void)hipEventDestroy(c->ev_fb0);
     if (c->ev_fb1) (void)hipEventDestroy(c->ev_fb1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -628,6 +631,39 @@ int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count, size_t budg
     return NCHMM_OK;
 }
 
+// rows (events) the buffer of emissions computed ahead may hold: NCHMM_EM_BUDGET_MB, default 256 MiB = 16 384 events -- what the
+// memory-side cache holds.  A read streams its rows back at ~28 GB/s, which is what ONE CU can take in (~12 B per clock): from
+// the cache that is 0.59 us per event (a 5000-event strand: 2.9 ms against 4.0 in the plain low-latency form); once the rows
+// come from HBM it is 0.77-0.83 (8 x 30 000 events: 23.0 against 24.7 ms; 96 x 10 000: slower) -- not worth 16 KiB per event.
+uint64_t viterbi_em_budget_rows(nchmm_ctx* c)
+{
+    if (c->em_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)32 << 30;
+        const char* e = std::getenv("NCHMM_EM_BUDGET_MB");
+        c->em_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : std::min<size_t>((size_t)256 << 20, free_b / 4);
+        if (c->em_budget < ((size_t)1 << 20)) c->em_budget = (size_t)1 << 20;
+    }
+    return (uint64_t)(c->em_budget / ((size_t)kStates * sizeof(float)));
+}
+
+namespace {
+int viterbi_em_prepare(nchmm_ctx* c, uint64_t rows)
+{
+    const size_t need = (size_t)std::max<uint64_t>(rows, 1) * kStates * sizeof(float);
+    if (c->d_em && c->em_bytes >= need) return NCHMM_OK;
+    for (int l = 0; l < kVitLanes; ++l) HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));     // (a sweep may be reading the old one)
+    c->em_pending = false;
+    if (c->d_em) { HIP_TRY(c, hipFree(c->d_em)); c->counters[6] -= c->em_bytes; c->d_em = nullptr; c->em_bytes = 0; }
+    const size_t want = std::min<size_t>(need + need / 4, std::max(need, c->em_budget));
+    void* p = nullptr;
+    const int rc = dev_alloc(c, &p, want);
+    if (rc != NCHMM_OK) return rc;
+    c->d_em = (float*)p; c->em_bytes = want;
+    return NCHMM_OK;
+}
+}  // namespace
+
 hipStream_t viterbi_next_lane_stream(nchmm_ctx* c) { return c->lane[c->ws_pooled ? c->next_lane : 0].stream; }
 
 // The outliers of a batch.  Reads too long for regions of which the whole pool fits the budget get a few regions of their own
@@ -661,10 +697,18 @@ namespace {
 int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_bytes, size_t regions, hipEvent_t after, hipEvent_t serial_after,
                         size_t first, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean, const float* d_stdv,
                         const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order,
-                        uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int li, int* lane_out, int sweep)
+                        uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int li, int* lane_out, int sweep, const AheadArgs* ahead)
 {
     VitLaneState& L = c->lane[li];
-    const bool ll = (c->sweep_mode == kSweepAuto ? sweep : c->sweep_mode) == kSweepLl;
+    const int form = c->sweep_mode == kSweepAuto ? sweep : c->sweep_mode;
+    const bool ll = form == kSweepLl || form == kSweepAhead;
+    // emissions ahead: only where the caller planned them (a forced "ahead" without a plan is the plain low-latency form), and
+    // not when the context is forced to another form
+    const bool em = ahead && ahead->n && form == kSweepAhead;
+    if (em) {
+        const int rc = viterbi_em_prepare(c, ahead->rows);
+        if (rc != NCHMM_OK) return rc;
+    }
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
     a.model_slot = d_model_slot; a.trans_slot = d_trans_slot; a.order = d_order;
@@ -679,6 +723,7 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     c->launch_seq = c->launch_seq % 4095u + 1u;
     a.launch_tag = c->launch_seq;
     a.tb_margin = c->tb_margin;
+    a.em = em ? c->d_em : nullptr; a.em_row0 = em ? ahead->d_row0 : nullptr;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     // the wide sweep: two blocks per CU; the low-latency sweep: one
@@ -687,9 +732,17 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     a.queue_base = L.vq_base;
     if (after) HIP_TRY(c, hipStreamWaitEvent(L.stream, after, 0));
     if (serial_after) HIP_TRY(c, hipStreamWaitEvent(L.stream, serial_after, 0));
+    if (em) {
+        // the buffer is one: behind the sweep that read it last; then the emissions of the first ahead->n reads of the order, by
+        // every CU that is free (the device is this launch's: nothing else is in flight when a plan asks for them)
+        if (c->em_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->ev_em, 0));
+        launch_emissions(a, (unsigned)ahead->n, ahead->longest, c->d_em, L.stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipEventRecord(L.ev0, L.stream));
     if (ll) launch_viterbi_ll(a, grid, L.stream); else launch_viterbi(a, grid, L.stream);
     HIP_TRY(c, hipGetLastError());
+    if (em) { HIP_TRY(c, hipEventRecord(c->ev_em, L.stream)); c->em_pending = true; c->ahead_stats[0] += 1; c->ahead_stats[1] += ahead->n; c->ahead_stats[2] += ahead->rows; }
     // every read takes a ticket, every block one more to find the queue empty -- counted only once the launch is in the queue
     // (a failure above must leave the lane's ticket base where the device's queue head will be)
     L.vq_base += (unsigned)count + (unsigned)grid;
@@ -712,26 +765,27 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
 int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
                          const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep)
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep, const AheadArgs* ahead)
 {
     if (!c->d_ws) return NCHMM_E_INVALID;
     // without a pool every launch owns regions 0 .. grid-1: one lane, strictly one launch after the other
     const int li = c->ws_pooled ? c->next_lane : 0;
     hipEvent_t serial = (!c->ws_pooled && c->last_lane >= 0 && c->last_lane != li) ? c->lane[c->last_lane].done : nullptr;
     return launch_on_next_lane(c, c->ws_pooled, c->d_ws, c->slot_bytes, c->ws_regions, after, serial, first, count, ev_count, d_off, d_cmean, d_stdv,
-                               d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status, li, lane_out, sweep);
+                               d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status, li, lane_out, sweep, ahead);
 }
 
 // The outliers of a batch (d_order lists them): one block per region of d_ws_big, behind the previous launch of outliers.
 int launch_viterbi_outliers(nchmm_ctx* c, hipEvent_t after, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean,
                             const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
-                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep)
+                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep,
+                            const AheadArgs* ahead)
 {
     if (!c->d_ws_big || !d_order || !c->ws_pooled) return NCHMM_E_INVALID;
     int li = 0;
     const int rc = launch_on_next_lane(c, false, c->d_ws_big, c->big_slot_bytes, c->big_regions, after, c->big_pending ? c->ev_big : nullptr, 0, count, ev_count,
                                        d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_order, d_out_state, d_out_logp, d_out_status,
-                                       c->next_lane, &li, sweep);
+                                       c->next_lane, &li, sweep, ahead);
     if (rc != NCHMM_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_big, c->lane[li].stream));
     c->big_pending = true;
@@ -879,10 +933,15 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
         HIP_TRY(c, hipGetLastError());
         order = c->d_plan[li];
     }
-    // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total)
-    const int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming);
+    // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total); emissions
+    // ahead = of every read of the batch (row of read r's event i: off[r] + i), when that fits the buffer
+    const uint64_t em_rows = viterbi_em_budget_rows(c);
+    int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming, SweepRates(), em_rows);
+    if (c->sweep_mode == kSweepAhead && !streaming && total_events <= em_rows && n_reads <= kMaxAheadReads) sweep = kSweepAhead;
+    AheadArgs ahead;
+    if (sweep == kSweepAhead) { ahead.n = n_reads; ahead.rows = total_events; ahead.longest = max_events; ahead.d_row0 = nullptr; }
     return launch_viterbi_range(c, after, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot,
-                                order, d_out_state, d_out_logp, d_out_status, nullptr, sweep);
+                                order, d_out_state, d_out_logp, d_out_status, nullptr, sweep, ahead.n ? &ahead : nullptr);
 }
 
 }  // namespace
@@ -1331,7 +1390,7 @@ int nchmm_mem_stats(const nchmm_ctx* c, uint64_t out[2])
 
 int nchmm_set_sweep(nchmm_ctx* c, int mode)
 {
-    if (!c || mode < kSweepAuto || mode > kSweepLl) return NCHMM_E_INVALID;
+    if (!c || mode < kSweepAuto || mode > kSweepAhead) return NCHMM_E_INVALID;
     c->sweep_mode = mode;
     return NCHMM_OK;
 }
@@ -1340,6 +1399,13 @@ int nchmm_sweep_stats(const nchmm_ctx* c, uint64_t out[4])
 {
     if (!c || !out) return NCHMM_E_INVALID;
     for (int i = 0; i < 4; ++i) out[i] = c->sweep_stats[i];
+    return NCHMM_OK;
+}
+
+int nchmm_ahead_stats(const nchmm_ctx* c, uint64_t out[3])
+{
+    if (!c || !out) return NCHMM_E_INVALID;
+    for (int i = 0; i < 3; ++i) out[i] = c->ahead_stats[i];
     return NCHMM_OK;
 }
 

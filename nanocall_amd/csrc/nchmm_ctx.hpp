@@ -47,6 +47,7 @@ struct nchmm_ctx {
     int vit_slots = 0;              // block slots of the wide sweep (viterbi_kernel.hip: two per CU)
     int sweep_mode = 0;             // nchmm::Sweep: 0 = per launch by nchmm_plan.hpp choose_sweep, 1 = wide always, 2 = ll always (NCHMM_VIT_SWEEP, nchmm_set_sweep)
     uint64_t sweep_stats[4] = {0, 0, 0, 0};   // launches wide, launches ll, reads wide, reads ll
+    uint64_t ahead_stats[3] = {0, 0, 0};      // low-latency launches with emissions ahead, reads ahead, rows (events) ahead
     int fb_slots = 0;
     float* d_models = nullptr;      // [kMaxSlots][kModelFloats]
     float* d_trans = nullptr;       // [kMaxSlots][kTransFloats]   log-space w0|w1|w2
@@ -75,6 +76,11 @@ struct nchmm_ctx {
     unsigned big_regions = 0;
     hipEvent_t ev_big = nullptr;    // behind the most recent launch of outliers (they use regions 0 .. grid-1: one at a time)
     bool big_pending = false;
+    // emissions computed ahead of a low-latency sweep (emission_kernel.hip): rows of 4096 floats, one buffer, one launch at a time
+    float* d_em = nullptr;
+    size_t em_bytes = 0, em_budget = 0;      // NCHMM_EM_BUDGET_MB (default 256)
+    hipEvent_t ev_em = nullptr;     // behind the most recent sweep that read d_em
+    bool em_pending = false;
     unsigned* d_slot_owner = nullptr;   // [kXcds][slots_per_xcd]
     unsigned slots_per_xcd = 0;     // capacity of the owner table per XCD
     unsigned ws_per_xcd = 0;        // regions per XCD the workspace holds now (<= slots_per_xcd)
@@ -126,15 +132,22 @@ int pipe_in_flight(const nchmm_ctx* c);
 int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count, size_t budget_share = 0);
 // Queue one launch (sweep + in-block traceback) for reads [first, first + count) on the next lane; *lane_out = that lane.
 // The launch starts after `after` (an event, may be null) and after the lane's previous launch.  viterbi_ws_prepare first.
-// sweep: nchmm::kSweepWide / kSweepLl (the caller has decided, nchmm_plan.hpp); the context's sweep_mode overrides it when forced.
+// Emissions ahead (sweep == kSweepAhead): the first `n` reads of the launch's order, `rows` rows of the buffer in total, the longest
+// of them `longest` events; d_row0 = per read (indexed by read) its first row or kNoEmRow, null = row of read r's event i is
+// off[r] + i (every read of the batch ahead).
+struct AheadArgs { size_t n = 0; uint64_t rows = 0, longest = 0; const uint64_t* d_row0 = nullptr; };
+uint64_t viterbi_em_budget_rows(nchmm_ctx* c);
+// sweep: nchmm::kSweepWide / kSweepLl / kSweepAhead (the caller has decided, nchmm_plan.hpp); the context's sweep_mode overrides it
+// when forced (forced "ahead" with ahead == nullptr: plain low-latency).
 int launch_viterbi_range(nchmm_ctx* c, hipEvent_t after, size_t first, size_t count, uint64_t ev_count,
                          const uint64_t* d_off, const float* d_cmean, const float* d_stdv, const float* d_lstdv,
                          const int32_t* d_model_slot, const int32_t* d_trans_slot, const uint32_t* d_order, uint16_t* d_out_state,
-                         float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep);
+                         float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep, const AheadArgs* ahead = nullptr);
 int viterbi_big_prepare(nchmm_ctx* c, uint64_t longest, size_t n_long, size_t budget_big);
 int launch_viterbi_outliers(nchmm_ctx* c, hipEvent_t after, size_t count, uint64_t ev_count, const uint64_t* d_off, const float* d_cmean,
                             const float* d_stdv, const float* d_lstdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
-                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep);
+                            const uint32_t* d_order, uint16_t* d_out_state, float* d_out_logp, int32_t* d_out_status, int* lane_out, int sweep,
+                            const AheadArgs* ahead = nullptr);
 // The stream of the lane the NEXT launch_viterbi_range will use (for kernels that must run in front of it).
 hipStream_t viterbi_next_lane_stream(nchmm_ctx* c);
 // Make `s` wait for everything queued on the lanes; then 1 if a block reported a pool failure.

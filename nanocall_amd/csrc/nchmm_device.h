@@ -31,6 +31,7 @@ enum ModelField {
 // touched through one L2, so a block that takes over a region sees exactly what it wrote itself.
 constexpr unsigned kXcds = 8;
 constexpr unsigned kNoSlot = 0xFFFFFFFFu;
+constexpr uint64_t kNoEmRow = ~(uint64_t)0;
 
 struct ViterbiArgs {
     const float* cmean;        // SoA events
@@ -58,6 +59,11 @@ struct ViterbiArgs {
     unsigned* queue;           // work-queue head of this launch's lane: never reset -- tickets start at queue_base
     unsigned queue_base;       // value of *queue when the launch starts (host-tracked: every launch adds n_reads + grid)
     unsigned n_reads;
+    // emissions computed ahead (emission_kernel.hip, read by viterbi_ll_kernel.hip): row i of read r -- 4096 floats, thread-major for
+    // the low-latency ownership map (thread tau's four states at [4 tau .. 4 tau + 3]) -- at em + (em_row0[r] + i) * 4096;
+    // em_row0[r] = kNoEmRow: the read computes its emissions itself.  em == nullptr: nobody's are ahead.
+    const float* em;
+    const uint64_t* em_row0;   // indexed by read; null with em != null: row of read r's event i = off[r] + i
     int tb_margin;             // events a speculative traceback segment runs before its first owned event
     float log_n_states;        // std::log(4096.f) from the host libm (Viterbi.hpp:51)
     float log_2pi;             // (float)std::log(2.0 * M_PI) (Pore_Model.hpp:28,37)
@@ -67,6 +73,9 @@ void launch_viterbi(const ViterbiArgs& a, int grid, hipStream_t stream);
 int viterbi_blocks_per_cu();
 // the low-latency form: one read per CU on 16 waves (viterbi_ll_kernel.hip); same arguments, same results, cu_progress unused
 void launch_viterbi_ll(const ViterbiArgs& a, int grid, hipStream_t stream);
+// The emissions of the first n_ahead reads of the launch's order (a.order / a.first_read as in the sweep) into a.em, so that the
+// sweep of those reads carries only the recurrence (emission_kernel.hip).  max_events = the longest of them.
+void launch_emissions(const ViterbiArgs& a, unsigned n_ahead, uint64_t max_events, float* em, hipStream_t stream);
 
 // plan_kernel.hip: longest-first order (and the reads longer than `outlier_above`) of a batch whose offsets are on the device
 void launch_plan_order(const uint64_t* d_off, unsigned n, uint64_t span, uint64_t outlier_above, uint32_t* d_order, uint32_t* d_outlier,

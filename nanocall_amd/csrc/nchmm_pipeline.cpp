@@ -144,6 +144,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     // are decided range by range, with the tail of a launch covered by its neighbours.
     const bool alone = (direct || tab) && P->in_flight == 0;
     int batch_sweep = kSweepWide;
+    size_t n_ahead = 0;             // leading reads of the (single) range's longest-first order whose emissions are computed ahead
     {
         size_t forced = 0;
         if (const char* e = std::getenv("NCHMM_PIPE_READS")) {      // test hook: ranges of that many reads
@@ -153,10 +154,24 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         if (alone && c->sweep_mode != kSweepWide) {
             std::vector<uint64_t> lens(n);
             for (size_t r = 0; r < n; ++r) lens[r] = off[r + 1] - off[r];
-            batch_sweep = c->sweep_mode == kSweepLl ? kSweepLl : choose_sweep(lens, (size_t)c->n_cu, (size_t)c->vit_slots, false);
+            const uint64_t em_rows = viterbi_em_budget_rows(c);
+            if (c->sweep_mode == kSweepAuto) {
+                batch_sweep = choose_sweep(lens, (size_t)c->n_cu, (size_t)c->vit_slots, false, SweepRates(), em_rows, &n_ahead);
+            } else {
+                // a forced low-latency form: "ahead" takes as many of the longest reads ahead as the buffer holds
+                batch_sweep = c->sweep_mode;
+                if (batch_sweep == kSweepAhead) {
+                    std::vector<uint64_t> desc(lens);
+                    std::sort(desc.begin(), desc.end(), std::greater<uint64_t>());
+                    uint64_t rows = 0;
+                    while (n_ahead < n && n_ahead < kMaxAheadReads && rows + desc[n_ahead] <= em_rows) rows += desc[n_ahead++];
+                }
+            }
         }
-        if (batch_sweep == kSweepLl && !forced && n <= 2 * (size_t)c->vit_slots) forced = n;
-        cut_ranges(off, n, batch_sweep == kSweepLl ? (size_t)c->n_cu : (size_t)c->vit_slots, direct, forced, &K.ranges);
+        const bool low_latency = batch_sweep == kSweepLl || batch_sweep == kSweepAhead;
+        if (low_latency && !forced && n <= 2 * (size_t)c->vit_slots) forced = n;
+        cut_ranges(off, n, low_latency ? (size_t)c->n_cu : (size_t)c->vit_slots, direct, forced, &K.ranges);
+        if (K.ranges.size() != 1) n_ahead = 0;      // (emissions ahead: one launch hands out the batch's longest reads first)
     }
     const size_t n_ranges = K.ranges.size();
 
@@ -192,7 +207,8 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     const size_t n_raw = raw ? raw->n_raw : 0;
     size_t o_off = 0, o_ms = o_off + al256(8 * (n + 1)), o_ts = o_ms + al256(4 * n), o_or = o_ts + al256(4 * n);
     size_t o_ol = o_or + al256(4 * n);        // the outliers' list
-    size_t o_src = o_ol + al256(4 * outliers.size()), o_dr = o_src + (raw ? al256(8 * n) : 0);
+    size_t o_er = o_ol + al256(4 * outliers.size());      // per read: first row of its emissions computed ahead (or kNoEmRow)
+    size_t o_src = o_er + (n_ahead ? al256(8 * n) : 0), o_dr = o_src + (raw ? al256(8 * n) : 0);
     const size_t small_bytes = std::max<size_t>(o_dr + (raw ? al256(4 * n) : 0), kMinCopy);
     size_t o_cm = small_bytes, o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total);
     size_t o_rm = o_ls + al256(4 * total), o_rs = o_rm + al256(4 * n_raw), o_rt = o_rs + al256(4 * n_raw);
@@ -253,6 +269,23 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
     if (trans_slot) std::memcpy(K.h + o_ts, trans_slot, 4 * n);
     std::memcpy(K.h + o_or, order.data(), 4 * n);
     if (!outliers.empty()) std::memcpy(K.h + o_ol, outliers.data(), 4 * outliers.size());
+    AheadArgs ahead;
+    if (n_ahead) {
+        // with outliers (reads with regions of their own: the longest of all) only those are taken ahead -- one launch reads the
+        // buffer at a time
+        if (!outliers.empty()) n_ahead = std::min(n_ahead, outliers.size());
+        uint64_t* row0 = (uint64_t*)(K.h + o_er);
+        for (size_t r = 0; r < n; ++r) row0[r] = kNoEmRow;
+        const uint32_t* lead = outliers.empty() ? order.data() : outliers.data();
+        for (size_t k = 0; k < n_ahead; ++k) {
+            const uint32_t r = lead[k];
+            row0[r] = ahead.rows;
+            ahead.rows += off[r + 1] - off[r];
+            ahead.longest = std::max<uint64_t>(ahead.longest, off[r + 1] - off[r]);
+        }
+        ahead.n = n_ahead;
+        ahead.d_row0 = (const uint64_t*)(d + o_er);
+    }
     if (raw) {
         std::memcpy(K.h + o_src, raw->src, 8 * n);
         std::memcpy(K.h + o_dr, raw->drift, 4 * n);
@@ -352,7 +385,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
                                       (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
                                       (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
                                       trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_or) + g.r0 + n_out[k], k_state, k_logp,
-                                      k_status, &lane, sweep);
+                                      k_status, &lane, sweep, (ahead.n && outliers.empty()) ? &ahead : nullptr);
             if (rc != NCHMM_OK) return rc;
         } else {
             // (a range of outliers only: what was queued in front of its launch -- tables, gather -- is on stream sl)
@@ -374,7 +407,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
         for (uint32_t r : outliers) ev_out += off[r + 1] - off[r];
         rc = launch_viterbi_outliers(c, nullptr, outliers.size(), ev_out, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
                                      (const float*)(d + o_ls), model_slot ? (const int32_t*)(d + o_ms) : nullptr,
-                                     trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_ol), k_state, k_logp, k_status, &lane_o, batch_sweep);
+                                     trans_slot ? (const int32_t*)(d + o_ts) : nullptr, (const uint32_t*)(d + o_ol), k_state, k_logp, k_status, &lane_o, batch_sweep, ahead.n ? &ahead : nullptr);
         if (rc != NCHMM_OK) return rc;
         hipEvent_t ev_o;
         if ((rc = pipe_event(c, K, &ev_o))) return rc;

@@ -113,8 +113,14 @@ inline OutlierPlan plan_outliers(const uint64_t* off, size_t n, const std::vecto
 // simulated for both forms (exactly up to kSimReads reads, by its two lower bounds beyond) and the shorter one wins.
 // Microseconds per event, measured (profiles/r05_ll_sweep.md): a wide block with a busy neighbour on its CU, a wide block
 // alone on its CU, an ll block.
-enum Sweep : int { kSweepAuto = 0, kSweepWide = 1, kSweepLl = 2 };
-struct SweepRates { double wide_shared = 1.55, wide_alone = 1.15, ll = 0.85; double per_read_us = 60.0; };
+enum Sweep : int { kSweepAuto = 0, kSweepWide = 1, kSweepLl = 2, kSweepAhead = 3 };
+// kSweepAhead: the low-latency form with the emissions of the launch's longest reads computed ahead by the whole device
+// (emission_kernel.hip): their columns carry the recurrence only.  us per event of a read: ahead; CU-us per event of the
+// emission kernel: em_cu (it runs on every CU at once, before the sweep: rows * em_cu / n_cu of wall time).
+struct SweepRates { double wide_shared = 1.55, wide_alone = 1.15, ll = 0.85, ahead = 0.60, em_cu = 0.85; double per_read_us = 60.0; };
+// A read whose emissions are ahead streams 16 KiB per event back in: 28 GB/s per block at 0.6 us per event.  Beyond ~100 such
+// blocks at once the sweep is HBM-bound and slower than computing the emissions in place (256 x 5000 events: 4.85 ms against 4.23).
+constexpr size_t kMaxAheadReads = 96;
 
 // makespan (us) of `lens` (events per read, any order) handed out longest first to `slots` blocks at `us_per_event`
 inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double us_per_event, double per_read_us)
@@ -142,22 +148,65 @@ inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double u
     return last;
 }
 
+// ---- which reads of a low-latency launch get their emissions ahead ----
+// lens: the launch's reads LONGEST FIRST.  Candidates: the first K reads, K = 0, 1, 2, 4, ... (and all), as far as `budget_rows`
+// (16 KiB per event) reaches; each is priced as the emission kernel's wall time plus the longest-processing-time schedule of
+// the sweep on n_cu blocks, and the cheapest wins.  Returns K; *t_us = its duration.
+inline size_t plan_ahead(const std::vector<uint64_t>& lens_desc, size_t n_cu, uint64_t budget_rows, double* t_us, const SweepRates& R = SweepRates())
+{
+    const size_t n = lens_desc.size();
+    n_cu = std::max<size_t>(n_cu, 1);
+    auto price = [&](size_t K) {
+        uint64_t rows = 0;
+        for (size_t k = 0; k < K; ++k) rows += lens_desc[k];
+        // (times, not lengths, go through the scheduler: scale the ahead reads' lengths by ahead / ll)
+        std::vector<uint64_t> eff(lens_desc);
+        for (size_t k = 0; k < K; ++k) eff[k] = (uint64_t)((double)eff[k] * (R.ahead / R.ll));
+        return (double)rows * R.em_cu / (double)n_cu + (K ? 30.0 : 0.0) + lpt_makespan_us(std::move(eff), n_cu, R.ll, R.per_read_us);
+    };
+    size_t best_k = 0;
+    double best = price(0);
+    uint64_t rows = 0;
+    size_t reach = 0;                                    // how many leading reads fit the budget
+    while (reach < n && reach < kMaxAheadReads && rows + lens_desc[reach] <= budget_rows) rows += lens_desc[reach++];
+    for (size_t K = 1; K <= reach; K = (K < reach && 2 * K > reach) ? reach : 2 * K) {
+        const double t = price(K);
+        if (t < best * 0.97) { best = t; best_k = K; }   // (3 %: not worth a second kernel for less)
+        if (K == reach) break;
+    }
+    if (t_us) *t_us = best;
+    return best_k;
+}
+
 // lens = the launch's reads.  busy: other launches run beside this one (a streaming caller's batches in flight, three lanes):
 // the tail of a launch is then covered by its neighbours and only throughput counts -- unless the launches are so small that
 // three of them do not fill the wide sweep's block slots.  (Three launches of 256 x 50 000-event reads in turn: 316 Mevents/s
 // wide, 288 low-latency, same box -- profiles/r05_ll_sweep.md.)
-inline Sweep choose_sweep(const std::vector<uint64_t>& lens, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates())
+inline Sweep choose_sweep(const std::vector<uint64_t>& lens, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates(),
+                          uint64_t ahead_budget_rows = 0, size_t* n_ahead = nullptr)
 {
+    if (n_ahead) *n_ahead = 0;
     if (lens.empty() || n_cu == 0) return kSweepWide;
     if (busy && lens.size() * 3 >= wide_slots) return kSweepWide;
-    const double t_ll = lpt_makespan_us(lens, n_cu, R.ll, R.per_read_us);
+    double t_ll = lpt_makespan_us(lens, n_cu, R.ll, R.per_read_us);
+    size_t k_ahead = 0;
+    if (ahead_budget_rows && !busy) {
+        std::vector<uint64_t> desc(lens);
+        std::sort(desc.begin(), desc.end(), std::greater<uint64_t>());
+        double t = t_ll;
+        k_ahead = plan_ahead(desc, n_cu, ahead_budget_rows, &t, R);
+        if (k_ahead) t_ll = t;
+    }
     const double t_wide = lens.size() <= n_cu ? lpt_makespan_us(lens, n_cu, R.wide_alone, R.per_read_us)
                                               : lpt_makespan_us(lens, wide_slots, R.wide_shared, R.per_read_us);
-    return t_ll < t_wide ? kSweepLl : kSweepWide;
+    if (t_ll >= t_wide) return kSweepWide;
+    if (n_ahead) *n_ahead = k_ahead;
+    return k_ahead ? kSweepAhead : kSweepLl;
 }
 
 // the same decision from what a device-pointer caller states: number of reads, longest read, total events
-inline Sweep choose_sweep_bounds(size_t n_reads, uint64_t longest, uint64_t total, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates())
+inline Sweep choose_sweep_bounds(size_t n_reads, uint64_t longest, uint64_t total, size_t n_cu, size_t wide_slots, bool busy, const SweepRates& R = SweepRates(),
+                                 uint64_t ahead_budget_rows = 0)
 {
     if (n_reads == 0 || n_cu == 0) return kSweepWide;
     if (busy && n_reads * 3 >= wide_slots) return kSweepWide;
@@ -168,6 +217,10 @@ inline Sweep choose_sweep_bounds(size_t n_reads, uint64_t longest, uint64_t tota
     };
     const double t_ll = bound(n_cu, R.ll);
     const double t_wide = n_reads <= n_cu ? bound(n_cu, R.wide_alone) : bound(wide_slots, R.wide_shared);
+    // every read ahead (the lengths are not known here): worth it when the batch is a few reads -- idle CUs compute the emissions
+    const double t_ahead = !busy && ahead_budget_rows && total <= ahead_budget_rows && n_reads <= kMaxAheadReads
+                               ? (double)total * R.em_cu / (double)n_cu + 30.0 + bound(n_cu, R.ahead) : 1e300;
+    if (t_ahead < 0.97 * std::min(t_ll, t_wide)) return kSweepAhead;
     return t_ll < t_wide ? kSweepLl : kSweepWide;
 }
 

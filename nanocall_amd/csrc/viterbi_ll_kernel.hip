@@ -94,14 +94,11 @@ struct ExchLL {
     const ValSlot* r2;    // four consecutive skip-group winners
 };
 
-template <bool FAST, int PAR>
-__device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* bp_row, unsigned tau, float x, float y,
-                                          float ry, float ly3, float log_2pi)
+// ---------------- group scans over the previous column, winners into the exchange arrays, the barrier ----------------
+template <int PAR>
+__device__ __forceinline__ void scan_and_publish(StateLL& S, const ExchLL& X, unsigned yy)
 {
     const float NEG_INF = -__builtin_inff();
-    const unsigned t = tau >> 2, yy = tau & 3u;
-
-    // ---------------- group scans over the previous column ----------------
     // the step group is this thread's own four states: raw maximum, strict >, ascending x => first maximum; the winner is
     // carried as its back-pointer code 1 + x straight away
     // (maximum first -- v_max3 + v_max -- then the FIRST member that equals it: the same winner as the ascending strict-> scan)
@@ -148,18 +145,47 @@ __device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* 
     if (yy == 0) X.w2[PAR * kV2Pitch] = ValSlot{s2, sl2};
     __syncthreads();
 
-    // ---------------- 3-way combine per state ----------------
-    // cell x (state j, k = 4x + y) takes the step group j >> 2 = (t>>2) + 64k -- produced by thread 4((t>>2) + 64y) + x -- and the
-    // skip group j >> 4 = (t>>4) + 16k: for x = 0..3 consecutive entries of either array
+}
+
+// the four step-group and the four skip-group winners of a thread's cells x = 0..3: two 16-byte reads per exchange array
+// (cell x takes the step group j >> 2 = (t>>2) + 64k -- produced by thread 4((t>>2) + 64y) + x -- and the skip group
+// j >> 4 = (t>>4) + 16k: for x = 0..3 consecutive entries of either array)
+template <int PAR>
+__device__ __forceinline__ void read_exchange(const ExchLL& X, float av_[4], unsigned as_[4], float bv_[4], unsigned bs_[4])
+{
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     const u4v a01 = *reinterpret_cast<const u4v*>(X.r1 + PAR * kV1Pitch), a23 = *reinterpret_cast<const u4v*>(X.r1 + PAR * kV1Pitch + 2);
     const u4v b01 = *reinterpret_cast<const u4v*>(X.r2 + PAR * kV2Pitch), b23 = *reinterpret_cast<const u4v*>(X.r2 + PAR * kV2Pitch + 2);
     // (element by element into scalars first: __builtin_bit_cast applied to a vector-element expression reads element 0)
     const unsigned a0v = a01.x, a1v = a01.z, a2v = a23.x, a3v = a23.z, b0v = b01.x, b1v = b01.z, b2v = b23.x, b3v = b23.z;
-    const float av_[4] = {__builtin_bit_cast(float, a0v), __builtin_bit_cast(float, a1v), __builtin_bit_cast(float, a2v), __builtin_bit_cast(float, a3v)};
-    const unsigned as_[4] = {a01.y, a01.w, a23.y, a23.w};
-    const float bv_[4] = {__builtin_bit_cast(float, b0v), __builtin_bit_cast(float, b1v), __builtin_bit_cast(float, b2v), __builtin_bit_cast(float, b3v)};
-    const unsigned bs_[4] = {b01.y, b01.w, b23.y, b23.w};
+    av_[0] = __builtin_bit_cast(float, a0v); av_[1] = __builtin_bit_cast(float, a1v); av_[2] = __builtin_bit_cast(float, a2v); av_[3] = __builtin_bit_cast(float, a3v);
+    as_[0] = a01.y; as_[1] = a01.w; as_[2] = a23.y; as_[3] = a23.w;
+    bv_[0] = __builtin_bit_cast(float, b0v); bv_[1] = __builtin_bit_cast(float, b1v); bv_[2] = __builtin_bit_cast(float, b2v); bv_[3] = __builtin_bit_cast(float, b3v);
+    bs_[0] = b01.y; bs_[1] = b01.w; bs_[2] = b23.y; bs_[3] = b23.w;
+}
+
+// exact rule of the 3-way combine when two class values are equal: first maximum in ascending predecessor order (strict >, NaN
+// never wins), Viterbi.hpp:79-89
+__device__ __forceinline__ void combine_exact(unsigned t, unsigned k, float s0, float av, unsigned as, float bv, unsigned bs, float& best, unsigned& slot)
+{
+    const unsigned j = t + 256u * k;
+    const unsigned p1 = ((as - 1u) << 10) | ((t >> 2) + 64u * k);
+    const unsigned p2 = ((bs - 5u) << 8) | ((t >> 4) + 16u * k);
+    float bb = -__builtin_inff(); unsigned bp = (unsigned)kStates, sl = 255u;
+    if (s0 > bb) { bb = s0; bp = j; sl = 0; }
+    if (av > bb || (av == bb && p1 < bp)) { bb = av; bp = p1; sl = as; }
+    if (bv > bb || (bv == bb && p2 < bp)) { bb = bv; bp = p2; sl = bs; }
+    best = bb; slot = sl;
+}
+
+template <bool FAST, int PAR>
+__device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* bp_row, unsigned tau, float x, float y,
+                                          float ry, float ly3, float log_2pi)
+{
+    const unsigned t = tau >> 2, yy = tau & 3u;
+    scan_and_publish<PAR>(S, X, yy);
+    float av_[4], bv_[4]; unsigned as_[4], bs_[4];
+    read_exchange<PAR>(X, av_, as_, bv_, bs_);
     unsigned bpw = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -183,15 +209,7 @@ __device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* 
         const mask_t tie = (e0 & e1) | ((e0 | e1) & e2);
         if (__builtin_expect(tie != 0, 0)) {
             ++S.n_tie;
-            // exact rule: first maximum in ascending predecessor order (strict >, NaN never wins)
-            const unsigned j = t + 256u * k;
-            const unsigned p1 = ((as_[i] - 1u) << 10) | ((t >> 2) + 64u * k);
-            const unsigned p2 = ((bs_[i] - 5u) << 8) | ((t >> 4) + 16u * k);
-            float bb = NEG_INF; unsigned bp = (unsigned)kStates, sl = 255u;
-            if (s0 > bb) { bb = s0; bp = j; sl = 0; }
-            if (av_[i] > bb || (av_[i] == bb && p1 < bp)) { bb = av_[i]; bp = p1; sl = as_[i]; }
-            if (bv_[i] > bb || (bv_[i] == bb && p2 < bp)) { bb = bv_[i]; bp = p2; sl = bs_[i]; }
-            best = bb; slot = sl;
+            combine_exact(t, k, s0, av_[i], as_[i], bv_[i], bs_[i], best, slot);
         }
         if constexpr (FAST) {
             // the rest of emission<true>() (same operations, same order of roundings)
@@ -216,6 +234,38 @@ __device__ __forceinline__ void column_ll(StateLL& S, const ExchLL& X, uint8_t* 
         }
     }
     // streaming store (the row is read once, by the traceback): byte (t<<4) | (y<<2) | x = dword tau
+    __builtin_nontemporal_store(bpw, reinterpret_cast<unsigned*>(bp_row) + tau);
+}
+
+// A column of a read whose emissions were computed ahead (emission_kernel.hip): the recurrence alone -- scans, exchange, 3-way
+// combine -- and one add of the row's four values.  No model parameter is touched: 60 % of a column's arithmetic is gone from
+// the read's critical path.
+template <int PAR>
+__device__ __forceinline__ void column_ahead(StateLL& S, const ExchLL& X, uint8_t* bp_row, unsigned tau, const float4 em4)
+{
+    const unsigned t = tau >> 2, yy = tau & 3u;
+    scan_and_publish<PAR>(S, X, yy);
+    float av_[4], bv_[4]; unsigned as_[4], bs_[4];
+    read_exchange<PAR>(X, av_, as_, bv_, bs_);
+    const float em[4] = {em4.x, em4.y, em4.z, em4.w};
+    unsigned bpw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned k = 4u * (unsigned)i + yy;
+        const float s0 = S.w0[i] + S.alpha[i];
+        float best = __builtin_fmaxf(__builtin_fmaxf(s0, av_[i]), bv_[i]);
+        const mask_t e0 = ballot(s0 == best), e1 = ballot(av_[i] == best), e2 = ballot(bv_[i] == best);
+        unsigned slot = selm_zero(e0, selm(e1, as_[i], bs_[i]));
+        const mask_t tie = (e0 & e1) | ((e0 | e1) & e2);
+        if (__builtin_expect(tie != 0, 0)) {
+            ++S.n_tie;
+            combine_exact(t, k, s0, av_[i], as_[i], bv_[i], bs_[i], best, slot);
+        }
+        if (i == 0) { S.alpha[i] = best + em[i]; bpw = slot; }
+        else if (i == 1) bpw = lshlor_add<8>(slot, bpw, best, em[i], S.alpha[i]);
+        else if (i == 2) bpw = lshlor_add<16>(slot, bpw, best, em[i], S.alpha[i]);
+        else bpw = lshlor_add<24>(slot, bpw, best, em[i], S.alpha[i]);
+    }
     __builtin_nontemporal_store(bpw, reinterpret_cast<unsigned*>(bp_row) + tau);
 }
 
@@ -299,6 +349,39 @@ __global__ __launch_bounds__(kLlThreads, 4) void viterbi_ll_kernel(ViterbiArgs P
         X.r1 = &sV1[0][v1_index(4u * ((t >> 2) + 64u * yy))];
         X.r2 = &sV2[0][v2_index((t >> 4) + 16u * yy)];
 
+        const uint64_t em_row = P.em ? (P.em_row0 ? P.em_row0[r] : e0) : kNoEmRow;
+        if (em_row != kNoEmRow) {
+            // ---- the read's emissions are in memory (emission_kernel.hip ran in front of this launch): rows of 1024 float4, this
+            // thread's at [tau].  Eight rows in flight per thread (16 KiB rows from HBM / L2: ~2 us away, a column takes ~0.45) ----
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v* __restrict__ emp = reinterpret_cast<const f4v*>(P.em) + em_row * (uint64_t)(kStates / 4) + tau;
+            auto row = [&](unsigned i) {       // (read once: streaming load; past the end: the last row again, unused)
+                const f4v v = __builtin_nontemporal_load(emp + (uint64_t)(i < n ? i : n - 1) * (kStates / 4));
+                return make_float4(v.x, v.y, v.z, v.w);
+            };
+            {
+                const float4 e = row(0);                                   // column 0 (Viterbi.hpp:55-68)
+                S.alpha[0] = e.x - P.log_n_states; S.alpha[1] = e.y - P.log_n_states; S.alpha[2] = e.z - P.log_n_states; S.alpha[3] = e.w - P.log_n_states;
+            }
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = row(1u + (unsigned)u);
+            unsigned i = 1;
+            for (; i + 8 <= n; i += 8) {                                   // (i is odd: the exchange buffer's parity is the unroll index's)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u & 1) column_ahead<0>(S, X, ws + (uint64_t)(i + u) * kStates, tau, q[u]);
+                    else column_ahead<1>(S, X, ws + (uint64_t)(i + u) * kStates, tau, q[u]);
+                    q[u] = row(i + 8u + (unsigned)u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                                  // the last n - i < 8 columns (block-uniform bound)
+                if (i + (unsigned)u >= n) break;
+                if (u & 1) column_ahead<0>(S, X, ws + (uint64_t)(i + u) * kStates, tau, q[u]);
+                else column_ahead<1>(S, X, ws + (uint64_t)(i + u) * kStates, tau, q[u]);
+            }
+        } else
         for (unsigned base = 0; base < n; base += kLlChunk) {
             // stage the next kLlChunk events: x, y, 3 log y, 1/y (one correctly rounded divide per event)
             const unsigned ie = base + tau;
@@ -396,6 +479,7 @@ __global__ __launch_bounds__(kLlThreads, 4) void viterbi_ll_kernel(ViterbiArgs P
     }
 }
 
+// (a.em != nullptr: the reads whose em_row0 is set take the recurrence-only columns)
 void launch_viterbi_ll(const ViterbiArgs& a, int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(viterbi_ll_kernel, dim3(grid), dim3(kLlThreads), 0, stream, a);

@@ -89,4 +89,5 @@ if CHECK:
     out["oracle_checked_reads"] = int(CHECK); out["oracle_equal"] = bool(ok)
 out["sweep"] = os.environ.get("SWEEP", "auto")
 out["launches_wide_ll_reads_wide_ll"] = list(ctx.sweep_stats())
+out["ahead_launches_reads_events"] = list(ctx.ahead_stats())
 print(json.dumps(out))

@@ -23,7 +23,7 @@ for R, E in SHAPES:
     cm, sd, ls = na.events_prepare(m, s, st, 0.0)
     row = {"reads": R, "events_per_read": E}
     sha = {}
-    for mode in ("wide", "ll", "auto"):
+    for mode in ("wide", "ll", "ahead", "auto"):
         ctx.set_sweep(mode)
         before = ctx.sweep_stats()
         best_wall, best_k = 1e9, 1e9
@@ -34,13 +34,14 @@ for R, E in SHAPES:
             best_k = min(best_k, ctx.last_kernel_ms()[0])
         after = ctx.sweep_stats()
         sha[mode] = hashlib.sha256(np.ascontiguousarray(states).tobytes() + np.ascontiguousarray(logp).tobytes()).hexdigest()[:16]
-        waves = -(-R // (2 * n_cu if mode == "wide" else n_cu))
+        waves = -(-R // (2 * n_cu if mode == "wide" else n_cu))      # (kernel_ms of "ahead" = the sweep alone: the emission kernel runs in front of the timed events)
         row[mode] = {"kernel_ms": round(best_k, 3), "wall_ms": round(best_wall * 1e3, 3),
                      "mevents_s_kernel": round(R * E / best_k / 1e3, 1), "mevents_s_wall": round(R * E / best_wall / 1e6, 1),
                      "launches_wide_ll": [after[0] - before[0], after[1] - before[1]]}
         if mode != "auto":
             row[mode]["us_per_event_of_a_read"] = round(best_k * 1e3 / (E * waves), 4)
-    row["same_bits"] = sha["wide"] == sha["ll"] == sha["auto"]
+        row[mode]["ahead_launches_reads_events"] = list(ctx.ahead_stats())
+    row["same_bits"] = sha["wide"] == sha["ll"] == sha["auto"] == sha["ahead"]
     rows.append(row)
     print(json.dumps(row), flush=True)
 print(json.dumps({"n_cu": n_cu, "shader_clock_mhz_under_load": round(ctx.shader_clock_mhz()), "all_same_bits": all(r["same_bits"] for r in rows)}))
