@@ -145,6 +145,32 @@ def test_ll_exchange_is_five_lds_instructions_per_column(ll_fast_loop):
     assert not [x for x in ll_fast_loop if x.startswith("v_readfirstlane")]
 
 
+def test_ll_columns_with_emissions_ahead_carry_the_recurrence_only(asm):
+    """the eight-column trip of a read whose emissions were computed ahead (column_ahead): one 16-byte global load per column and
+    thread, no model parameter in sight (no v_fma: the only FMAs of a column are the next-float probes' two), no scratch"""
+    lines = asm["viterbi_ll_kernel"].split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^\S*viterbi_ll_kernel\S*:", l))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    best = None
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m:
+            continue
+        back = [k for k in range(i + 1, len(body)) if re.search(r"s_c?branch\S*\s+" + re.escape(m.group(1)) + r"\b", body[k])]
+        if back:
+            seg = [x.split(";")[0].strip() for x in body[i:back[0] + 1]]
+            seg = [x for x in seg if x and not x.startswith(".")]
+            if sum(x.startswith("s_barrier") for x in seg) == 8 and sum(x.startswith("global_load_dwordx4") for x in seg) == 8:
+                if best is None or len(seg) < len(best):
+                    best = seg
+    assert best, "no eight-column loop with one row load per column found"
+    assert not [x for x in best if x.startswith("scratch_") or "accvgpr" in x]
+    assert sum(x.startswith(("v_fma_f32", "v_fmac_f32")) for x in best) <= 8 * 2 + 4, [x for x in best if x.startswith("v_fma")][:6]
+    assert sum(x.startswith("v_") for x in best) < 8 * 75          # 61 VALU per column today (127 with the emissions in place)
+    assert sum(x.startswith("global_store_dword") for x in best) == 8
+
+
 def test_ll_tie_and_rescan_paths_are_out_of_line(ll_fast_loop):
     assert len(ll_fast_loop) < 460, len(ll_fast_loop)       # 400 today for two columns
 

@@ -15,7 +15,7 @@ from helpers import IDENT, ragged_batch, oracle_viterbi_batch, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
-FORMS = ("wide", "ll")
+FORMS = ("wide", "ll", "ahead")      # "ahead": ll with the emissions of the longest reads computed in front of the sweep (emission_kernel.hip)
 
 
 def _ctx(form, **env):
@@ -33,11 +33,18 @@ def _ctx(form, **env):
 def _check(ctx, table, params, p_skip, p_stay, off, cm, sd, ls, form):
     ctx.put_model(0, na.scaled_model_table(table, params))
     ctx.put_transitions(0, *na.transitions_fast(p_skip, p_stay))
-    before = ctx.sweep_stats()
+    before, ahead_before = ctx.sweep_stats(), ctx.ahead_stats()
     states, logp, status = ctx.viterbi(off, cm, sd, ls)
-    after = ctx.sweep_stats()
+    after, ahead_after = ctx.sweep_stats(), ctx.ahead_stats()
     launches = (after[0] - before[0], after[1] - before[1])
-    assert launches[0 if form == "ll" else 1] == 0 and launches[1 if form == "ll" else 0] > 0, (form, launches)
+    low_latency = form in ("ll", "ahead")
+    assert launches[0 if low_latency else 1] == 0 and launches[1 if low_latency else 0] > 0, (form, launches)
+    lens = np.diff(off.astype(np.int64))
+    if form == "ahead" and 0 < lens.max() <= 16384 and len(lens) <= 2 * ctx.grid_slots():
+        # (one-call batches of up to two grid-fulls go up as one launch: its longest reads, as far as the 256 MiB buffer holds)
+        assert ahead_after[0] > ahead_before[0] and ahead_after[1] > ahead_before[1], (ahead_before, ahead_after)
+    if form != "ahead":
+        assert ahead_after == ahead_before
     ostates, ologp = oracle_viterbi_batch(table, params, p_skip, p_stay, off, cm, sd, ls)
     nz = np.diff(off.astype(np.int64)) > 0
     assert np.array_equal(states, ostates), form
@@ -146,8 +153,9 @@ def test_both_forms_return_the_same_bits_on_a_full_grid(r73t):
         for form in FORMS:
             ctx.set_sweep(form)
             res[form] = ctx.viterbi(off, cm, sd, ls, model_slot=slot, trans_slot=slot)
-        assert np.array_equal(res["wide"][0], res["ll"][0]) and res["wide"][1].tobytes() == res["ll"][1].tobytes()
-        assert (res["ll"][2] == 0).all()
+        for form in ("ll", "ahead"):
+            assert np.array_equal(res["wide"][0], res[form][0]) and res["wide"][1].tobytes() == res[form][1].tobytes(), form
+            assert (res[form][2] == 0).all()
     finally:
         ctx.close()
 
@@ -178,7 +186,9 @@ def test_the_plan_picks_the_form_from_the_read_lengths(r73t):
             assert np.array_equal(out["auto"][0], out["wide"][0]) and out["auto"][1].tobytes() == out["wide"][1].tobytes()
             return out["auto_launches"]
 
-        assert run([700]) == (0, 1)                                   # one strand
+        a0 = ctx.ahead_stats()
+        assert run([700]) == (0, 1)                                   # one strand ...
+        assert ctx.ahead_stats()[0] == a0[0] + 1                      # ... with its emissions computed ahead by the idle CUs
         assert run([300] * n_cu) == (0, 1)                            # one read per CU
         w, l = run([200] * (2 * slots))                               # equal reads, slots filled twice
         assert l == 0 and w >= 1

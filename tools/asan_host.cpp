@@ -174,5 +174,31 @@ int main(){
       if (nchmm::choose_sweep(skew, n_cu, wide, false, R) != nchmm::kSweepLl || nchmm::choose_sweep_bounds(1000, 400000, 1000 * 2000 + 398000, n_cu, wide, false, R) != nchmm::kSweepLl) return 69;
       if (nchmm::choose_sweep(std::vector<uint64_t>(), n_cu, wide, false, R) != nchmm::kSweepWide || nchmm::choose_sweep_bounds(0, 0, 0, n_cu, wide, false, R) != nchmm::kSweepWide) return 70;
     }
+    // emissions ahead (plan_ahead): never more reads than the buffer holds or than kMaxAheadReads, never when it does not pay
+    for (int trial = 0; trial < 200; ++trial) {
+      const size_t n = 1 + r() % 700;
+      std::vector<uint64_t> lens(n);
+      for (auto& l : lens) l = 1 + r() % (trial % 3 ? 3000 : 40000);
+      std::sort(lens.begin(), lens.end(), std::greater<uint64_t>());
+      const uint64_t budget = (r() % 4 == 0) ? 0 : 1 + r() % 60000;
+      double t = -1;
+      const size_t K = nchmm::plan_ahead(lens, 256, budget, &t, R);
+      uint64_t rows = 0; for (size_t k = 0; k < K; ++k) rows += lens[k];
+      if (K > n || K > nchmm::kMaxAheadReads || rows > budget || t <= 0) return 71;
+      const double t0 = nchmm::lpt_makespan_us(lens, 256, R.ll, R.per_read_us);
+      if (K == 0 ? t != t0 : t >= t0) return 72;
+      size_t k2 = 99;
+      const nchmm::Sweep c = nchmm::choose_sweep(lens, 256, 512, false, R, budget, &k2);
+      if ((c == nchmm::kSweepAhead) != (k2 > 0) || (c == nchmm::kSweepAhead && k2 != K)) return 73;
+      if (nchmm::choose_sweep(lens, 256, 512, false, R, 0, &k2) == nchmm::kSweepAhead || k2 != 0) return 74;
+    }
+    { // one strand: ahead when it fits the buffer
+      std::vector<uint64_t> one(1, 5000);
+      size_t k = 0;
+      if (nchmm::choose_sweep(one, 256, 512, false, R, 16384, &k) != nchmm::kSweepAhead || k != 1) return 75;
+      if (nchmm::choose_sweep_bounds(1, 5000, 5000, 256, 512, false, R, 16384) != nchmm::kSweepAhead) return 76;
+      if (nchmm::choose_sweep_bounds(1, 50000, 50000, 256, 512, false, R, 16384) != nchmm::kSweepLl) return 77;
+      if (nchmm::choose_sweep_bounds(1, 5000, 5000, 256, 512, true, R, 16384) == nchmm::kSweepAhead) return 78;
+    }
     puts("sweep choice: ok"); }
   puts("host ABI under ASan/UBSan: ok"); return 0; }
