@@ -34,10 +34,11 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lens = np.arange(1, 41) * 100
     mine = shard.lpt_partition(lens, world)[rank]
-    local = np.array([len(mine), int(lens[mine].sum()), 0, 1, 0, 0, 0, 0], np.uint64)
+    local = np.array([len(mine), int(lens[mine].sum()), 0, 1, 0, 0, 0, 0, 1], np.uint64)      # last slot: "a rank was here" (bench.py)
     tot = shard.gather_counters(local)
     mx = shard.max_over_ranks(1.0 + rank)
-    q.put((rank, tot.tolist(), mx, mine.tolist()))
+    per = shard.gather_per_rank([10.0 + rank, 2000.0 + 7 * rank, 15.0, float(len(mine))])    # bench.py: step time, clock, kernel ms, reads
+    q.put((rank, tot.tolist(), mx, mine.tolist(), per.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,11 +54,17 @@ def test_two_rank_gloo_counter_gather():
     assert all(p.exitcode == 0 for p in ps)
     lens = np.arange(1, 41) * 100
     seen = []
-    for rank, tot, mx, mine in res:
-        assert tot[0] == 40 and tot[1] == int(lens.sum()) and tot[3] == world
+    for rank, tot, mx, mine, per in res:
+        assert tot[0] == 40 and tot[1] == int(lens.sum()) and tot[3] == world and tot[8] == world
         assert mx == 2.0
+        # every rank sees every rank's row, in rank order
+        assert per == [[10.0, 2000.0, 15.0, float(len(shard.lpt_partition(lens, world)[0]))], [11.0, 2007.0, 15.0, float(len(shard.lpt_partition(lens, world)[1]))]]
         seen += mine
     assert sorted(seen) == list(range(40))
+
+
+def test_gather_per_rank_without_a_process_group_is_one_row():
+    assert shard.gather_per_rank([1.5, 2.5]).tolist() == [[1.5, 2.5]]
 
 
 def test_c_abi_lpt_partition_equals_the_python_one():
