@@ -643,6 +643,10 @@ uint64_t viterbi_em_budget_rows(nchmm_ctx* c)
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)32 << 30;
         const char* e = std::getenv("NCHMM_EM_BUDGET_MB");
         c->em_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : std::min<size_t>((size_t)256 << 20, free_b / 4);
+        // a caller that bounds the back-pointer workspace (NCHMM_WS_BUDGET_MB) is short of memory: the buffer follows, a quarter of
+        // that at most (unless it was set on its own)
+        size_t ws = 0;
+        if (!e && viterbi_ws_budget(c, &ws) == NCHMM_OK) c->em_budget = std::min(c->em_budget, ws / 4);
         if (c->em_budget < ((size_t)1 << 20)) c->em_budget = (size_t)1 << 20;
     }
     return (uint64_t)(c->em_budget / ((size_t)kStates * sizeof(float)));
