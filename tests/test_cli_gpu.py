@@ -212,6 +212,23 @@ def test_two_contexts_shard_the_reads_and_gather_counters(tmp_path):
     assert "gathered_by=rccl_allreduce" in c4 and pick(c4, "events_decoded") == pick(c1, "events_decoded")
 
 
+def test_chunk_stages_side_by_side_give_the_serial_output(tmp_path):
+    """Event loading / packing, the GPU stages and FASTA writing run side by side on consecutive chunks of reads
+    (process_reads); `--serial-chunks` takes one chunk at a time through all three as rounds 1-4 did.  Same FASTA, same --stats,
+    same --dump-params, with training, over many small chunks -- and with the process's destructors run (NANOCALL_FULL_EXIT: the
+    default leaves through _Exit once everything is written)."""
+    names = ["r73_2d_a", "r73_1d_b", "r73_short_c", "r73_2d_e", "r73_2d_a", "r73_1d_b", "r73_2d_e", "r73_2d_a"]
+    files = [os.path.join(G, n + ".fast5") for n in names]
+    base = ["--pore", "r73", "--scaling-num-events", "120", "--scaling-max-rounds", "2", "--chunk-events", "900", "-t", "4"]
+    out = {}
+    for tag, extra, env in (("serial", ["--serial-chunks"], {}), ("staged", [], {}), ("staged_full_exit", [], {"NANOCALL_FULL_EXIT": "1"})):
+        fa, st, dp = tmp_path / f"{tag}.fa", tmp_path / f"{tag}.tsv", tmp_path / f"{tag}.params"
+        r = run_cli(base + extra + ["-o", str(fa), "--stats", str(st), "--dump-params", str(dp)] + files, env=env)
+        out[tag] = (fa.read_text(), st.read_text(), dp.read_text())
+        assert out[tag][0].count(">") >= 10, r.stderr[-2000:]
+    assert out["staged"] == out["serial"] and out["staged_full_exit"] == out["serial"]
+
+
 def test_counter_gather_falls_back_to_the_host_sum_when_rccl_cannot_be_used(tmp_path):
     """nchmm_pool_counters' RCCL path (csrc/nchmm_pool.cpp: rccl_sum) must never cost a run its counters: librccl missing
     (dlopen fails), librccl without the entry points, and a library whose ncclCommInitAll returns an error all end in the
