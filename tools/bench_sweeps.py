@@ -29,7 +29,7 @@ for R, E in SHAPES:
         best_wall, best_k = 1e9, 1e9
         for _ in range(REPS):
             t0 = time.perf_counter()
-            states, logp, status = ctx.viterbi(off, cm, sd, ls)
+            states, logp, status = ctx.viterbi(off, cm, sd, ls, raise_on_numeric=False)    # (experiment builds return wrong results on purpose)
             best_wall = min(best_wall, time.perf_counter() - t0)
             best_k = min(best_k, ctx.last_kernel_ms()[0])
         after = ctx.sweep_stats()
