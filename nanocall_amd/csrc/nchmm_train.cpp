@@ -100,6 +100,7 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         return NCHMM_E_INVALID;
     const float NEG_INF = -std::numeric_limits<float>::infinity();
     const uint64_t total_events = strand_off[2 * n_reads];
+    const auto t_call = std::chrono::steady_clock::now();
     // Only the training windows (first and last scaling_num_events / 2 events of a strand, nanocall.cpp:333-337) are
     // ever read: they are compacted strand by strand -- [head window | tail window] at position 2 * half * k of the
     // compact arrays for strand k -- and only those go to the device.  log_stdv: Event::update_logs happened at load
@@ -163,6 +164,7 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::vector<size_t> act;
+    const auto t_rounds = now();
     for (;;) {
         const auto t_0 = now();
         act.clear();
@@ -259,6 +261,9 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             std::fprintf(stderr, "[nchmm_train_reads] round: %zu jobs, gather %.2f ms, tables %.2f ms, fwbw %.2f ms, finish %.2f ms\n", na,
                          ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3), ms(t_3, now()));
     }
+    if (dbg_time)
+        std::fprintf(stderr, "[nchmm_train_reads] %zu jobs of %zu reads: setup (windows, job table, events up) %.2f ms, rounds %.2f ms\n", n_jobs, n_reads,
+                     ms(t_call, t_rounds), ms(t_rounds, now()));
     for (size_t k = 0; k < n_jobs; ++k) {
         std::memcpy(job_pm + 6 * k, jobs[k].pm, sizeof(jobs[k].pm));
         std::memcpy(job_st + 4 * k, jobs[k].st, sizeof(jobs[k].st));
