@@ -567,6 +567,17 @@ int nchmm_pool_basecall_reads(nchmm_pool* pool, const nchmm_train_opts* opts, si
                               const float* job_pm, const float* job_st, const int32_t* read_preferred, uint16_t* out_state,
                               int32_t* out_best_job, float* out_best_logp);
 
+/* Take the forward-backward alpha-row workspace (16 KiB per window event, bounded by NCHMM_FB_BUDGET_MB) for batches of up to
+ * `events` window events now instead of in the first EM round: a host that knows a long run is coming calls it while it still
+ * reads its input (the first multi-GiB allocation on a device whose memory is not mapped yet costs ~20 ms per GiB).  No
+ * reference counterpart (`Forward_Backward::fill` allocates its matrix per call, Forward_Backward.hpp:52). */
+int nchmm_reserve_fb_workspace(nchmm_ctx* ctx, size_t events);
+int nchmm_pool_reserve_fb_workspace(nchmm_pool* pool, size_t events_per_device);
+/* The same for the Viterbi back-pointer regions (`Viterbi::fill` allocates its matrix per call, Viterbi.hpp:50): a full pool of
+ * regions for reads of up to longest_events (0: the longest a full pool fits in NCHMM_WS_BUDGET_MB). */
+int nchmm_reserve_viterbi_workspace(nchmm_ctx* ctx, size_t longest_events);
+int nchmm_pool_reserve_viterbi_workspace(nchmm_pool* pool, size_t longest_events);
+
 /* nchmm_counters summed over the pool's contexts.  With two or more DISTINCT devices the sum is one RCCL all-reduce
  * (ncclCommInitAll over the pool's devices, single process; librccl is loaded at run time) and *used_rccl = 1;
  * otherwise (one device, repeated ids, librccl missing) it is a host sum and *used_rccl = 0.  NCHMM_POOL_FORCE_RCCL=1

@@ -96,6 +96,10 @@ SIGNATURES = {
     "nchmm_pool_create": (C.c_int, [C.POINTER(vp), C.c_int, vp]),
     "nchmm_pool_destroy": (C.c_int, [vp]),
     "nchmm_pool_size": (C.c_int, [vp]),
+    "nchmm_reserve_fb_workspace": (C.c_int, [vp, C.c_size_t]),
+    "nchmm_pool_reserve_fb_workspace": (C.c_int, [vp, C.c_size_t]),
+    "nchmm_reserve_viterbi_workspace": (C.c_int, [vp, C.c_size_t]),
+    "nchmm_pool_reserve_viterbi_workspace": (C.c_int, [vp, C.c_size_t]),
     "nchmm_pool_ctx": (vp, [vp, C.c_int]),
     "nchmm_lpt_partition": (C.c_int, [C.c_size_t, vp, C.c_int, vp]),
     "nchmm_pool_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),

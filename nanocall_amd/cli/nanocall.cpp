@@ -1120,6 +1120,20 @@ static int real_main()
         }
         { STAGE("device_init_s"); check(nchmm_pool_create(&pool, use, ids.empty() ? nullptr : ids.data()), "nchmm_pool_create"); }
         LOG(info) << "devices=" << use << " (of " << n_dev << " visible)" << std::endl;
+        if (opts::train && files.size() >= 512) {
+            // a long run: the alpha-row workspace of the EM rounds now, while the summary pass is still reading files -- on a device
+            // whose memory is not mapped yet its first allocation costs ~20 ms per GiB, which would land in the first chunk's rounds
+            // (a read brings ~2 model pairs x 4 windows x scaling_num_events / 2 events per round; the library caps it at its budget)
+            STAGE("reserve_workspace_s");
+            check(nchmm_pool_reserve_fb_workspace(pool, files.size() / (size_t)use * 8 * (size_t)opts::scaling_num_events.get()), "nchmm_pool_reserve_fb_workspace");
+        }
+        if (opts::basecall && files.size() >= 512) {
+            // ... and the back-pointer regions for strands of up to 6000 events (16 GiB; they grow when longer strands come).  On a
+            // device nobody has used since it was brought up these allocations cost ~30 ms per GiB wherever they happen; here they
+            // happen while the summary pass is reading files
+            STAGE("reserve_workspace_s");
+            check(nchmm_pool_reserve_viterbi_workspace(pool, 6000), "nchmm_pool_reserve_viterbi_workspace");
+        }
         return EXIT_SUCCESS;
     };
     try {

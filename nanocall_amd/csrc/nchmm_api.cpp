@@ -1205,6 +1205,38 @@ int nchmm_em_load_events(nchmm_ctx* c, size_t n_events, const float* mean, const
 
 // A round whose alpha rows exceed the forward-backward budget is cut at job boundaries (a job's windows stay together:
 // its outer sums are reduced on the device) and the ranges run one after the other.
+// Take the alpha-row workspace for batches of up to `events` window events NOW (bounded by the FB budget).  A host that knows a
+// long run is coming calls this while it is still reading its input: the first allocation of a multi-GiB workspace on a device
+// whose memory is not mapped yet costs ~20 ms per GiB, which otherwise lands in the first EM round (nanocall: 690 ms against
+// 200 for the first chunk's rounds, profiles/r05_notes.md).
+int nchmm_reserve_fb_workspace(nchmm_ctx* c, size_t events)
+{
+    if (!c) return NCHMM_E_INVALID;
+    if (events == 0) return NCHMM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t cap = fb_budget_events(c, (size_t)kStates * sizeof(float));
+    void* p = c->d_fb_ws;
+    size_t have = c->fb_ws_floats * sizeof(float);
+    const int rc = ensure(c, &p, &have, std::min(events, cap) * kStates * sizeof(float));
+    c->d_fb_ws = (float*)p; c->fb_ws_floats = have / sizeof(float);
+    return rc;
+}
+
+// The same for the Viterbi back-pointer regions: a full pool (launches of any size, all three lanes) of regions for reads of up
+// to longest_events; 0 = the longest a full pool fits in the budget (NCHMM_WS_BUDGET_MB).
+int nchmm_reserve_viterbi_workspace(nchmm_ctx* c, size_t longest_events)
+{
+    if (!c) return NCHMM_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t budget = 0;
+    int rc = viterbi_ws_budget(c, &budget);
+    if (rc != NCHMM_OK) return rc;
+    const size_t fit = budget / ((size_t)kXcds * c->slots_per_xcd) / kBpRowBytes;
+    if (longest_events == 0 || longest_events > fit) longest_events = fit;
+    // (the pool keeps 1/8 head-room on top of what it is asked for: ask for that much less)
+    return longest_events ? viterbi_ws_prepare(c, std::max<size_t>(longest_events * 8 / 9, 1), (size_t)c->vit_slots) : NCHMM_OK;
+}
+
 int nchmm_em_round(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift,
                    const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
                    size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_lpd, float* out_st, double* out_acc)

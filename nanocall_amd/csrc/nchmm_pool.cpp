@@ -446,6 +446,26 @@ int nchmm_pool_basecall_reads(nchmm_pool* pool, const nchmm_train_opts* o, size_
     });
 }
 
+int nchmm_pool_reserve_fb_workspace(nchmm_pool* pool, size_t events_per_device)
+{
+    if (!pool || pool->ctx.empty()) return NCHMM_E_INVALID;
+    for (nchmm_ctx* c : pool->ctx) {
+        const int rc = nchmm_reserve_fb_workspace(c, events_per_device);
+        if (rc != NCHMM_OK) return rc;
+    }
+    return NCHMM_OK;
+}
+
+int nchmm_pool_reserve_viterbi_workspace(nchmm_pool* pool, size_t longest_events)
+{
+    if (!pool || pool->ctx.empty()) return NCHMM_E_INVALID;
+    for (nchmm_ctx* c : pool->ctx) {
+        const int rc = nchmm_reserve_viterbi_workspace(c, longest_events);
+        if (rc != NCHMM_OK) return rc;
+    }
+    return NCHMM_OK;
+}
+
 int nchmm_pool_counters(nchmm_pool* pool, uint64_t out[8], int* used_rccl)
 {
     if (!pool || !out) return NCHMM_E_INVALID;
