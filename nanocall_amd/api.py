@@ -588,6 +588,14 @@ class Context:
         check(lib().nchmm_mem_stats(self._h, _p(out)), "nchmm_mem_stats")
         return int(out[0]), int(out[1])
 
+    def reserve_workspaces(self, fb_events=0, viterbi_longest=None):
+        """take the FB alpha-row workspace (for batches of up to fb_events window events) and / or the Viterbi back-pointer regions
+        (for reads of up to viterbi_longest events; 0 = as long as a full pool fits in the budget) now instead of at first use"""
+        if fb_events:
+            check(lib().nchmm_reserve_fb_workspace(self._h, int(fb_events)), "nchmm_reserve_fb_workspace")
+        if viterbi_longest is not None:
+            check(lib().nchmm_reserve_viterbi_workspace(self._h, int(viterbi_longest)), "nchmm_reserve_viterbi_workspace")
+
     def grid_slots(self):
         v = C.c_int(0)
         check(lib().nchmm_grid_slots(self._h, C.byref(v)), "nchmm_grid_slots")

@@ -339,6 +339,36 @@ def test_contexts_give_their_device_memory_back(r73t):
     assert free0 - free1 < (32 << 20), f"{(free0 - free1) >> 20} MiB of device memory not returned after 12 create/destroy cycles"
 
 
+def test_workspaces_reserved_ahead_are_the_ones_the_batches_use(r73t):
+    """nchmm_reserve_viterbi_workspace / nchmm_reserve_fb_workspace (what the command line calls while it still reads files): the
+    device memory is taken at the call, the batches that follow allocate no workspace of their own, and decode the same bits."""
+    from nanocall_amd import synth
+    ev = synth.generate(r73t, 40, 900)
+    off, mean, stdv, start = synth.flat_batch(ev)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    woff = (np.arange(41) * 100).astype(np.uint64)
+    stp = np.tile(np.float32([0.1, 0.3]), (40, 1))
+    with na.Context(0) as fresh:
+        fresh.put_model(0, na.scaled_model_table(r73t)); fresh.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        want = fresh.viterbi(off, cm, sd, ls)
+        want_fb = fresh.fwbw(woff, cm[:4000], sd[:4000], ls[:4000], st_params=stp)["log_pr_data"]
+    with na.Context(0) as ctx:
+        ctx.put_model(0, na.scaled_model_table(r73t)); ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+        m0 = ctx.mem_stats()[0]
+        ctx.reserve_workspaces(fb_events=5000, viterbi_longest=2000)
+        m1 = ctx.mem_stats()[0]
+        assert m1 - m0 >= 5000 * 16384 + 2000 * 4096 * 64          # alpha rows + at least one region per block slot of an XCD
+        got = ctx.viterbi(off, cm, sd, ls)
+        got_fb = ctx.fwbw(woff, cm[:4000], sd[:4000], ls[:4000], st_params=stp)["log_pr_data"]
+        m2 = ctx.mem_stats()[0]
+        assert m2 - m1 < (64 << 20), (m0, m1, m2)                  # staging only: no second workspace
+        assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes() and got_fb.tobytes() == want_fb.tobytes()
+        ctx.reserve_workspaces(viterbi_longest=0)                  # as long as a full pool fits in the budget: grows, still works
+        assert ctx.mem_stats()[0] > m2
+        again = ctx.viterbi(off, cm, sd, ls)
+        assert np.array_equal(again[0], want[0])
+
+
 _ORDER_CHILD = r"""
 import faulthandler, sys, time
 # a child that does not come back prints every thread's Python stack after 280 s and exits (never left hanging, never re-executed).
