@@ -258,7 +258,13 @@ int nchmm_viterbi_dev(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t 
  *   join     makes the context's stream wait for every batch enqueued so far: what is queued on that stream
  *            afterwards sees their outputs.  (nchmm_synchronize joins, waits, and reports.)
  * Between enqueue and join the caller leaves the batch's inputs and outputs alone, and must not hand the same output
- * arrays to a second batch.  nchmm_viterbi_dev is enqueue followed by join. */
+ * arrays to a second batch.  nchmm_viterbi_dev is enqueue followed by join.
+ * The lengths are only on the device, so the plan the host-pointer forms make on the host is made there (plan_kernel.hip): a
+ * batch whose stated longest read is well above its mean is handed out longest first (a kernel in front of the sweep, nothing
+ * waited for); and in ONE case the call does wait -- for the lanes and for one 32-byte read-back: when max_events is so long
+ * that a full pool of back-pointer regions of that length does not fit NCHMM_WS_BUDGET_MB, the few reads that long are found on
+ * the device and get regions of their own beside the pooled launch (else the whole batch would run on as many blocks as the
+ * budget has regions of that length for).  d_order != NULL switches both off: the caller's order is taken as it is. */
 int nchmm_viterbi_dev_enqueue(nchmm_ctx* ctx, size_t n_reads, size_t max_events, size_t total_events,
                               const uint64_t* d_off, const float* d_corrected_mean, const float* d_stdv,
                               const float* d_log_stdv, const int32_t* d_model_slot, const int32_t* d_trans_slot,
