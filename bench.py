@@ -484,7 +484,11 @@ def main():
         sys.exit(2)
     dev = torch.device("cuda", local_rank_dev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # A process group whenever a launcher started this rank (torch.distributed.run exports RANK / MASTER_ADDR) -- also for ONE
+    # rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` then takes the very calls an 8-rank run takes
+    # (RCCL communicator, barrier, the counters' all-reduce, the per-rank all-gather) on the one GPU a test box has.
+    group = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if group:
         if share_gpu0:
             dist.init_process_group("gloo")
         else:
@@ -557,7 +561,7 @@ def main():
     ctx.viterbi_dev_join()
     torch.cuda.synchronize()
     launches0 = int(ctx.counters()[3]) - c_settle[3]
-    if world > 1:
+    if group:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -565,7 +569,7 @@ def main():
         step()
     ctx.viterbi_dev_join()
     torch.cuda.synchronize()
-    if world > 1:
+    if group:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -602,7 +606,7 @@ def main():
     torch.cuda.synchronize()
     t_serial = time.perf_counter() - t_serial
     sclk_serial_mhz = clock()    # right behind the serial launches
-    red_dev = dev if (world > 1 and not share_gpu0) else None      # gloo reduces host tensors
+    red_dev = dev if (group and not share_gpu0) else None      # gloo reduces host tensors
     # per rank: wall of the timed region, shader clock behind it, the kernel alone -- one all-gather; the step time of the line is
     # the maximum over ranks, as the contract says
     per_rank = shard.gather_per_rank([dt, sclk_mhz, float(np.mean([k[0] for k in kernel_ms])), float(n_reads)], red_dev)
@@ -652,7 +656,7 @@ def main():
             workload = (f"BASELINE {which}: {reads_per_gpu} reads x {n_events} events per GPU ({reads_per_gpu * world} reads "
                         f"over {world} GPU(s)), template-only Viterbi, builtin {args.model} 6-mer model, identity scaling, "
                         f"transitions p_skip=.3 p_stay=.1")
-        if world == 1:
+        if not group:
             collective = "none (one rank)"
         elif share_gpu0:
             collective = f"gloo, communicator of {dist.get_world_size()} ranks all on GPU 0 (test hook)"
@@ -700,7 +704,7 @@ def main():
                                                    "serial_launches": (round(sclk_serial_mhz, 0) if sclk_serial_mhz == sclk_serial_mhz else None)},
                        "note": "rank 0, ~3 ms full-chip VALU probe right behind each leg (nchmm_shader_clock_mhz)"},
         }
-        if world > 1:
+        if group:
             stat = lambda v: {"min": round(float(np.min(v)), 3), "median": round(float(np.median(v)), 3), "max": round(float(np.max(v)), 3)}
             result["ranks"] = {"ms_per_step": stat(per_rank[:, 0] / args.steps * 1e3), "kernel_ms": stat(per_rank[:, 2]),
                                "shader_clock_mhz": [round(float(x)) if x == x else None for x in per_rank[:, 1]],
@@ -779,7 +783,7 @@ def main():
                 result["fwbw"] = {"error": str(e)}
         print(json.dumps(result), flush=True)
     ctx.close()
-    if world > 1:
+    if group:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -109,3 +109,30 @@ def test_pool_leg_drives_every_device_from_host_arrays():
     assert d["n_gpus"] == 2 and d["config"]["pool_devices"] == [0, 0] and d["config"]["reads_total"] == 600
     assert d["counters"]["reads"] == 600 * 3 and d["counters"]["events"] == 600 * 800 * 3 and d["counters_through_rccl"] is False
     assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"] and d["value"] > 0
+
+
+def test_one_rank_under_the_launcher_goes_through_rccl():
+    """The driver starts an N-GPU run as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, one rank per GPU
+    over RCCL.  No multi-GPU box has run that yet; what a 1-GPU box can run is the same command with N = 1: the rank forms its
+    RCCL communicator ("nccl" backend, device_id = its GPU), takes the barriers on both sides of the timed region, the
+    all-reduce of the counters and the all-gather of the per-rank numbers as device tensors -- every call of the N > 1 path, on a
+    communicator of one.  (The share-GPU-0 rehearsal above cannot: RCCL refuses two ranks on one device, so it runs on gloo.)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NCHMM_BENCH_SHARE_GPU0"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--reads", "300", "--events", "800", "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end", "--no-shard-leg"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["collective"].startswith("rccl:") and "communicator of 1 ranks" in d["config"]["collective"]
+    assert d["ranks_in_collective"] == 1 and d["ranks"]["reads"] == [300]
+    assert d["counters"]["reads"] == 300 * 3 and d["counters"]["events"] == 300 * 800 * 3
+    assert abs(d["value"] - 300 * 800 * 2 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) <= 0.01 * d["value"]
