@@ -1,6 +1,6 @@
 """Throughput of the host-pointer Viterbi on RAGGED batches (what real runs look like: nanopore reads are log-normally
 long) against the uniform batch of the same total size.  Lengths: lognormal(median MEDIAN, sigma SIGMA) clipped to
-[200, MAXLEN], seeded.  Reports the one-call form, the streaming form (two batches in flight) and the lower bound the
+[200, MAXLEN], seeded.  Reports the one-call form, the streaming form (DEPTH batches in flight, default one per lane) and the lower bound the
 longest read sets (a read is sequential: one block, one event after the other)."""
 import hashlib, json, os, sys, time
 import numpy as np
@@ -46,7 +46,7 @@ out["kernels_ms"] = [round(x, 2) for x in ctx.last_kernel_ms()[:2]]
 out["states_sha"] = hashlib.sha256(np.ascontiguousarray(st).tobytes()).hexdigest()[:16]
 
 
-DEPTH = int(os.environ.get("DEPTH", 2))     # batches in flight (the library takes as many as it has lanes)
+DEPTH = int(os.environ.get("DEPTH", 3))     # batches in flight (the library takes as many as it has lanes: three)
 NB = int(os.environ.get("BATCHES", 6))
 
 
