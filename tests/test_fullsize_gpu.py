@@ -153,3 +153,80 @@ def test_config4_shard_12500_reads_sub_batched(r73t):
         assert np.array_equal(states[:n_events], os_) and ol[0].tobytes() == logp[0].tobytes()
     finally:
         ctx.close()
+
+
+def test_config3_2d_reads_four_round_em_at_full_size(gpu_ctx):
+    """BASELINE config 3 at the size tools/bench_config3.py times it: 1024 template+complement reads of 5000 events per strand,
+    two candidate model pairs each, exactly four Parameter_Trainer rounds per pair (nanocall.cpp:360-426 with
+    scaling_max_rounds 2, :420), then both strands of every pair decoded with its trained parameters and the better pair kept
+    (nanocall.cpp:692-712).  Size-independent checks: (1) a pair's training result does not depend on the batch it is in -- six
+    pairs trained on their own return the same bits; (2) one of them equals the reference's loop driven by the CPU oracle, within
+    the EM tolerances of test_train_reads_gpu.py; (3) every round counter says four and every fit is finite; (4) every read
+    gets a winner, whose decode equals that read decoded in a batch of its own, bit for bit, and stays on the stay / step / skip
+    graph; (5) the second call returns the same bits as the first."""
+    from nanocall_amd import api
+    from test_train_reads_gpu import reference_train_job
+    n_reads, n_ev = 1024, 5000
+    names = ["r73.c.p1", "r73.c.p2", "r73.t"]           # sorted by name, like the reference's std::map
+    strands = [1, 1, 0]
+    tables = [na.builtin_model(n) for n in names]
+    states = np.stack([na.model_load(t) for t in tables])
+    e0 = synth.generate(tables[2], n_reads, n_ev)
+    e1 = synth.generate(tables[0], n_reads, n_ev, first_read=10**6)
+    mean = np.stack([e0["mean"], e1["mean"]], 1).reshape(-1)
+    stdv = np.stack([e0["stdv"], e1["stdv"]], 1).reshape(-1)
+    start = np.stack([e0["start"], e1["start"]], 1).reshape(-1)
+    del e0, e1
+    _, stdv, _ = na.events_prepare(mean, stdv, None, 0.0)          # Event::update_logs: stdv 0 -> .01
+    so = (np.arange(2 * n_reads + 1) * n_ev).astype(np.uint64)
+    opts = api.train_opts(scaling_max_rounds=2, scaling_min_progress=0.0)
+    jr, j0, j1 = api.train_enumerate(opts, strands, so, np.ones(n_reads, np.uint8))
+    assert len(jr) == 2 * n_reads and list(zip(jr[:2], j0[:2], j1[:2])) == [(0, 2, 0), (0, 2, 1)]
+    out = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    # (3)
+    assert (out["rounds"] == 4).all() and np.isfinite(out["fit"]).all() and np.isfinite(out["pm"]).all() and np.isfinite(out["st"]).all()
+    assert (out["pm"][:, 0] > 0.5).all() and (out["pm"][:, 0] < 2.0).all() and (out["st"] > 0).all() and (out["st"] < 1).all()
+    # (5)
+    again = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    for k in ("pm", "st", "fit", "rounds", "preferred"):
+        assert out[k].tobytes() == again[k].tobytes(), k
+    # (1) six pairs on their own
+    for r in (0, 511, 1023):
+        a, b = int(so[2 * r]), int(so[2 * r + 2])
+        so1 = (so[2 * r:2 * r + 3] - so[2 * r]).astype(np.uint64)
+        jr1, j01, j11 = api.train_enumerate(opts, strands, so1, np.ones(1, np.uint8))
+        one = gpu_ctx.train_reads(opts, states, so1, mean[a:b], stdv[a:b], start[a:b], jr1, j01, j11)
+        for k in ("pm", "st", "fit", "rounds"):
+            assert one[k].tobytes() == out[k][2 * r:2 * r + 2].tobytes(), (r, k, one[k], out[k][2 * r:2 * r + 2])
+    # (2) the reference's loop on the oracle, pair (t, c.p1) of read 511
+    r, k = 511, 2 * 511
+    windows, wst = [], []
+    for s in (0, 1):
+        lo, hi = int(so[2 * r + s]), int(so[2 * r + s + 1])
+        half = min(opts.scaling_num_events, hi - lo) // 2
+        for sl in (slice(lo, lo + half), slice(hi - half, hi)):
+            windows.append((mean[sl], stdv[sl], start[sl])); wst.append(s)
+    pm, st, fit, rnd = reference_train_job(opts, tables, windows, wst, (2, 0), [1, 0, 0, 1, 1, 1], [0.1, 0.3, 0.1, 0.3])
+    assert rnd == 4 and abs(out["fit"][k] - fit) <= 1e-4 * abs(fit), (rnd, out["fit"][k], fit)
+    got = out["pm"][k]
+    for q in (0, 4):
+        assert abs(got[q] - pm[q]) <= 2e-4 * abs(pm[q]), (q, got, pm)
+    for q in (3, 5):                                                   # var, var_sd: the reference's own fp32 noise (test_fwbw_gpu.py)
+        assert abs(got[q] - pm[q]) <= 1.5e-3 * abs(pm[q]), (q, got, pm)
+    assert np.allclose(out["st"][k], st, rtol=5e-4, atol=0), (out["st"][k], st)
+    # (4) decode with the trained parameters
+    bc = gpu_ctx.basecall_reads(opts, states, so, mean, stdv, start, jr, j0, j1, out["pm"], out["st"])
+    assert (bc["best_job"] >= 0).all() and (bc["best_job"][:, 0] == bc["best_job"][:, 1]).all()
+    assert (bc["best_job"][:, 0] // 2 == np.arange(n_reads)).all() and np.isfinite(bc["best_logp"]).all()
+    # (the complement strands were generated from r73.c.p1: the pair trained on it should win nearly everywhere)
+    assert (bc["best_job"][:, 0] % 2 == 0).mean() > 0.95
+    S = bc["states"].reshape(2 * n_reads, n_ev).astype(np.int64)
+    prev, cur = S[:, :-1], S[:, 1:]
+    assert ((prev == cur) | ((prev & 1023) == (cur >> 2)) | ((prev & 255) == (cur >> 4))).all()
+    for r in (0, 511, 1023):
+        a, b = int(so[2 * r]), int(so[2 * r + 2])
+        so1 = (so[2 * r:2 * r + 3] - so[2 * r]).astype(np.uint64)
+        jr1, j01, j11 = api.train_enumerate(opts, strands, so1, np.ones(1, np.uint8))
+        one = gpu_ctx.basecall_reads(opts, states, so1, mean[a:b], stdv[a:b], start[a:b], jr1, j01, j11, out["pm"][2 * r:2 * r + 2], out["st"][2 * r:2 * r + 2])
+        assert np.array_equal(one["states"], bc["states"][a:b]) and one["best_logp"].tobytes() == bc["best_logp"][r:r + 1].tobytes()
+        assert one["best_job"][0, 0] == bc["best_job"][r, 0] - 2 * r
