@@ -155,7 +155,7 @@ def test_config4_shard_12500_reads_sub_batched(r73t):
         ctx.close()
 
 
-def test_config3_2d_reads_four_round_em_at_full_size(gpu_ctx):
+def test_config3_2d_reads_four_round_em_at_full_size():
     """BASELINE config 3 at the size tools/bench_config3.py times it: 1024 template+complement reads of 5000 events per strand,
     two candidate model pairs each, exactly four Parameter_Trainer rounds per pair (nanocall.cpp:360-426 with
     scaling_max_rounds 2, :420), then both strands of every pair decoded with its trained parameters and the better pair kept
@@ -166,6 +166,11 @@ def test_config3_2d_reads_four_round_em_at_full_size(gpu_ctx):
     graph; (5) the second call returns the same bits as the first."""
     from nanocall_amd import api
     from test_train_reads_gpu import reference_train_job
+    with na.Context(0) as ctx:        # (its own context: 2048 candidate tables go through the model slots)
+        _config3(ctx, api, reference_train_job)
+
+
+def _config3(gpu_ctx, api, reference_train_job):
     n_reads, n_ev = 1024, 5000
     names = ["r73.c.p1", "r73.c.p2", "r73.t"]           # sorted by name, like the reference's std::map
     strands = [1, 1, 0]
