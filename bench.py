@@ -242,6 +242,61 @@ def end_to_end_leg(ctx, off, cm, sd, ls, d_state, d_logp, reps):
             "identical_to_device_resident_run": True}
 
 
+def ragged_leg(ctx, table, reps=3):
+    """The headline's reads are all 5000 events long; real reads are log-normally long, and a read is sequential.  This leg
+    decodes 1024 reads with lengths lognormal(median 4000, sigma 0.7) clipped to [200, 30 000] (tools/bench_ragged.py's batch,
+    seeded) from host arrays: one synchronous call per batch (it lasts as long as its longest read: the plan takes the
+    one-read-per-CU form of the sweep, nchmm_plan.hpp) and a caller that streams batches, three in flight (the tail of one is
+    covered by the next).  Both results compared with each other; never the headline `value`."""
+    import torch
+    import nanocall_amd as na
+    from nanocall_amd import synth
+    R = 1024
+    rng = np.random.default_rng(20261002)
+    lens = np.clip(np.round(np.exp(rng.normal(np.log(4000.0), 0.7, R))), 200, 30000).astype(np.int64)
+    ev = synth.generate(table, R, int(lens.max()))
+    keep = np.arange(int(lens.max()))[None, :] < lens[:, None]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    cm, sd, ls = na.events_prepare(ev["mean"][keep], ev["stdv"][keep], ev["start"][keep], 0.0)
+    del ev, keep
+    total = int(off[-1])
+    ctx.use_own_stream()
+    try:
+        sw0 = ctx.sweep_stats()
+        st, lp, status = ctx.viterbi(off, cm, sd, ls)              # sizes the staging buffers
+        one = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            st, lp, status = ctx.viterbi(off, cm, sd, ls)
+            one.append(time.perf_counter() - t0)
+        k_ms = ctx.last_kernel_ms()[0]
+        sw1 = ctx.sweep_stats()
+        assert (status == 0).all()
+        depth, nb = 3, 9
+        best = 1e9
+        for _ in range(2):
+            tk = []
+            t0 = time.perf_counter()
+            for _b in range(nb):
+                if len(tk) == depth:
+                    ctx.viterbi_end(tk.pop(0))
+                tk.append(ctx.viterbi_begin(off, cm, sd, ls))
+            while len(tk) > 1:
+                ctx.viterbi_end(tk.pop(0))
+            st2, lp2, status2 = ctx.viterbi_end(tk.pop(0))
+            best = min(best, time.perf_counter() - t0)
+        assert np.array_equal(st[:total], st2[:total]) and lp[:R].tobytes() == lp2[:R].tobytes(), "streamed ragged batches decode differently"
+    finally:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    return {"workload": "1024 reads, lengths lognormal(median 4000, sigma 0.7) clipped to [200, 30000] events, host arrays in and out",
+            "events": total, "longest_read_events": int(lens.max()),
+            "one_call": {"value": round(total / min(one) / 1e6, 1), "unit": "Mevents/s", "ms_per_call": round(min(one) * 1e3, 2),
+                         "kernel_ms": round(k_ms, 2), "launches_wide_ll": [int(sw1[0] - sw0[0]) // (reps + 1), int(sw1[1] - sw0[1]) // (reps + 1)],
+                         "note": "bounded below by the longest read: one block, one event after the other"},
+            "streaming": {"value": round(nb * total / best / 1e6, 1), "unit": "Mevents/s", "batches": nb, "in_flight": depth},
+            "output_sha256_16": hashlib.sha256(np.ascontiguousarray(st[:total]).tobytes() + np.ascontiguousarray(lp[:R]).tobytes()).hexdigest()[:16]}
+
+
 def fwbw_leg(ctx, dev, steps):
     """The forward-backward + EM-statistics kernels on the BASELINE config-3 window shape: 1024 2D reads x
     (2 strands x 2 windows x 100 events) = 4096 windows, one pass ("event-round") per window, inputs resident."""
@@ -441,6 +496,7 @@ def main():
                          "every kernel's duration in the trace is its own")
     ap.add_argument("--events", type=int, default=5000, help="events per read")
     ap.add_argument("--model", default="r73.t")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the leg on log-normally long reads (one call / streaming, host arrays; --no-end-to-end skips it too)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwbw", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -759,6 +815,12 @@ def main():
             except Exception as e:      # a secondary leg must not cost the run its headline line
                 sys.stderr.write(f"bench.py: end-to-end leg failed: {e}\n")
                 result["end_to_end"] = {"error": str(e)}
+        if world == 1 and not args.no_ragged and not args.no_end_to_end and not args.serial_launches:     # (both host-pointer legs go together)
+            try:
+                result["ragged"] = ragged_leg(ctx, table)
+            except Exception as e:      # a secondary leg must not cost the run its headline line
+                sys.stderr.write(f"bench.py: ragged leg failed: {e}\n")
+                result["ragged"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and n_events <= 5000:
             logical, physical = physical_cores()
             threads = args.cpu_threads or max(1, min(physical, logical))      # T = physical cores

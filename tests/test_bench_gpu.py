@@ -53,7 +53,7 @@ def test_strong_scaling_splits_one_global_read_set(ranks):
     """--scaling strong: the SAME global read set at every N (BASELINE config 4 as written is 100 000 reads; 1 001 here,
     deliberately not divisible), split by lpt_partition -- the counters prove every read was decoded exactly once per step."""
     d = _bench(["--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--reads", "1001", "--events", "600", "--scaling", "strong",
-                "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end"])
+                "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end", "--no-ragged"])
     assert d["n_gpus"] == ranks and d["scaling"] == "strong"
     assert d["config"]["reads_total"] == 1001 and "1001 reads x 600 events in total" in d["config"]["workload"]
     assert d["counters"]["reads"] == 1001 * 3 and d["counters"]["events"] == 1001 * 600 * 3
@@ -86,12 +86,18 @@ def test_default_line_carries_every_object_of_the_contract():
     assert sl["launch_ms"]["min"] <= sl["launch_ms"]["median"] <= sl["launch_ms"]["max"] and sl["value"] > 0
     assert d["ranks_in_collective"] == 1 and "ranks" not in d
     assert sum(d["config"]["sweep_launches_wide_ll"]) > 0
+    # the realistic shape beside the headline: log-normally long reads, one call (the one-read-per-CU form, bounded by the longest
+    # read) and streamed (three batches in flight)
+    g = d["ragged"]
+    assert g["longest_read_events"] == 30000 and g["one_call"]["launches_wide_ll"][1] >= 1 and len(g["output_sha256_16"]) == 16
+    assert 0 < g["one_call"]["value"] < g["streaming"]["value"] < 1.2 * d["value"]
+    assert g["events"] / (g["one_call"]["ms_per_call"] * 1e3) == pytest.approx(g["one_call"]["value"], rel=0.01)
 
 
 def test_config2_line_carries_the_shard_of_a_scaling_series():
     """the driver's N = 1 command (config 2): `n1_same_shard` = the 12 500-read shard every rank of its N = 2 / 4 / 8 runs
     decodes, timed on this GPU the same way -- the like-for-like denominator of the weak-scaling ratio"""
-    d = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end"], env_extra={"NCHMM_BENCH_SHARE_GPU0": "0"})
+    d = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end", "--no-ragged"], env_extra={"NCHMM_BENCH_SHARE_GPU0": "0"})
     assert "config 2" in d["config"]["workload"] and d["config"]["sweep_launches_wide_ll"][1] == 0      # 1024 equal reads: the wide form
     s = d["n1_same_shard"]
     assert s["reads"] == 12500 and s["events_per_read"] == 5000 and s["steps"] == 2
@@ -126,7 +132,7 @@ def test_one_rank_under_the_launcher_goes_through_rccl():
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--reads", "300", "--events", "800", "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end", "--no-shard-leg"],
+                        "--reads", "300", "--events", "800", "--no-cpu-baseline", "--no-fwbw", "--no-end-to-end", "--no-shard-leg", "--no-ragged"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
