@@ -2,8 +2,8 @@
 // src/nanocall/Viterbi.hpp:44-99,120-142), gfx950: ONE read on a whole CU.
 //
 // Why a second form.  A read is sequential: viterbi_kernel.hip puts a read on 8 waves (8 states per thread) and two such blocks
-// on a CU, which is how a CU decodes the most events per second -- but every read then advances at 1.4-1.5 us per event whatever
-// else the GPU has to do.  A launch lasts as long as its longest read, a batch with fewer reads than block slots leaves
+// on a CU, which is how a CU decodes the most events per second -- but every read then advances at 1.5-1.6 us per event with a
+// neighbour on its CU and at 1.12-1.18 without, whatever else the GPU has to do.  A launch lasts as long as its longest read, a batch with fewer reads than block slots leaves
 // issue slots empty, and the reference's own call shape is one strand per call (nanocall.cpp:687-689, default -t 1, :93).  Here
 // the same column is spread over 16 waves, 4 states per thread, one block per CU: about half the time per event for one read, at
 // ~8 % fewer events per second and CU when every CU has two reads to work on.  Which form a launch takes is decided per launch by
