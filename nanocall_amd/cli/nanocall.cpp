@@ -1128,11 +1128,33 @@ static int real_main()
             check(nchmm_pool_reserve_fb_workspace(pool, files.size() / (size_t)use * 8 * (size_t)opts::scaling_num_events.get()), "nchmm_pool_reserve_fb_workspace");
         }
         if (opts::basecall && files.size() >= 512) {
-            // ... and the back-pointer regions for strands of up to 6000 events (16 GiB; they grow when longer strands come).  On a
-            // device nobody has used since it was brought up these allocations cost ~30 ms per GiB wherever they happen; here they
-            // happen while the summary pass is reading files
+            // ... and the back-pointer regions: for strands half as long again as the longest among the first thousand reads the
+            // summary pass delivers, at least 6000 events (16 GiB).  They grow when longer
+            // strands come -- but growing means freeing and allocating tens of GiB in the middle of the decode stage, which costs
+            // 0.5-1.4 s on a device that earlier processes have left memory to be reclaimed on (measured: a run on log-normally long
+            // reads behind five runs on 5000-event reads), so the estimate is taken from the data, not from a constant.  Here the
+            // allocation happens while the summary pass is still reading files.
             STAGE("reserve_workspace_s");
-            check(nchmm_pool_reserve_viterbi_workspace(pool, 6000), "nchmm_pool_reserve_viterbi_workspace");
+            size_t seen;
+            {
+                // (the first thousand summaries are there 0.1 s into the pass; the first chunk needs three times as many, so the
+                // wait is not on anybody's path)
+                const size_t enough = std::min<size_t>(files.size(), 1024);
+                std::unique_lock<std::mutex> lk(progress.m);
+                progress.cv.wait(lk, [&] { return progress.ready >= enough || progress.done; });
+                seen = progress.ready;
+            }
+            uint64_t longest_strand = 0;
+            for (size_t i = 0; i < seen; ++i) {        // (`reads` was sized up front and [0, ready) is final: safe beside the pass)
+                const Fast5_Summary_Type& r = reads[i];
+                if (!r.num_ed_events) continue;
+                longest_strand = std::max<uint64_t>(longest_strand, r.strand_bounds[1] - r.strand_bounds[0]);
+                if (r.strand_bounds[3] > r.strand_bounds[2]) longest_strand = std::max<uint64_t>(longest_strand, r.strand_bounds[3] - r.strand_bounds[2]);
+            }
+            size_t strand_events = (size_t)std::max<uint64_t>(6000, longest_strand + longest_strand / 2);
+            if (const char* e = std::getenv("NANOCALL_RESERVE_EVENTS")) strand_events = (size_t)std::atol(e);      // (measurement hook; 0: no reservation)
+            LOG(info) << "reserve_viterbi_workspace strand_events=" << strand_events << " (longest of the first " << seen << " reads: " << longest_strand << ")" << std::endl;
+            if (strand_events) check(nchmm_pool_reserve_viterbi_workspace(pool, strand_events), "nchmm_pool_reserve_viterbi_workspace");
         }
         return EXIT_SUCCESS;
     };
@@ -1170,6 +1192,21 @@ static int real_main()
             s.write_tsv(sfs);
             sfs << std::endl;
         }
+        sfs.close();
+        if (!sfs) { LOG(error) << "error writing stats file [" << opts::stats_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+    }
+    // Everything this run produces is written: close the output here and leave from HERE -- returning would first take down
+    // this function's locals (every read's summary and event vectors: a gigabyte in a few hundred thousand allocations for
+    // 8000 reads, 0.3 s of free() that buy nothing), then the GPU runtime and the worker threads' statics.
+    // (NANOCALL_FULL_EXIT=1: return and run every destructor, for leak checkers.)
+    if (ofs.is_open()) {
+        ofs.close();
+        if (!ofs) { LOG(error) << "error writing output [" << opts::output_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+    }
+    if (!std::getenv("NANOCALL_FULL_EXIT")) {
+        readers.finish();            // (the reader processes have served their last file: reaped here, not left to init)
+        std::cout.flush(); std::cerr.flush(); std::clog.flush();
+        std::_Exit(EXIT_SUCCESS);
     }
     return EXIT_SUCCESS;
 }
@@ -1269,9 +1306,7 @@ int main(int argc, char* argv[])
         LOG(error) << e.what() << std::endl;
         return EXIT_FAILURE;
     }
-    // Everything this run produced is written and closed, the devices are released (nchmm_pool_destroy).  What is left between
-    // here and the end of the process is tearing down the GPU runtime and the worker threads' statics -- 0.1-0.3 s that buy
-    // nothing: leave now.  (NANOCALL_FULL_EXIT=1: run the destructors, for leak checkers.)
+    // (a successful run has left from real_main already; what comes back here failed early or wants the full exit)
     std::cout.flush(); std::cerr.flush(); std::clog.flush();
     if (!std::getenv("NANOCALL_FULL_EXIT")) std::_Exit(rc);
     return rc;

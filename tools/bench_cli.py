@@ -62,13 +62,14 @@ try:
     stages = [l for l in p.stderr.splitlines() if "stage_wall_secs" in l][-1].split("stage_wall_secs")[1].split()
     stages = {t.split("=")[0]: round(float(t.split("=")[1]), 3) for t in stages}
     n_rec = sum(1 for l in open(out) if l.startswith(">"))
+    reserve = [l.split("reserve_viterbi_workspace", 1)[1].strip() for l in p.stderr.splitlines() if "reserve_viterbi_workspace" in l]
     ev_in = int(sum(int(lens[r % distinct]) for r in range(int(kv["reads"]))))
     print(json.dumps({"reads": int(kv["reads"]), "events_per_read": n_events, "ragged": ragged, "longest_read_events": int(lens.max()), "input_events": ev_in, "fasta_records": n_rec, "bases": int(kv["bases"]),
                       "wall_s": round(wall, 3), "training_s": float(kv["training_secs"]), "basecalling_s": float(kv["basecalling_secs"]),
                       "other_s_(summaries, event loading, FASTA)": round(wall - float(kv["training_secs"]) - float(kv["basecalling_secs"]), 3),
                       "reads_per_s": round(int(kv["reads"]) / wall, 1), "input_Mevents_per_s_end_to_end": round(ev_in / wall / 1e6, 2),
                       "events_decoded": int(kv["events_decoded"]), "decoded_Mevents_per_s_in_basecalling": round(int(kv["events_decoded"]) / float(kv["basecalling_secs"]) / 1e6, 1),
-                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages,
+                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages, "viterbi_workspace_reserved": reserve[-1] if reserve else None,
                       "cmd": " ".join(cmd[:1] + cmd[1:-1])}))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
