@@ -1040,8 +1040,15 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
     for (const std::exception_ptr& e : {device_error, prepare_error, finish_error}) if (e) std::rethrow_exception(e);
 }
 
+static double epoch_now()
+{
+    return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
 static int real_main()
 {
+    // (wall-clock marks for whoever times the process from outside: tools/bench_cli.py splits its wall into before / inside / after)
+    LOG(info) << "epoch_at_main=" << std::fixed << epoch_now() << std::endl;
     Stage_Clock::Scope* whole = new Stage_Clock::Scope(stage_clock, "main_total_s");
     Pore_Model_Dict_Type models;
     State_Transitions_Type default_transitions;
@@ -1203,6 +1210,15 @@ static int real_main()
         ofs.close();
         if (!ofs) { LOG(error) << "error writing output [" << opts::output_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
     }
+    {   // (what the kernel has to take down when this process leaves: resident, pinned and peak memory, threads)
+        std::ifstream st("/proc/self/status");
+        std::string line, keep;
+        while (std::getline(st, line))
+            for (const char* k : {"VmHWM:", "VmRSS:", "VmPin:", "VmLck:", "Threads:"})
+                if (line.compare(0, std::strlen(k), k) == 0) { for (char& ch : line) if (ch == '\t') ch = ' '; keep += " [" + line + "]"; }
+        LOG(info) << "memory_at_exit" << keep << std::endl;
+    }
+    LOG(info) << "epoch_at_exit=" << std::fixed << epoch_now() << std::endl;
     if (!std::getenv("NANOCALL_FULL_EXIT")) {
         readers.finish();            // (the reader processes have served their last file: reaped here, not left to init)
         std::cout.flush(); std::cerr.flush(); std::clog.flush();

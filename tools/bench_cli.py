@@ -52,8 +52,10 @@ try:
     out = os.path.join(tmp, "out.fa")
     cmd = [cli, "--pore", "r73", "-t", str(threads), "-o", out] + sys.argv[1:] + [d]
     t0 = time.perf_counter()
+    e0 = time.time()
     p = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.perf_counter() - t0
+    e1 = time.time()
     assert p.returncode == 0, p.stderr[-2000:]
     if os.environ.get("NCHMM_DEBUG"):
         sys.stderr.write("".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("[nchmm")))
@@ -62,6 +64,9 @@ try:
     stages = [l for l in p.stderr.splitlines() if "stage_wall_secs" in l][-1].split("stage_wall_secs")[1].split()
     stages = {t.split("=")[0]: round(float(t.split("=")[1]), 3) for t in stages}
     n_rec = sum(1 for l in open(out) if l.startswith(">"))
+    marks = {k: float(l.split(k + "=")[1].split()[0]) for l in p.stderr.splitlines() for k in ("epoch_at_main", "epoch_at_exit") if k + "=" in l}
+    outside = ({"spawn_to_main_s": round(marks["epoch_at_main"] - e0, 3), "exit_to_reaped_s": round(e1 - marks["epoch_at_exit"], 3)}
+               if len(marks) == 2 else None)
     reserve = [l.split("reserve_viterbi_workspace", 1)[1].strip() for l in p.stderr.splitlines() if "reserve_viterbi_workspace" in l]
     ev_in = int(sum(int(lens[r % distinct]) for r in range(int(kv["reads"]))))
     print(json.dumps({"reads": int(kv["reads"]), "events_per_read": n_events, "ragged": ragged, "longest_read_events": int(lens.max()), "input_events": ev_in, "fasta_records": n_rec, "bases": int(kv["bases"]),
@@ -69,7 +74,7 @@ try:
                       "other_s_(summaries, event loading, FASTA)": round(wall - float(kv["training_secs"]) - float(kv["basecalling_secs"]), 3),
                       "reads_per_s": round(int(kv["reads"]) / wall, 1), "input_Mevents_per_s_end_to_end": round(ev_in / wall / 1e6, 2),
                       "events_decoded": int(kv["events_decoded"]), "decoded_Mevents_per_s_in_basecalling": round(int(kv["events_decoded"]) / float(kv["basecalling_secs"]) / 1e6, 1),
-                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages, "viterbi_workspace_reserved": reserve[-1] if reserve else None,
+                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages, "viterbi_workspace_reserved": reserve[-1] if reserve else None, "outside_main": outside, "stderr_bytes": len(p.stderr), "memory_at_exit": ([l.split("memory_at_exit", 1)[1].strip() for l in p.stderr.splitlines() if "memory_at_exit" in l] or [None])[-1],
                       "cmd": " ".join(cmd[:1] + cmd[1:-1])}))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
