@@ -118,7 +118,7 @@ enum Sweep : int { kSweepAuto = 0, kSweepWide = 1, kSweepLl = 2, kSweepAhead = 3
 // (emission_kernel.hip): their columns carry the recurrence only.  us per event of a read: ahead; CU-us per event of the
 // emission kernel: em_cu (it runs on every CU at once, before the sweep: rows * em_cu / n_cu of wall time).
 struct SweepRates { double wide_shared = 1.55, wide_alone = 1.15, ll = 0.85, ahead = 0.60, em_cu = 0.85; double per_read_us = 60.0; };
-// A read whose emissions are ahead streams 16 KiB per event back in (~28 GB/s per block at 0.6 us per event).  Beyond ~100 such
+// A read whose emissions are ahead streams 16 KiB per event back in (27 GB/s per block at 0.6 us per event; 256 such streams are the device's whole bandwidth).  Beyond ~100 such
 // blocks at once the sweep is HBM-bound and slower than computing the emissions in place (256 x 5000 events: 4.85 ms against 4.23).
 constexpr size_t kMaxAheadReads = 96;
 
