@@ -90,7 +90,7 @@ def test_default_line_carries_every_object_of_the_contract():
     # read) and streamed (three batches in flight)
     g = d["ragged"]
     assert g["longest_read_events"] == 30000 and g["one_call"]["launches_wide_ll"][1] >= 1 and len(g["output_sha256_16"]) == 16
-    assert 0 < g["one_call"]["value"] < g["streaming"]["value"] < 1.2 * d["value"]
+    assert 0 < g["one_call"]["value"] < g["streaming"]["value"] < 1.5 * d["value"]      # (the headline here is a quarter-size batch)
     assert g["events"] / (g["one_call"]["ms_per_call"] * 1e3) == pytest.approx(g["one_call"]["value"], rel=0.01)
 
 
