@@ -633,9 +633,9 @@ int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count, size_t budg
 
 // rows (events) the buffer of emissions computed ahead may hold: NCHMM_EM_BUDGET_MB, default 256 MiB = 16 384 events -- what the
 // memory-side cache holds.  From there the recurrence-only column runs at its own pace, 0.59 us per event (a 5000-event strand:
-// 2.9 ms against 4.0 in the plain low-latency form; the same loop without any stream: 0.577); once the rows come from HBM the
-// stream through one CU sets it, 0.77-0.83 (8 x 30 000 events: 23.0 against 24.7 ms; 96 x 10 000: slower) -- not worth 16 KiB
-// per event.
+// 2.9 ms against 4.0 in the plain low-latency form; the same loop without any stream: 0.577); once the rows come from HBM a
+// column costs 0.77-0.83 whatever the prefetch schedule (8 x 30 000 events: 23.0 against 24.7 ms; 96 x 10 000: slower;
+// profiles/r05_fed_reads.md) -- not worth 16 KiB per event.
 uint64_t viterbi_em_budget_rows(nchmm_ctx* c)
 {
     if (c->em_budget == 0) {
