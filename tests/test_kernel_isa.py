@@ -167,7 +167,7 @@ def test_ll_columns_with_emissions_ahead_carry_the_recurrence_only(asm):
     assert best, "no eight-column loop with one row load per column found"
     assert not [x for x in best if x.startswith("scratch_") or "accvgpr" in x]
     assert sum(x.startswith(("v_fma_f32", "v_fmac_f32")) for x in best) <= 8 * 2 + 4, [x for x in best if x.startswith("v_fma")][:6]
-    assert sum(x.startswith("v_") for x in best) < 8 * 75          # 61 VALU per column today (127 with the emissions in place)
+    assert sum(x.startswith("v_") for x in best) < 8 * 75          # 61 VALU per column today (137.5 with the emissions in place)
     assert sum(x.startswith("global_store_dword") for x in best) == 8
 
 
