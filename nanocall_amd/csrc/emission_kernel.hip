@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kLlThreads) void emission_kernel(ViterbiArgs P, uns
         const unsigned n = (unsigned)(P.off[r + 1] - e0);
         if (blockIdx.x * kEmChunk >= n) continue;
         const uint64_t row0 = P.em_row0 ? P.em_row0[r] : e0;
-        if (row0 == kNoEmRow) continue;
+        if (row0 == kNoEmRow || row0 > P.em_rows || n > P.em_rows - row0) continue;   // (not ahead, or not inside the buffer: the sweep computes in place)
         const int ms = P.model_slot ? P.model_slot[r] : 0;
         const float* __restrict__ M = P.models + (size_t)ms * kModelFloats;
         const bool model_fast = P.model_fast[ms] != 0;

@@ -729,6 +729,7 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     a.launch_tag = c->launch_seq;
     a.tb_margin = c->tb_margin;
     a.em = em ? c->d_em : nullptr; a.em_row0 = em ? ahead->d_row0 : nullptr;
+    a.em_rows = em ? (uint64_t)(c->em_bytes / ((size_t)kStates * sizeof(float))) : 0;
     a.log_n_states = std::log(static_cast<float>(kStates));           // Viterbi.hpp:51
     a.log_2pi = static_cast<float>(std::log(2.0 * M_PI));
     // the wide sweep: two blocks per CU; the low-latency sweep: one
@@ -737,14 +738,14 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     a.queue_base = L.vq_base;
     if (after) HIP_TRY(c, hipStreamWaitEvent(L.stream, after, 0));
     if (serial_after) HIP_TRY(c, hipStreamWaitEvent(L.stream, serial_after, 0));
+    if (em && c->em_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->ev_em, 0));   // the buffer is one: behind the sweep that read it last
+    HIP_TRY(c, hipEventRecord(L.ev0, L.stream));      // (the launch's duration -- nchmm_last_kernel_ms -- includes its emission kernel)
     if (em) {
-        // the buffer is one: behind the sweep that read it last; then the emissions of the first ahead->n reads of the order, by
-        // every CU that is free (the device is this launch's: nothing else is in flight when a plan asks for them)
-        if (c->em_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->ev_em, 0));
+        // the emissions of the first ahead->n reads of the order, by every CU that is free (the device is this launch's: nothing
+        // else is in flight when a plan asks for them)
         launch_emissions(a, (unsigned)ahead->n, ahead->longest, c->d_em, L.stream);
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipEventRecord(L.ev0, L.stream));
     if (ll) launch_viterbi_ll(a, grid, L.stream); else launch_viterbi(a, grid, L.stream);
     HIP_TRY(c, hipGetLastError());
     if (em) { HIP_TRY(c, hipEventRecord(c->ev_em, L.stream)); c->em_pending = true; c->ahead_stats[0] += 1; c->ahead_stats[1] += ahead->n; c->ahead_stats[2] += ahead->rows; }
@@ -853,7 +854,10 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
     size_t budget = 0;
     if ((rc = viterbi_ws_budget(c, &budget))) return rc;
     const size_t pool = (size_t)kXcds * std::min<size_t>(c->slots_per_xcd, n_reads * kVitLanes);
-    const bool tight = !d_order && n_reads >= 8 && (size_t)max_events * kBpRowBytes > budget / pool;
+    // (a batch shape -- reads, longest -- whose plan found most reads to be long is not planned again: the plan costs every lane a
+    // wait and a read-back, and for uniformly long reads it changes nothing; such batches go the usual way, longest first)
+    const bool tight = !d_order && n_reads >= 8 && (size_t)max_events * kBpRowBytes > budget / pool &&
+                       !(c->tight_skip_reads == n_reads && c->tight_skip_longest == max_events);
     const bool ragged = !d_order && n_reads > 1 && total_events && (double)max_events * (double)n_reads > 1.25 * (double)total_events;
     auto plan_buffer = [&](int slot) -> int {           // [order n | outliers n] for lane `slot` (kVitLanes: the tight path's own)
         if (c->plan_cap[slot] >= 2 * n_reads) return NCHMM_OK;
@@ -892,11 +896,13 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
         if (n_in + n_out != n_reads || longest > max_events) return NCHMM_E_INVALID;      // (the offsets do not match what the caller stated)
         c->counters[0] += n_reads;
         c->counters[1] += total_events;
+        if (!(small_cap >= 256 && n_out * 8 <= n_reads)) { c->tight_skip_reads = n_reads; c->tight_skip_longest = max_events; }
         if (small_cap >= 256 && n_out * 8 <= n_reads && n_out > 0) {
             // a few long reads: the pool for the rest, regions of their own for them, one more launch beside the pooled one
             if ((rc = viterbi_ws_prepare(c, std::max<uint64_t>(longest_in, 1), std::max<size_t>(n_in, 1), budget - budget / 10 * 3))) return rc;
-            if ((rc = viterbi_big_prepare(c, longest, n_out, budget / 10 * 3))) return rc;
-            if (c->ws_pooled) {
+            // (no memory for regions of their own -- an earlier batch may hold the whole budget as the pool: everything the usual way)
+            const int rc_big = viterbi_big_prepare(c, longest, n_out, budget / 10 * 3);
+            if (rc_big == NCHMM_OK && c->ws_pooled) {
                 // (the outliers first: they are the longest reads of the batch and set its duration -- one per CU in the low-latency
                 // form while there are no more of them than CUs; every lane is idle here, so their blocks are placed before the
                 // pooled launch's)

@@ -64,6 +64,7 @@ struct ViterbiArgs {
     // em_row0[r] = kNoEmRow: the read computes its emissions itself.  em == nullptr: nobody's are ahead.
     const float* em;
     const uint64_t* em_row0;   // indexed by read; null with em != null: row of read r's event i = off[r] + i
+    uint64_t em_rows;          // rows the buffer at em holds: a read whose rows would not all lie inside computes its emissions itself
     int tb_margin;             // events a speculative traceback segment runs before its first owned event
     float log_n_states;        // std::log(4096.f) from the host libm (Viterbi.hpp:51)
     float log_2pi;             // (float)std::log(2.0 * M_PI) (Pore_Model.hpp:28,37)

@@ -349,8 +349,10 @@ __global__ __launch_bounds__(kLlThreads, 4) void viterbi_ll_kernel(ViterbiArgs P
         X.r1 = &sV1[0][v1_index(4u * ((t >> 2) + 64u * yy))];
         X.r2 = &sV2[0][v2_index((t >> 4) + 16u * yy)];
 
+        // (rows stated by the caller are taken only if all of them lie inside the buffer -- the same test as emission_kernel's:
+        // offsets that do not match the stated total cost the read its rows ahead, never an access outside the buffer)
         const uint64_t em_row = P.em ? (P.em_row0 ? P.em_row0[r] : e0) : kNoEmRow;
-        if (em_row != kNoEmRow) {
+        if (em_row != kNoEmRow && em_row <= P.em_rows && n <= P.em_rows - em_row) {
             // ---- the read's emissions are in memory (emission_kernel.hip ran in front of this launch): rows of 1024 float4, this
             // thread's at [tau].  Eight rows in flight per thread (16 KiB rows from HBM / L2: ~2 us away, a column takes ~0.45) ----
             typedef float f4v __attribute__((ext_vector_type(4)));
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(kLlThreads, 4) void viterbi_ll_kernel(ViterbiArgs P
                 if (u & 1) column_ahead<0>(S, X, ws + (uint64_t)(i + u) * kStates, tau, q[u]);
                 else column_ahead<1>(S, X, ws + (uint64_t)(i + u) * kStates, tau, q[u]);
             }
+            __syncthreads();   // the last column's exchange reads are done before sRed (= sV1[0]) is written below
         } else
         for (unsigned base = 0; base < n; base += kLlChunk) {
             // stage the next kLlChunk events: x, y, 3 log y, 1/y (one correctly rounded divide per event)

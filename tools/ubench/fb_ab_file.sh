@@ -3,6 +3,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 V=$(realpath "$1")
 cd $R/nanocall_amd/csrc
+# whatever ends this script (an error, an interrupt, a time limit): the tree's own object is rebuilt, never a variant's left behind
+trap 'rm -f fwbw_scaled_kernel.o; make -s > /dev/null 2>&1' EXIT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -fno-slp-vectorize"
 run() { (cd $R && for i in 1 2 3; do STEPS=20 python tools/bench_fwbw.py 2>/dev/null | python -c "
 import sys, json

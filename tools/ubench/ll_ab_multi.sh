@@ -3,6 +3,8 @@
 #   bash tools/ubench/ll_ab_multi.sh variant1.hip.txt [variant2 ...]      SHAPES / REPS as in tools/bench_sweeps.py; TESTS=1: parity tests per variant
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/nanocall_amd/csrc
+# whatever ends this script (an error, an interrupt, a time limit): the tree's own object is rebuilt, never a variant's left behind
+trap 'rm -f viterbi_ll_kernel.o; make -s > /dev/null 2>&1' EXIT
 FLAGS=$(make -s print-hipflags)
 export SHAPES=${SHAPES:-1:5000,256:5000,1024:5000}
 run() { (cd $R && python tools/bench_sweeps.py 2>/dev/null | python -c "

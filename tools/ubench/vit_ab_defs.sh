@@ -5,6 +5,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 REPS=${REPS:-3}
 cd $R/nanocall_amd/csrc
+# whatever ends this script (an error, an interrupt, a time limit): the tree's own object is rebuilt, never a variant's left behind
+trap 'rm -f viterbi_kernel.o; make -s > /dev/null 2>&1' EXIT
 FLAGS=$(make -s print-hipflags 2>/dev/null)
 [ -z "$FLAGS" ] && FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -fno-slp-vectorize"
 line() { python -c "

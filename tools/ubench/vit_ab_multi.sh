@@ -2,6 +2,8 @@
 # tests with TESTS=1), tree again.   bash tools/ubench/vit_ab_multi.sh <variant1.hip.txt> <variant2.hip.txt> ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/nanocall_amd/csrc
+# whatever ends this script (an error, an interrupt, a time limit): the tree's own object is rebuilt, never a variant's left behind
+trap 'rm -f viterbi_kernel.o; make -s > /dev/null 2>&1' EXIT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-result -fno-slp-vectorize"
 run() { (cd $R && for i in $(seq 1 ${RUNS:-2}); do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fwbw --no-end-to-end 2>/dev/null | python -c "
 import sys, json

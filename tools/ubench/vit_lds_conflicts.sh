@@ -4,6 +4,8 @@
 # different banks), same library otherwise, serialised config-2 launches.    bash tools/ubench/vit_lds_conflicts.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/nanocall_amd/csrc
+# whatever ends this script (an error, an interrupt, a time limit): the tree's own object is rebuilt, never a variant's left behind
+trap 'rm -f viterbi_kernel.o; make -s > /dev/null 2>&1' EXIT
 FLAGS=$(make -s print-hipflags)
 BENCH="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fwbw --no-end-to-end --serial-launches --no-shard-leg"
 pmc() {   # $1 = label
