@@ -76,6 +76,18 @@ def test_default_line_carries_every_object_of_the_contract():
     assert 0 < e["one_call"]["value"] < e["value"] * 1.05 and e["batches"] >= 5
     assert d["device"]["peak_mem_bytes"] > 0 and d["device"]["library_peak_bytes"] > 0 and len(d["output_sha256_16"]) == 16
     assert d["fwbw"]["roofline"]["frac"] > 0
+    # the FB leg's own baseline and parity (Forward_Backward.hpp:72-125 on the oracle, same windows, same run)
+    fc = d["fwbw"]["cpu_baseline"]
+    assert fc["parity_checked_windows"] >= 128 and fc["parity_max_rel"] <= 1e-4 and fc["cores"] == 8 and fc["value"] > 0 and fc["unit"] == "Mevent-rounds/s"
+    # config 3 end to end in the line: the 4-round EM over 2048 jobs, the decode of every candidate, the reference loop on the oracle beside it
+    c3 = d["config3"]
+    assert c3["jobs"] == 2048 and c3["em"]["value"] > 0 and c3["decode"]["value"] > 0 and c3["em_rounds_per_job"]["max"] <= 4
+    assert c3["cpu_baseline"]["parity_checked_jobs"] >= 32 and c3["cpu_baseline"]["parity_fit_max_rel"] <= 1e-4
+    assert c3["cpu_baseline"]["jobs_with_equal_round_count"] >= c3["cpu_baseline"]["parity_checked_jobs"] - 1
+    # the headline, clock-normalised, and its ratio to the CPU path of this run -- in front of the line, not in its tail
+    assert d["vs_baseline"] is None and d["vs_cpu_baseline"] == c["gpu_over_cpu"] > 1
+    assert d["cycles_per_block_event"] == d["cycles_per_event"]["timed_region"] == d["config"]["clock_normalised"]["cycles_per_block_event"]
+    assert 400 <= d["shader_clock_mhz"] <= 2600
     # comparability across boxes and legs: cycles per block-event and a clock sample per leg; the serial figure beside the
     # overlapping one; one output set per lane
     cy = d["cycles_per_event"]
@@ -92,6 +104,16 @@ def test_default_line_carries_every_object_of_the_contract():
     assert g["longest_read_events"] == 30000 and g["one_call"]["launches_wide_ll"][1] >= 1 and len(g["output_sha256_16"]) == 16
     assert 0 < g["one_call"]["value"] < g["streaming"]["value"] < 1.5 * d["value"]      # (the headline here is a quarter-size batch)
     assert g["events"] / (g["one_call"]["ms_per_call"] * 1e3) == pytest.approx(g["one_call"]["value"], rel=0.01)
+
+
+def test_config5_line_has_its_cpu_baseline_and_parity():
+    """BASELINE config 5's shape (r9.t, 50 000-event reads; eight of them here): `cpu_baseline` = the oracle on 8 reads on 8 threads
+    ("For the 50 k-event config: 8 reads"), every one compared bit for bit with the GPU's decode in the run."""
+    d = _bench(["--steps", "2", "--warmup", "1", "--model", "r9.t", "--events", "50000", "--reads", "8", "--no-fwbw", "--no-end-to-end", "--no-shard-leg"],
+               env_extra={"NCHMM_BENCH_SHARE_GPU0": "0"})
+    c = d["cpu_baseline"]
+    assert c["parity_checked_reads"] == 8 and c["cores"] == 8 and "8 reads x 50000 events" in c["sample"] and c["gpu_over_cpu"] > 1
+    assert d["config"]["events_per_read"] == 50000 and d["vs_cpu_baseline"] == c["gpu_over_cpu"]
 
 
 def test_config2_line_carries_the_shard_of_a_scaling_series():

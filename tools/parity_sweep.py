@@ -1,9 +1,21 @@
 #!/usr/bin/env python3
-"""Randomised bit-parity sweep of the Viterbi path against the CPU oracle: random builtin model, random (valid) scaling
-parameters and transition probabilities per configuration, ragged reads.  Every read must match the oracle's k-mer path
-and path log-probability bit for bit.   CONFIGS=40 READS=6 SWEEP=auto|wide|ll python tools/parity_sweep.py   (run on the GPU box;
-READS > the number of CUs makes the plan pick the wide form for some configurations)"""
+"""Randomised bit-parity sweep of the Viterbi path against the CPU oracle (run on the GPU box).
+
+Per configuration: a random builtin model, random (valid) scaling parameters and transition probabilities, READS ragged reads.
+Round 6: the events are no longer only draws from the model they are decoded with -- each read takes one of the kinds of
+tests/adversarial.py (model-matched, another builtin model's stream, uniform levels, constant runs of 50-500 events, 1 % spikes at
++-20 sigma, stdv log-uniform over [0.01, 50], stdv == 0, abasic stretches) and a length log-uniform over [1, LONGEST] -- and every
+configuration is decoded in EVERY form of the sweep named in FORMS (one context per form, the form forced with nchmm_set_sweep;
+"auto" = the plan's choice), each compared with the oracle's k-mer path and path log-probability bit for bit.  Per form the sweep
+also reports how often the two exactness branches of the kernels fired (nchmm_profile_ticks()[6..7]: group rescans, cells decided
+by the tie rule) -- the contract (Viterbi.hpp:79-89,125-132) rests on them.
+
+The inputs and the oracle's decode of a configuration are made by worker PROCESSES (they never touch the GPU); the parent decodes.
+
+  CONFIGS=500 READS=6 LONGEST=30000 FORMS=wide,ll,ahead WORKERS=48 OUT=gpurun_out/parity_sweep.json python tools/parity_sweep.py
+  KINDS=matched  LONGEST=2500 reproduces the round-5 sweep's distribution."""
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
@@ -11,45 +23,101 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import nanocall_amd as na                 # noqa: E402
-from nanocall_amd import models, synth    # noqa: E402
-import nc_oracle as oracle                # noqa: E402
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
-n_cfg, n_reads = int(os.environ.get("CONFIGS", 40)), int(os.environ.get("READS", 6))
-n_check = int(os.environ.get("CHECK_READS", n_reads))     # reads per configuration compared with the oracle (the first ones; all are decoded)
-rng = np.random.default_rng(int(os.environ.get("SEED", 20260101)))
-meta, tables = models._load()
-ctx = na.Context(0)
-ctx.set_sweep(os.environ.get("SWEEP", "auto"))     # auto | wide | ll: which form of the sweep is checked (nchmm_set_sweep)
-t0 = time.time()
-events = mismatches = 0
-for c in range(n_cfg):
+N_READS = int(os.environ.get("READS", 6))
+LONGEST = int(os.environ.get("LONGEST", 30000))
+SEED = int(os.environ.get("SEED", 20260606))
+KINDS = tuple(k for k in os.environ.get("KINDS", "").split(",") if k)
+
+
+def make_config(c):
+    """(worker process) inputs of configuration c and the oracle's decode of every read"""
+    import nanocall_amd as na
+    from nanocall_amd import models
+    import nc_oracle as oracle
+    import adversarial
+    kinds = KINDS or adversarial.KINDS
+    rng = np.random.default_rng([SEED, c])
+    meta, tables = models._load()
     m = int(rng.integers(len(tables)))
     table = tables[m]
     params = (float(rng.uniform(0.8, 1.2)), float(rng.uniform(-6, 6)), float(rng.uniform(-0.01, 0.01)),
               float(rng.uniform(0.7, 1.5)), float(rng.uniform(0.8, 1.25)), float(rng.uniform(0.5, 2.0)))
     p_skip, p_stay = float(rng.uniform(0.05, 0.4)), float(rng.uniform(0.05, 0.4))
-    lens = [int(x) for x in rng.integers(1, 2500, n_reads)]
-    ev = synth.generate(table, n_reads, max(lens), first_read=1000 * c)
-    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-    cat = lambda k: np.concatenate([ev[k][r, :n] for r, n in enumerate(lens)])
-    mean = cat("mean") * np.float32(params[0]) + np.float32(params[1])          # events that fit the scaled model
-    cm, sd, ls = na.events_prepare(mean, cat("stdv"), cat("start"), params[2])
-    ctx.put_model(0, na.scaled_model_table(table, params))
-    ctx.put_transitions(0, *na.transitions_fast(p_skip, p_stay))
-    states, logp, status = ctx.viterbi(off, cm, sd, ls)
+    lens = adversarial.log_uniform_lengths(rng, N_READS, LONGEST)
+    read_kinds = [kinds[int(rng.integers(len(kinds)))] for _ in lens]
+    other = tables[(m + 1 + int(rng.integers(len(tables) - 1))) % len(tables)]
+    cms, sds, lss = [], [], []
+    for r, (n, kind) in enumerate(zip(lens, read_kinds)):
+        mean, stdv, start = adversarial.events(kind, table, params, n, seed=1000 * c + r, other_table=other)
+        cm, sd, ls = na.events_prepare(mean, stdv, start, params[2])
+        cms.append(cm); sds.append(sd); lss.append(ls)
     om, ot = oracle.Model(table, params), oracle.Transitions(p_skip, p_stay)
-    for r, n in enumerate(lens[:n_check]):
-        a, b = int(off[r]), int(off[r + 1])
-        s, mv, lp = oracle.viterbi(om, ot, cm[a:b], sd[a:b], ls[a:b])
-        ok = status[r] == 0 and np.array_equal(s, states[a:b]) and np.float32(lp).tobytes() == np.float32(logp[r]).tobytes()
-        if not ok:
-            mismatches += 1
-            print(f"MISMATCH config {c} model {meta['names'][m]} params {params} trans {(p_skip, p_stay)} read {r} len {n}", flush=True)
-        events += n
-print(json.dumps({"configs": n_cfg, "reads_decoded": n_cfg * n_reads, "reads_checked": n_cfg * min(n_check, n_reads), "events": events, "mismatches": mismatches,
-                  "seconds": round(time.time() - t0, 1), "sweep": os.environ.get("SWEEP", "auto"),
-                  "launches_wide_ll_reads_wide_ll": list(ctx.sweep_stats())}))
-sys.exit(1 if mismatches else 0)
+    want = []
+    for cm, sd, ls in zip(cms, sds, lss):
+        s, mv, lp = oracle.viterbi(om, ot, cm, sd, ls)
+        want.append((s, np.float32(lp)))
+    return dict(c=c, model=m, name=meta["names"][m], params=params, trans=(p_skip, p_stay), lens=lens, kinds=read_kinds,
+                off=np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64), cm=np.concatenate(cms), sd=np.concatenate(sds),
+                ls=np.concatenate(lss), want=want)
+
+
+def main():
+    n_cfg = int(os.environ.get("CONFIGS", 40))
+    forms = [f for f in os.environ.get("FORMS", os.environ.get("SWEEP", "auto")).split(",") if f]
+    workers = int(os.environ.get("WORKERS", max(1, min(48, (os.cpu_count() or 2) // 2))))
+    t0 = time.time()
+    pool = mp.get_context("spawn").Pool(workers)          # before anything here touches the GPU; spawn: no forked HIP state either way
+    todo = pool.imap(make_config, range(n_cfg), chunksize=1)
+    import nanocall_amd as na
+    from nanocall_amd import models
+    meta, tables = models._load()
+    os.environ["NCHMM_PROFILE"] = "1"
+    ctxs = {}
+    for f in forms:
+        ctxs[f] = na.Context(0)
+        ctxs[f].set_sweep(f)
+    del os.environ["NCHMM_PROFILE"]
+    stats = {f: dict(mismatches=0, rescans=0, tie_rule_cells=0) for f in forms}
+    by_kind = {}
+    events = reads = longest_seen = 0
+    for cfg in todo:
+        table = tables[cfg["model"]]
+        for f in forms:
+            ctx = ctxs[f]
+            ctx.put_model(0, na.scaled_model_table(table, cfg["params"]))
+            ctx.put_transitions(0, *na.transitions_fast(*cfg["trans"]))
+            states, logp, status = ctx.viterbi(cfg["off"], cfg["cm"], cfg["sd"], cfg["ls"])
+            tk = ctx.profile_ticks()
+            stats[f]["rescans"] += int(tk[6]); stats[f]["tie_rule_cells"] += int(tk[7])
+            for r, (n, (s, lp)) in enumerate(zip(cfg["lens"], cfg["want"])):
+                a, b = int(cfg["off"][r]), int(cfg["off"][r + 1])
+                ok = status[r] == 0 and np.array_equal(s, states[a:b]) and np.float32(lp).tobytes() == np.float32(logp[r]).tobytes()
+                if not ok:
+                    stats[f]["mismatches"] += 1
+                    print(f"MISMATCH form {f} config {cfg['c']} model {cfg['name']} params {cfg['params']} trans {cfg['trans']} read {r} "
+                          f"kind {cfg['kinds'][r]} len {n}", flush=True)
+        for n, k in zip(cfg["lens"], cfg["kinds"]):
+            by_kind[k] = by_kind.get(k, 0) + 1
+            events += n; reads += 1; longest_seen = max(longest_seen, n)
+    pool.close(); pool.join()
+    out = {"configs": n_cfg, "reads_per_config": N_READS, "reads_checked_per_form": reads, "events_per_form": events, "longest_read": longest_seen,
+           "length_distribution": f"log-uniform over [1, {LONGEST}]", "reads_by_kind": by_kind, "forms": stats,
+           "launches_wide_ll_reads_wide_ll": {f: list(ctxs[f].sweep_stats()) for f in forms},
+           "ahead_launches_reads_events": {f: list(ctxs[f].ahead_stats()) for f in forms},
+           "mismatches": sum(s["mismatches"] for s in stats.values()), "seed": SEED, "oracle_workers": workers, "seconds": round(time.time() - t0, 1)}
+    for ctx in ctxs.values():
+        ctx.close()
+    line = json.dumps(out)
+    print(line)
+    if os.environ.get("OUT"):
+        with open(os.environ["OUT"], "w") as fh:
+            fh.write(line + "\n")
+    return 1 if out["mismatches"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
