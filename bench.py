@@ -389,8 +389,9 @@ def fwbw_leg(ctx, dev, steps, cpu_threads=0, with_cpu=True):
     base = None
     if with_cpu:
         logical, physical = physical_cores()
-        threads = cpu_threads or max(1, min(physical, logical))
-        base = fwbw_cpu_baseline((t0, t1), off, cm, sd, ls, strand, lpd, threads, max(128, 2 * threads))
+        # bounded sample: 128 windows, two per thread on 64 threads (~10 s of wall; with every core busy a window takes 10 x as long)
+        threads = cpu_threads or max(1, min(physical, logical, 64))
+        base = fwbw_cpu_baseline((t0, t1), off, cm, sd, ls, strand, lpd, threads, 128)
         base["gpu_over_cpu"] = round(total * steps / dt / 1e6 / base["value"], 1)
     return {"metric": "FB + EM-statistics event-rounds/s", "value": round(total * steps / dt / 1e6, 3), "unit": "Mevent-rounds/s",
             "workload": "4096 windows x 100 events (config-3 shape: 1024 2D reads x 2 strands x 2 windows), r73.t / r73.c.p1",
@@ -492,8 +493,10 @@ def config3_leg(ctx, host_threads, cpu_threads, with_cpu, n_reads=1024, n_ev=500
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nc_oracle as oracle
         logical, physical = physical_cores()
-        threads = cpu_threads or max(1, min(physical, logical))
-        pick = np.unique(np.linspace(0, nj - 1, max(32, min(threads, 128))).astype(np.int64))
+        # bounded sample: 16 jobs on 16 threads -- a job is 4 rounds x 4 windows of the oracle's forward-backward (~0.5 s per window on
+        # an idle host, 6 s with 128 of them running at once: the port allocates per cell like the reference's logsumset): ~15 s of wall
+        threads = cpu_threads or max(1, min(physical, logical, 16))
+        pick = np.unique(np.linspace(0, nj - 1, max(16, threads)).astype(np.int64))
         got = [None] * len(pick)
 
         def work(tid):

@@ -594,6 +594,21 @@ int nchmm_pool_reserve_viterbi_workspace(nchmm_pool* pool, size_t longest_events
  * thread while nchmm_pool_counters runs (the command line calls it once, after its last record is flushed). */
 int nchmm_pool_counters(nchmm_pool* pool, uint64_t out[8], int* used_rccl);
 
+/* One PROCESS per GPU (what `nanocall --gpus N` starts: the reference's unit of parallelism is a pfor worker inside one
+ * process, nanocall.cpp:282,611; here a worker process per device, started before anything touches the HIP runtime).  The only
+ * exchange between the workers is the same counter reduction, as one RCCL all-reduce across processes:
+ *   nchmm_rccl_unique_id        rank 0 makes the communicator's id (ncclGetUniqueId; 128 bytes) and hands it to the others by any
+ *                               means (the command line: over its pipes, through the parent)
+ *   nchmm_counters_allreduce    every rank, with that id: ncclCommInitRank(n_ranks, id, rank) on `device_id` (the rank's own
+ *                               device, as ITS process numbers it), one ncclAllReduce(sum) of the eight counters in place, the
+ *                               communicator destroyed again.  All ranks must call it; their devices must be distinct.
+ * NCHMM_E_NO_DEVICE when librccl (NCHMM_RCCL_LIB) cannot be loaded or lacks an entry point, NCHMM_E_HIP when RCCL or HIP
+ * fails (nchmm_last_hip_error is not set: no context is involved) -- the caller then sums on the host, as nchmm_pool_counters
+ * does.  n_ranks = 1 is allowed (a communicator of one: the whole call sequence on a machine with one GPU). */
+#define NCHMM_RCCL_ID_BYTES 128
+int nchmm_rccl_unique_id(uint8_t id[NCHMM_RCCL_ID_BYTES]);
+int nchmm_counters_allreduce(int device_id, int n_ranks, int rank, const uint8_t id[NCHMM_RCCL_ID_BYTES], uint64_t inout[8]);
+
 #ifdef __cplusplus
 }
 #endif

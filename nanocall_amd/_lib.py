@@ -105,6 +105,8 @@ SIGNATURES = {
     "nchmm_pool_train_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 8),
     "nchmm_pool_basecall_reads": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t] + [vp] * 9),
     "nchmm_pool_counters": (C.c_int, [vp, vp, vp]),
+    "nchmm_rccl_unique_id": (C.c_int, [vp]),
+    "nchmm_counters_allreduce": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp]),
 }
 
 

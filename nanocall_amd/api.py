@@ -629,6 +629,22 @@ def device_count():
     return n.value
 
 
+def rccl_unique_id():
+    """nchmm_rccl_unique_id -> 128 bytes (rank 0 of a one-process-per-GPU run makes it, the others receive it)"""
+    b = np.zeros(128, np.uint8)
+    check(lib().nchmm_rccl_unique_id(_p(b)), "nchmm_rccl_unique_id")
+    return b
+
+
+def counters_allreduce(device_id, n_ranks, rank, unique_id, counters8):
+    """nchmm_counters_allreduce: ncclCommInitRank + one all-reduce (sum) of eight uint64 across the ranks -> the sums"""
+    c = np.ascontiguousarray(counters8, np.uint64).copy()
+    assert c.shape == (8,)
+    check(lib().nchmm_counters_allreduce(int(device_id), int(n_ranks), int(rank), _p(np.ascontiguousarray(unique_id, np.uint8)), _p(c)),
+          "nchmm_counters_allreduce")
+    return c
+
+
 def device_mem_info(device_id=0):
     """nchmm_device_mem_info -> (free, total) bytes of one GPU, through the library's own HIP runtime."""
     f, t = C.c_uint64(0), C.c_uint64(0)

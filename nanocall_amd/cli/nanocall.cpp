@@ -10,6 +10,14 @@
 // Not provided (fails with a message): --write-fast5 (HDF5 write-back), -s/--trans (the device tables, and the
 // transition statistics of the EM rounds, are built from (pr_skip, pr_stay)).
 // Extra options: --gpus N (devices to use, default all), --chunk-events N (events decoded per batch and device).
+//
+// More than one GPU: ONE WORKER PROCESS PER GPU (fan_out below).  The reference's unit of parallelism is a pfor worker inside one
+// process (:282,611); one process cannot feed eight MI355X (its host stages -- summaries, event loading and packing, FASTA -- keep up
+// with two or three), so the input files are partitioned over N children forked BEFORE anything in this process or in a child has
+// touched the HIP runtime; each child runs the whole pipeline on its share with its own reader processes, host threads and one
+// device, and streams its records, tagged with the input index, up a pipe; the parent writes them in input order (:859-861).
+// The only exchange between the workers is the counter reduction: one RCCL all-reduce across the processes (ncclCommInitRank, the
+// unique id relayed over the pipes), with the host sum as the fall-back.  --single-process keeps every GPU in this process.
 #include <dirent.h>
 #include <fcntl.h>
 #include <signal.h>
@@ -24,12 +32,14 @@
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
+#include <cstring>
 #include <deque>
 #include <exception>
 #include <fstream>
 #include <iostream>
 #include <list>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <string>
 
@@ -60,11 +70,13 @@ enum level { error = 0, warning, info, debug, debug1, debug2 };
 inline int& threshold() { static int t = info; return t; }
 inline std::mutex& mutex() { static std::mutex m; return m; }
 inline const char* name(int l) { static const char* n[] = {"error", "warning", "info", "debug", "debug1", "debug2"}; return n[std::min(l, 5)]; }
+inline std::string& tag() { static std::string t; return t; }      // "[w3] " in worker process 3 of a multi-GPU run
 struct Line {
     std::ostringstream os;
     int lvl;
-    explicit Line(int l) : lvl(l) { os << "= nanocall " << name(l) << ": "; }
-    ~Line() { std::lock_guard<std::mutex> g(mutex()); std::clog << os.str(); }
+    explicit Line(int l) : lvl(l) { os << "= nanocall " << tag() << name(l) << ": "; }
+    // (one write per line: the worker processes of a multi-GPU run share this stream)
+    ~Line() { std::lock_guard<std::mutex> g(mutex()); const std::string t = os.str(); std::clog.write(t.data(), (std::streamsize)t.size()); std::clog.flush(); }
 };
 inline int parse_level(const std::string& s)
 {
@@ -176,10 +188,11 @@ SwitchArg write_fast5("", "write-fast5", "Write basecalls to fast5 files.");
 ValueArg<std::string> output_fn("o", "output", "Output.", false, "", "file");
 ValueArg<unsigned> num_threads("t", "threads", "Number of parallel threads.", false, 1, "int");
 // MI355X additions
-ValueArg<int> gpus("", "gpus", "Number of GPUs to shard the reads over. (default: all visible)", false, 0, "int");
+ValueArg<int> gpus("", "gpus", "Number of GPUs to shard the reads over, one worker process each. (default: all visible)", false, 0, "int");
 ValueArg<unsigned long> chunk_events("", "chunk-events", "Events decoded per batch and GPU.", false, 32000000ul, "int");
 ValueArg<unsigned long> ed_cache_mb("", "ed-cache-mb", "Memory (MiB) in which event tables read by the summary pass are kept for the basecalling pass instead of re-reading the files.", false, 4096ul, "int");
 ValueArg<int> reader_procs("", "reader-procs", "Processes that read the input files (HDF5 serialises its calls inside one process). 0: read in this process. (default: min(threads, 16))", false, -1, "int");
+SwitchArg single_process("", "single-process", "Drive every GPU from this process (one host thread per GPU) instead of starting one worker process per GPU.");
 SwitchArg serial_chunks("", "serial-chunks", "Take one chunk of reads at a time through event loading, the GPUs and FASTA writing instead of running the three side by side on consecutive chunks.");
 ValueArg<std::string> dump_params_fn("", "dump-params", "Write the exact (hex float) parameters and path log-probability of every basecalled strand.", false, "", "file");
 std::vector<std::string> input_fn;   // UnlabeledMultiArg "inputs"
@@ -610,6 +623,68 @@ private:
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// One worker process per GPU: the link between a worker and the parent.  Frames {type, index, two payload lengths} + payloads
+// travel up the worker's data pipe; the parent answers once, on the control pipe, before the counter reduction.
+//   'R' index = input index of a read, payloads = its FASTA records, its --dump-params rows   (EVERY read of the share, ascending)
+//   'S' index = input index, payload = the read's --stats row                                    (every read, after the last 'R')
+//   'U' payload = the RCCL unique id (rank 0 only, when the reduction goes through RCCL; empty: could not make one)
+//   'C' payload = 4 host counters + 8 device counters of this worker (uint64); then the worker waits for the parent's verdict:
+//       one byte (1: all-reduce with the id that follows, 128 bytes; 0: the parent sums)
+//   'G' payload = 1 byte (the all-reduce succeeded) + the 8 reduced counters + this worker's stage clock as text
+//   'E' the worker is done; anything else at the end of the stream means it died
+// ---------------------------------------------------------------------------------------------------------------
+struct Frame_Header { uint8_t type; uint8_t pad[7]; uint64_t index, len_a, len_b; };
+
+static bool fd_read_all(int fd, void* p, size_t n)
+{
+    char* c = static_cast<char*>(p);
+    while (n) {
+        const ssize_t r = read(fd, c, n);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;
+        c += r; n -= (size_t)r;
+    }
+    return true;
+}
+static bool fd_write_all(int fd, const void* p, size_t n)
+{
+    const char* c = static_cast<const char*>(p);
+    while (n) {
+        const ssize_t r = write(fd, c, n);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;
+        c += r; n -= (size_t)r;
+    }
+    return true;
+}
+
+struct Worker_Link {
+    int rank = 0, n_ranks = 1, device = 0;
+    int data_fd = -1, ctl_fd = -1;
+    bool use_rccl = false;
+    std::vector<size_t> global_index;      // of the worker's reads, ascending
+    size_t next_emit = 0;                  // reads [0, next_emit) of the share have had their 'R' frame
+    std::mutex m;
+
+    void send(uint8_t type, uint64_t index, const std::string& a, const std::string& b = std::string())
+    {
+        Frame_Header h{};
+        h.type = type; h.index = index; h.len_a = a.size(); h.len_b = b.size();
+        std::lock_guard<std::mutex> g(m);
+        // (the parent gone: nothing to write for any more -- leave at once, without the destructors of a process that holds a GPU)
+        if (!fd_write_all(data_fd, &h, sizeof(h)) || !fd_write_all(data_fd, a.data(), a.size()) || !fd_write_all(data_fd, b.data(), b.size())) std::_Exit(EXIT_FAILURE);
+    }
+    // the record of local read j; reads the pipeline skipped on the way (no events, no candidate) get their empty frame first
+    void emit(size_t j, const std::string& fasta, const std::string& dump)
+    {
+        for (; next_emit < j; ++next_emit) send('R', global_index[next_emit], std::string());
+        send('R', global_index[j], fasta, dump);
+        next_emit = j + 1;
+    }
+    void emit_rest() { for (; next_emit < global_index.size(); ++next_emit) send('R', global_index[next_emit], std::string()); }
+};
+
 // how far the summary pass has got: reads [0, ready) are summarised (the decode loop runs behind it)
 struct Read_Progress {
     std::mutex m;
@@ -761,10 +836,12 @@ private:
 //   finish    base sequences, FASTA records in input order, parameter dump, drop the events                  -- host threads
 // so that the GPUs decode chunk k while chunk k + 1 is being packed and chunk k - 1 is being written.
 static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, std::deque<Fast5_Summary_Type>& reads, std::ostream* os_p,
-                          uint64_t counters[4], Read_Progress& progress)
+                          uint64_t counters[4], Read_Progress& progress, Worker_Link* link)
 {
+    // (a worker process hands its records and dump rows to the parent, which owns the output files)
+    const bool want_dump = !opts::dump_params_fn.get().empty();
     std::ofstream dump;
-    if (!opts::dump_params_fn.get().empty()) {
+    if (want_dump && !link) {
         dump.open(opts::dump_params_fn.get());
         dump << "#read_id\tstrand\tmodel\tscale\tshift\tdrift\tvar\tscale_sd\tvar_sd\tp_stay\tp_skip\tlog_path_prob\trounds\tfit" << std::endl;
         dump << std::hexfloat;
@@ -989,7 +1066,7 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
                     std::ostringstream nm;
                     nm << r.read_id << ":" << r.base_file_name << ":" << st;
                     write_fasta(oss, nm.str(), seq);
-                    if (dump.is_open()) {
+                    if (want_dump) {
                         std::ostringstream d;
                         d << std::hexfloat << r.read_id << '\t' << st << '\t' << key[st] << '\t' << best_pm.scale << '\t' << best_pm.shift << '\t' << best_pm.drift
                           << '\t' << best_pm.var << '\t' << best_pm.scale_sd << '\t' << best_pm.var_sd << '\t' << best_st.p_stay << '\t' << best_st.p_skip << '\t'
@@ -1000,8 +1077,11 @@ static void process_reads(nchmm_pool* pool, const Pore_Model_Dict_Type& models, 
                 record[i] = oss.str();
             });
             for (size_t i = 0; i < nr; ++i) {
-                *os_p << record[i];
-                if (dump.is_open()) dump << dump_rec[i];
+                if (link) link->emit(idx[i], record[i], dump_rec[i]);
+                else {
+                    *os_p << record[i];
+                    if (dump.is_open()) dump << dump_rec[i];
+                }
                 bool header = false;
                 for (char c : record[i]) {   // bases = sequence characters (header lines excluded)
                     if (c == '>') header = true;
@@ -1054,18 +1134,12 @@ static double epoch_now()
     return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
-static int real_main()
+// The whole pipeline over `files` in this process: reader processes, summary pass, devices, training, basecalling, output.
+// link == nullptr: the run is this process (output, --stats and --dump-params files written here, every device of the run in the
+// pool).  link != nullptr: a worker process of a multi-GPU run -- one device, records / stats rows / counters go to the parent.
+static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, Stage_Clock::Scope* whole, Worker_Link* link)
 {
-    // (wall-clock marks for whoever times the process from outside: tools/bench_cli.py splits its wall into before / inside / after)
-    LOG(info) << "epoch_at_main=" << std::fixed << epoch_now() << std::endl;
-    Stage_Clock::Scope* whole = new Stage_Clock::Scope(stage_clock, "main_total_s");
-    Pore_Model_Dict_Type models;
-    State_Transitions_Type default_transitions;
     std::deque<Fast5_Summary_Type> reads;
-    std::list<std::string> files;
-    { STAGE("init_models_s"); init_models(models); }
-    init_transitions(default_transitions);
-    { STAGE("init_files_s"); init_files(files); }
     // reader processes: forked here, while this process is still single-threaded and has not touched the GPU
     Reader_Procs readers;
     {
@@ -1084,7 +1158,7 @@ static int real_main()
     }
     std::ofstream ofs;
     std::ostream* os_p = &std::cout;
-    if (!opts::output_fn.get().empty()) {
+    if (!link && !opts::output_fn.get().empty()) {
         ofs.open(opts::output_fn.get());
         if (!ofs) { LOG(error) << "cannot open output [" << opts::output_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
         os_p = &ofs;
@@ -1098,8 +1172,9 @@ static int real_main()
         LOG(error) << "no usable GPU: this build of nanocall decodes on MI355X only (there is no CPU path)" << std::endl;
         return EXIT_FAILURE;
     }
-    use = opts::gpus.get() > 0 ? opts::gpus.get() : n_dev;
+    use = link ? 1 : (opts::gpus.get() > 0 ? opts::gpus.get() : n_dev);
     if (use > n_dev) { LOG(error) << "--gpus " << use << " requested but only " << n_dev << " visible" << std::endl; return EXIT_FAILURE; }
+    if (link && link->device >= n_dev) { LOG(error) << "worker " << link->rank << ": no device " << link->device << " (" << n_dev << " visible)" << std::endl; return EXIT_FAILURE; }
     // the summary pass (init_reads) runs on its own threads -- from here on, i.e. while the devices are being initialised below
     // (0.05-0.2 s: runtime start-up, contexts, streams) -- and the decode loop follows it block by block
     reads.resize(files.size());
@@ -1128,7 +1203,8 @@ static int real_main()
         setenv("NCHMM_WS_BUDGET_MB", "32768", 0);
         setenv("NCHMM_FB_BUDGET_MB", "16384", 0);
         std::vector<int> ids;
-        if (const char* e = std::getenv("NANOCALL_DEVICE_IDS")) {   // e.g. "0,0": several contexts on one GPU (test hook)
+        if (link) ids.push_back(link->device);
+        else if (const char* e = std::getenv("NANOCALL_DEVICE_IDS")) {   // e.g. "0,0": several contexts on one GPU (test hook)
             std::istringstream is(e);
             std::string tok;
             while (std::getline(is, tok, ',')) ids.push_back(std::atoi(tok.c_str()));
@@ -1182,7 +1258,7 @@ static int real_main()
         throw;
     }
     try {
-        if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters, progress); }
+        if (opts::train || opts::basecall) { STAGE("process_reads_s"); process_reads(pool, models, reads, os_p, counters, progress, link); }
     } catch (...) {
         summary_pass.join();
         throw;
@@ -1192,6 +1268,46 @@ static int real_main()
     os_p->flush();
     uint64_t dev[8];
     int used_rccl = 0;
+    if (link) {
+        // ---- a worker: the rest of its records, its --stats rows, its counters; then the reduction with the other workers ----
+        link->emit_rest();
+        if (!opts::stats_fn.get().empty())
+            for (size_t j = 0; j < reads.size(); ++j) {
+                std::ostringstream row;
+                reads[j].write_tsv(row);
+                link->send('S', link->global_index[j], row.str());
+            }
+        unsetenv("NCHMM_POOL_FORCE_RCCL");          // (this worker's own figures: a plain read-out; the reduction is across the workers)
+        check(nchmm_pool_counters(pool, dev, nullptr), "nchmm_pool_counters");
+        if (link->use_rccl && link->rank == 0) {
+            uint8_t id[NCHMM_RCCL_ID_BYTES];
+            const bool have = nchmm_rccl_unique_id(id) == NCHMM_OK;
+            link->send('U', 0, have ? std::string(reinterpret_cast<const char*>(id), sizeof(id)) : std::string());
+        }
+        uint64_t mine[12] = {counters[0], counters[1], counters[2], counters[3]};
+        std::copy(dev, dev + 8, mine + 4);
+        link->send('C', 0, std::string(reinterpret_cast<const char*>(mine), sizeof(mine)));
+        uint8_t go = 0, id[NCHMM_RCCL_ID_BYTES];
+        if (!fd_read_all(link->ctl_fd, &go, 1) || (go && !fd_read_all(link->ctl_fd, id, sizeof(id)))) std::_Exit(EXIT_FAILURE);      // the parent is gone
+        uint64_t red[8];
+        std::copy(dev, dev + 8, red);
+        if (go) {
+            STAGE("counter_allreduce_s");
+            used_rccl = nchmm_counters_allreduce(link->device, link->n_ranks, link->rank, id, red) == NCHMM_OK;
+        }
+        LOG(info) << "worker_counters reads=" << counters[0] << " bases=" << counters[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
+                  << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " training_secs=" << counters[2] / 1e6 << " basecalling_secs=" << counters[3] / 1e6 << std::endl;
+        { STAGE("device_release_s"); nchmm_pool_destroy(pool); }
+        delete whole;
+        LOG(info) << "worker_stage_wall_secs" << stage_clock.str() << std::endl;
+        std::string g(1, used_rccl ? '\1' : '\0');
+        g.append(reinterpret_cast<const char*>(red), sizeof(red));
+        link->send('G', 0, g, stage_clock.str());
+        link->send('E', 0, std::string());
+        readers.finish();
+        std::cout.flush(); std::cerr.flush(); std::clog.flush();
+        std::_Exit(EXIT_SUCCESS);
+    }
     check(nchmm_pool_counters(pool, dev, &used_rccl), "nchmm_pool_counters");
     LOG(info) << "counters reads=" << counters[0] << " bases=" << counters[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
               << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " gathered_by=" << (used_rccl ? "rccl_allreduce" : "host_sum")
@@ -1234,6 +1350,323 @@ static int real_main()
         std::_Exit(EXIT_SUCCESS);
     }
     return EXIT_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One worker process per GPU
+// ---------------------------------------------------------------------------------------------------------------
+// How many devices a process of this environment would see -- asked by a short-lived child, so that THIS process has not touched
+// the HIP runtime when it forks its workers (and never does: the parent of a multi-GPU run only moves bytes).
+struct Device_Probe {
+    pid_t pid = -1;
+    int fd = -1;
+    void start()
+    {
+        int p[2];
+        if (pipe(p) != 0) return;
+        std::cout.flush(); std::clog.flush();
+        pid = fork();
+        if (pid < 0) { close(p[0]); close(p[1]); return; }
+        if (pid == 0) {
+            close(p[0]);
+            int n = 0;
+            if (nchmm_device_count(&n) != NCHMM_OK) n = 0;
+            (void)fd_write_all(p[1], &n, sizeof(n));
+            _exit(0);
+        }
+        close(p[1]);
+        fd = p[0];
+    }
+    int finish()      // the count; -1: could not ask
+    {
+        if (pid < 0) return -1;
+        int n = -1;
+        if (!fd_read_all(fd, &n, sizeof(n))) n = -1;
+        close(fd);
+        int st = 0;
+        while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+        pid = -1;
+        return n;
+    }
+};
+
+// frames of one worker, taken off its pipe by a thread of the parent as they come (a worker never waits for the merge)
+struct Worker_Stream {
+    pid_t pid = -1;
+    int data_fd = -1, ctl_fd = -1, device = 0;
+    size_t n_reads = 0;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    struct Frame { uint8_t type; uint64_t index; std::string a, b; };
+    std::deque<Frame> q;
+    bool eof = false;            // the pipe has ended (after 'E': normally; before: the worker died)
+
+    void pump()
+    {
+        for (;;) {
+            Frame_Header h;
+            Frame f;
+            bool ok = fd_read_all(data_fd, &h, sizeof(h));
+            if (ok) { f.type = h.type; f.index = h.index; f.a.resize(h.len_a); f.b.resize(h.len_b); }
+            ok = ok && (!h.len_a || fd_read_all(data_fd, &f.a[0], h.len_a)) && (!h.len_b || fd_read_all(data_fd, &f.b[0], h.len_b));
+            std::lock_guard<std::mutex> g(m);
+            if (!ok) { eof = true; cv.notify_all(); return; }
+            const bool last = f.type == 'E';
+            q.push_back(std::move(f));
+            if (last) eof = true;
+            cv.notify_all();
+            if (last) return;
+        }
+    }
+    // the next frame; false: the stream ended without one (or nothing came within `timeout_s`, when that is >= 0)
+    bool next(Frame& f, double timeout_s = -1.0)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        auto ready = [&] { return !q.empty() || eof; };
+        if (timeout_s < 0) cv.wait(lk, ready);
+        else if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), ready)) return false;
+        if (q.empty()) return false;
+        f = std::move(q.front());
+        q.pop_front();
+        return true;
+    }
+};
+
+// `devices[k]` = the device of worker k (as every process of this environment numbers them).  The files are partitioned by size
+// (a FAST5 file is its EventDetection table and little else: bytes stand for events until a summary pass has run, and that pass
+// is the workers' own), longest-processing-time first -- nchmm_lpt_partition, the rule the in-process pool and bench.py use.
+static int fan_out(const Pore_Model_Dict_Type& models, const std::list<std::string>& files, const std::vector<int>& devices, Stage_Clock::Scope* whole)
+{
+    const std::vector<std::string> fv(files.begin(), files.end());
+    const size_t n = fv.size();
+    const int W = (int)devices.size();
+    std::vector<uint64_t> weight(n, 1);
+    for (size_t i = 0; i < n; ++i) {
+        struct stat sb;
+        if (stat(fv[i].c_str(), &sb) == 0 && sb.st_size > 0) weight[i] = (uint64_t)sb.st_size;
+    }
+    std::vector<int32_t> owner(n, 0);
+    check(nchmm_lpt_partition(n, weight.data(), W, owner.data()), "nchmm_lpt_partition");
+    const bool distinct = std::set<int>(devices.begin(), devices.end()).size() == devices.size();
+    const char* force = std::getenv("NCHMM_POOL_FORCE_RCCL");
+    const bool use_rccl = distinct && (W > 1 || (force && force[0] == '1'));
+    const unsigned threads_each = std::max(1u, (opts::num_threads.get() + (unsigned)W - 1) / (unsigned)W);
+
+    std::vector<std::unique_ptr<Worker_Stream>> ws;
+    for (int k = 0; k < W; ++k) {
+        int up[2], down[2];
+        if (pipe(up) != 0) throw std::runtime_error("pipe() failed");
+        if (pipe(down) != 0) { close(up[0]); close(up[1]); throw std::runtime_error("pipe() failed"); }
+#ifdef F_SETPIPE_SZ
+        (void)fcntl(up[1], F_SETPIPE_SZ, 1 << 20);
+#endif
+        std::cout.flush(); std::clog.flush();
+        const pid_t pid = fork();
+        if (pid < 0) { close(up[0]); close(up[1]); close(down[0]); close(down[1]); throw std::runtime_error("fork() failed"); }
+        if (pid == 0) {
+            // ---- worker k: nothing in this process has touched the HIP runtime yet; this one will, for device devices[k] only ----
+            signal(SIGPIPE, SIG_IGN);              // (a parent that has gone shows as a failed write: Worker_Link::send leaves)
+            close(up[0]); close(down[1]);
+            for (const auto& o : ws) { close(o->data_fd); close(o->ctl_fd); }
+            logger::tag() = "[w" + std::to_string(k) + "] ";
+            Worker_Link link;
+            link.rank = k; link.n_ranks = W; link.device = devices[(size_t)k]; link.data_fd = up[1]; link.ctl_fd = down[0]; link.use_rccl = use_rccl;
+            std::list<std::string> mine;
+            for (size_t i = 0; i < n; ++i) if (owner[i] == k) { mine.push_back(fv[i]); link.global_index.push_back(i); }
+            opts::num_threads.get() = threads_each;
+            if (const char* e = std::getenv("NANOCALL_TEST_WORKER_ABORT"))      // test hook: the worker of that rank dies before its first record
+                if (std::atoi(e) == k) abort();
+            int rc = EXIT_FAILURE;
+            try {
+                if (mine.empty()) {
+                    // (more workers than files: nothing to decode, but the reduction still counts this rank in)
+                    uint64_t zero[12] = {0};
+                    if (use_rccl && k == 0) {
+                        uint8_t id[NCHMM_RCCL_ID_BYTES];
+                        const bool have = nchmm_rccl_unique_id(id) == NCHMM_OK;
+                        link.send('U', 0, have ? std::string(reinterpret_cast<const char*>(id), sizeof(id)) : std::string());
+                    }
+                    link.send('C', 0, std::string(reinterpret_cast<const char*>(zero), sizeof(zero)));
+                    uint8_t go = 0, id[NCHMM_RCCL_ID_BYTES];
+                    if (!fd_read_all(link.ctl_fd, &go, 1) || (go && !fd_read_all(link.ctl_fd, id, sizeof(id)))) std::_Exit(EXIT_FAILURE);
+                    uint64_t red[8] = {0};
+                    const bool ok = go && nchmm_counters_allreduce(link.device, W, k, id, red) == NCHMM_OK;
+                    std::string g(1, ok ? '\1' : '\0');
+                    g.append(reinterpret_cast<const char*>(red), sizeof(red));
+                    link.send('G', 0, g);
+                    link.send('E', 0, std::string());
+                    std::_Exit(EXIT_SUCCESS);
+                }
+                rc = run_reads(models, mine, new Stage_Clock::Scope(stage_clock, "worker_total_s"), &link);      // (leaves from inside when all went well)
+            } catch (const std::exception& e) {
+                LOG(error) << e.what() << std::endl;
+            }
+            std::cout.flush(); std::cerr.flush(); std::clog.flush();
+            std::_Exit(rc == EXIT_SUCCESS ? EXIT_FAILURE : rc);      // run_reads returning at all is an early failure
+        }
+        close(up[1]); close(down[0]);
+        ws.emplace_back(new Worker_Stream());
+        ws.back()->pid = pid; ws.back()->data_fd = up[0]; ws.back()->ctl_fd = down[1]; ws.back()->device = devices[(size_t)k];
+        for (size_t i = 0; i < n; ++i) ws.back()->n_reads += owner[i] == k;
+    }
+    signal(SIGPIPE, SIG_IGN);                      // (a worker that died shows as a failed write on its control pipe)
+    LOG(info) << "workers=" << W << " devices=[" << [&] { std::ostringstream o; for (int k = 0; k < W; ++k) o << (k ? "," : "") << devices[(size_t)k]; return o.str(); }()
+              << "] threads_per_worker=" << threads_each << " counters_through=" << (use_rccl ? "rccl_allreduce" : "host_sum") << " files_per_worker=["
+              << [&] { std::ostringstream o; for (int k = 0; k < W; ++k) o << (k ? "," : "") << ws[(size_t)k]->n_reads; return o.str(); }() << "]" << std::endl;
+    for (auto& w : ws) { Worker_Stream* p = w.get(); p->th = std::thread([p] { p->pump(); }); }
+
+    // ---- the output, in input order (nanocall.cpp:859-861): read i comes from worker owner[i], whose frames are ascending ----
+    std::ofstream ofs, dump;
+    std::ostream* os_p = &std::cout;
+    if (!opts::output_fn.get().empty()) {
+        ofs.open(opts::output_fn.get());
+        if (!ofs) { LOG(error) << "cannot open output [" << opts::output_fn.get() << "]" << std::endl; for (auto& w : ws) kill(w->pid, SIGKILL); for (auto& w : ws) { w->th.join(); int st; waitpid(w->pid, &st, 0); } return EXIT_FAILURE; }
+        os_p = &ofs;
+    }
+    if (!opts::dump_params_fn.get().empty()) {
+        dump.open(opts::dump_params_fn.get());
+        dump << "#read_id\tstrand\tmodel\tscale\tshift\tdrift\tvar\tscale_sd\tvar_sd\tp_stay\tp_skip\tlog_path_prob\trounds\tfit" << std::endl;
+    }
+    std::vector<char> dead((size_t)W, 0);
+    std::vector<size_t> lost((size_t)W, 0);
+    {
+        STAGE("merge_output_s");
+        for (size_t i = 0; i < n; ++i) {
+            const size_t k = (size_t)owner[i];
+            if (dead[k]) { ++lost[k]; continue; }
+            Worker_Stream::Frame f;
+            if (!ws[k]->next(f) || f.type != 'R' || f.index != i) { dead[k] = 1; ++lost[k]; continue; }
+            *os_p << f.a;
+            if (dump.is_open()) dump << f.b;
+        }
+        os_p->flush();
+    }
+    // ---- --stats rows, then the counters ----
+    std::vector<std::string> stats_row(n);
+    std::vector<std::array<uint64_t, 12>> mine((size_t)W);
+    std::string unique_id;
+    bool have_id = false;
+    for (size_t k = 0; k < (size_t)W; ++k) {
+        mine[k].fill(0);
+        while (!dead[k]) {
+            Worker_Stream::Frame f;
+            if (!ws[k]->next(f)) { dead[k] = 1; break; }
+            if (f.type == 'S' && f.index < n) stats_row[(size_t)f.index].swap(f.a);
+            else if (f.type == 'U') { unique_id.swap(f.a); have_id = unique_id.size() == NCHMM_RCCL_ID_BYTES; }
+            else if (f.type == 'C' && f.a.size() == sizeof(uint64_t) * 12) { std::memcpy(mine[k].data(), f.a.data(), f.a.size()); break; }
+            else { dead[k] = 1; break; }
+        }
+    }
+    const bool any_dead = std::find(dead.begin(), dead.end(), (char)1) != dead.end();
+    // the verdict: every worker is alive and waiting for it -- all-reduce among them, or the sum is taken here
+    const bool go = use_rccl && have_id && !any_dead;
+    for (size_t k = 0; k < (size_t)W; ++k) {
+        if (dead[k]) continue;
+        const uint8_t b = go ? 1 : 0;
+        if (!fd_write_all(ws[k]->ctl_fd, &b, 1) || (go && !fd_write_all(ws[k]->ctl_fd, unique_id.data(), unique_id.size()))) dead[k] = 1;
+    }
+    uint64_t red[8] = {0};
+    bool reduced = go;
+    std::vector<std::string> worker_stages((size_t)W);
+    for (size_t k = 0; k < (size_t)W; ++k) {
+        if (dead[k]) { reduced = false; continue; }
+        // (a reduction that does not come back within a minute: a rank is stuck in the rendezvous -- the figures are summed here)
+        Worker_Stream::Frame f;
+        if (!ws[k]->next(f, go ? 60.0 : -1.0) || f.type != 'G' || f.a.size() != 1 + sizeof(red)) {
+            LOG(warning) << "worker " << k << ": no answer to the counter reduction; its counters are summed on the host" << std::endl;
+            reduced = false;
+            kill(ws[k]->pid, SIGKILL);
+            continue;
+        }
+        worker_stages[k] = f.b;
+        if (!f.a[0]) reduced = false;
+        else if (reduced) std::memcpy(red, f.a.data() + 1, sizeof(red));          // (every rank holds the same sums)
+        Worker_Stream::Frame e;
+        (void)ws[k]->next(e, 10.0);                                               // 'E'
+    }
+    uint64_t host[4] = {0, 0, 0, 0}, dev[8] = {0};
+    for (size_t k = 0; k < (size_t)W; ++k) {
+        host[0] += mine[k][0]; host[1] += mine[k][1];
+        host[2] = std::max(host[2], mine[k][2]); host[3] = std::max(host[3], mine[k][3]);      // the stages run side by side: wall = the slowest worker's
+        for (int q = 0; q < 8; ++q) dev[q] += mine[k][4 + (size_t)q];
+    }
+    if (reduced) std::copy(red, red + 8, dev);
+    int rc = EXIT_SUCCESS;
+    for (size_t k = 0; k < (size_t)W; ++k) {
+        close(ws[k]->ctl_fd);
+        int st = 0;
+        while (waitpid(ws[k]->pid, &st, 0) < 0 && errno == EINTR) {}
+        ws[k]->th.join();
+        close(ws[k]->data_fd);
+        const bool failed = dead[k] || !WIFEXITED(st) || WEXITSTATUS(st) != EXIT_SUCCESS;
+        if (failed && (dead[k] || lost[k])) {
+            // a worker that failed is reported, with what it leaves undone; it is never started again in place (its device may be
+            // in any state), and the records of the other workers are all in the output
+            LOG(error) << "worker " << k << " (device " << ws[k]->device << ") failed"
+                       << (WIFSIGNALED(st) ? " with signal " + std::to_string(WTERMSIG(st)) : WIFEXITED(st) ? " with exit code " + std::to_string(WEXITSTATUS(st)) : std::string())
+                       << ": " << lost[k] << " of its " << ws[k]->n_reads << " reads are not in the output" << std::endl;
+            rc = EXIT_FAILURE;
+        }
+    }
+    for (size_t k = 0; k < (size_t)W; ++k)
+        if (!worker_stages[k].empty()) { LOG(info) << "worker " << k << " device " << ws[k]->device << " reads " << ws[k]->n_reads << " stage_wall_secs" << worker_stages[k] << std::endl; }
+    LOG(info) << "counters reads=" << host[0] << " bases=" << host[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
+              << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " gathered_by=" << (reduced ? "rccl_allreduce" : "host_sum")
+              << " training_secs=" << host[2] / 1e6 << " basecalling_secs=" << host[3] / 1e6 << " workers=" << W << std::endl;
+    delete whole;
+    LOG(info) << "stage_wall_secs" << stage_clock.str() << std::endl;
+    if (!opts::stats_fn.get().empty()) {   // nanocall.cpp:893-903
+        std::ofstream sfs(opts::stats_fn.get());
+        if (!sfs) { LOG(error) << "cannot open stats file [" << opts::stats_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+        Fast5_Summary_Type::write_tsv_header(sfs);
+        sfs << std::endl;
+        for (size_t i = 0; i < n; ++i)
+            if (!dead[(size_t)owner[i]] || !stats_row[i].empty()) sfs << stats_row[i] << std::endl;
+        sfs.close();
+        if (!sfs) { LOG(error) << "error writing stats file [" << opts::stats_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+    }
+    if (ofs.is_open()) {
+        ofs.close();
+        if (!ofs) { LOG(error) << "error writing output [" << opts::output_fn.get() << "]" << std::endl; return EXIT_FAILURE; }
+    }
+    if (dump.is_open()) dump.close();
+    LOG(info) << "epoch_at_exit=" << std::fixed << epoch_now() << std::endl;
+    return rc;
+}
+
+static int real_main()
+{
+    // (wall-clock marks for whoever times the process from outside: tools/bench_cli.py splits its wall into before / inside / after)
+    LOG(info) << "epoch_at_main=" << std::fixed << epoch_now() << std::endl;
+    Stage_Clock::Scope* whole = new Stage_Clock::Scope(stage_clock, "main_total_s");
+    Pore_Model_Dict_Type models;
+    State_Transitions_Type default_transitions;
+    std::list<std::string> files;
+    { STAGE("init_models_s"); init_models(models); }
+    init_transitions(default_transitions);
+    // Which devices, and how many processes.  One GPU (or --single-process): this process does everything, as before.  More: one
+    // worker process per GPU, forked below while this process is still single-threaded and has not touched the HIP runtime --
+    // so even the device count is asked by a child (started here, answered while the input list is being made).
+    std::vector<int> worker_devices;
+    if (const char* e = std::getenv("NANOCALL_WORKER_DEVICES")) {      // e.g. "0,0,0,0": four workers on GPU 0 (test hook; one entry: one worker)
+        std::istringstream is(e);
+        std::string tok;
+        while (std::getline(is, tok, ',')) worker_devices.push_back(std::atoi(tok.c_str()));
+    }
+    int probed = -2;
+    const bool may_fan_out = !opts::single_process && !std::getenv("NANOCALL_DEVICE_IDS");
+    Device_Probe probe;
+    if (may_fan_out && worker_devices.empty() && opts::gpus.get() != 1) probe.start();
+    { STAGE("init_files_s"); init_files(files); }
+    if (probe.pid >= 0) { STAGE("device_count_s"); probed = probe.finish(); }
+    if (may_fan_out && worker_devices.empty() && probed >= 2) {
+        const int use = opts::gpus.get() > 0 ? opts::gpus.get() : probed;
+        if (use > probed) { LOG(error) << "--gpus " << use << " requested but only " << probed << " visible" << std::endl; return EXIT_FAILURE; }
+        if (use >= 2) for (int k = 0; k < use; ++k) worker_devices.push_back(k);
+    }
+    if (may_fan_out && !worker_devices.empty()) return fan_out(models, files, worker_devices, whole);
+    return run_reads(models, files, whole, nullptr);
 }
 
 int main(int argc, char* argv[])

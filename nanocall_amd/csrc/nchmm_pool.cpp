@@ -85,7 +85,9 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    bool ok = false;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;      // one process per GPU (nchmm_counters_allreduce)
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    bool ok = false, ok_ranks = false;
     Rccl()
     {
         // RCCL writes its version banner / warnings to stdout unless told otherwise; a host program may be streaming
@@ -107,7 +109,10 @@ struct Rccl {
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(handle, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
         ok = CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd;
+        ok_ranks = GetUniqueId && CommInitRank && CommDestroy && AllReduce;
     }
 };
 
@@ -489,6 +494,50 @@ int nchmm_pool_counters(nchmm_pool* pool, uint64_t out[8], int* used_rccl)
     std::memset(out, 0, 8 * sizeof(uint64_t));
     for (size_t d = 0; d < n; ++d)
         for (int k = 0; k < 8; ++k) out[k] += per[8 * d + (size_t)k];
+    return NCHMM_OK;
+}
+
+static_assert(sizeof(ncclUniqueId) == NCHMM_RCCL_ID_BYTES, "the id travels as NCHMM_RCCL_ID_BYTES bytes");
+
+int nchmm_rccl_unique_id(uint8_t id[NCHMM_RCCL_ID_BYTES])
+{
+    if (!id) return NCHMM_E_INVALID;
+    Rccl& R = rccl();
+    if (!R.ok_ranks) return NCHMM_E_NO_DEVICE;
+    ncclUniqueId u;
+    {
+        Stdout_To_Stderr guard;
+        if (R.GetUniqueId(&u) != ncclSuccess) return NCHMM_E_HIP;
+    }
+    std::memcpy(id, &u, sizeof(u));
+    return NCHMM_OK;
+}
+
+int nchmm_counters_allreduce(int device_id, int n_ranks, int rank, const uint8_t id[NCHMM_RCCL_ID_BYTES], uint64_t inout[8])
+{
+    if (!id || !inout || n_ranks < 1 || rank < 0 || rank >= n_ranks || device_id < 0) return NCHMM_E_INVALID;
+    Rccl& R = rccl();
+    if (!R.ok_ranks) return NCHMM_E_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return NCHMM_E_HIP;
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    {
+        Stdout_To_Stderr guard;
+        if (R.CommInitRank(&comm, n_ranks, u, rank) != ncclSuccess) return NCHMM_E_HIP;
+    }
+    uint64_t* buf = nullptr;
+    hipStream_t st = nullptr;
+    bool ok = hipMalloc((void**)&buf, 8 * sizeof(uint64_t)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess
+              && hipMemcpyAsync(buf, inout, 8 * sizeof(uint64_t), hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && R.AllReduce(buf, buf, 8, ncclUint64, ncclSum, comm, st) == ncclSuccess;
+    uint64_t got[8];
+    ok = ok && hipMemcpyAsync(got, buf, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (st) (void)hipStreamDestroy(st);
+    if (buf) (void)hipFree(buf);
+    R.CommDestroy(comm);
+    if (!ok) return NCHMM_E_HIP;
+    std::memcpy(inout, got, sizeof(got));
     return NCHMM_OK;
 }
 

@@ -477,3 +477,93 @@ def test_partial_training_modes_teacher_forced(tmp_path, extra, kw):
         if "--train-drift" in extra:
             assert v["pm"][2] == 0
     same, n = check_free_running(o, inputs, d, p.stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one worker process per GPU (nanocall.cpp: fan_out) -- on the one GPU a test box has, every worker on device 0
+# ---------------------------------------------------------------------------------------------------------------
+def _worker_inputs(tmp_path, n=26):
+    """ragged synthetic reads (1D and 2D, a few hundred to a few thousand events per strand) + two of the FAST5 fixtures"""
+    rng = np.random.default_rng(77)
+    files = []
+    for k in range(n):
+        n0 = int(rng.integers(150, 2600))
+        n1 = int(rng.integers(150, 2600)) if k % 3 else 0
+        ed = op.synth_ed_table("r73", n0, n1, seed=300 + k, hairpin=8 if n1 else 0, complement_model="r73.c.p1.006.ont.model" if k % 2 else "r73.c.p2.006.ont.model",
+                               scale=1.0 + 0.01 * (k % 5), shift=float(k % 7) - 3.0, drift=0.002 * (k % 3))
+        path = tmp_path / f"w_{k:02d}.events"
+        op.write_events_table(str(path), ed, 4000.0, f"w-{k}")
+        files.append(str(path))
+    files[5:5] = [os.path.join(G, "r73_2d_a.fast5"), os.path.join(G, "r73_short_c.fast5")]
+    return files
+
+
+def _pick(line, key):
+    return [w for w in line.split() if w.startswith(key + "=")][0].split("=")[1]
+
+
+@pytest.mark.parametrize("workers", [1, 2, 4])
+def test_worker_processes_give_the_single_process_output(tmp_path, workers):
+    """`nanocall --gpus N` starts one worker process per GPU before anything touches the HIP runtime, gives each an LPT share of the
+    input files and writes their records in input order (nanocall.cpp:282,611,859-866).  N = 1, 2, 4 workers sharing GPU 0
+    (NANOCALL_WORKER_DEVICES): FASTA, --stats and --dump-params byte-identical to the single-process run, with training, over
+    several chunks per worker; the counters add up; the parent never creates a device context."""
+    files = _worker_inputs(tmp_path)
+    base = ["--pore", "r73", "--scaling-num-events", "120", "--scaling-max-rounds", "2", "--chunk-events", "6000", "-t", "8"]
+    outs = {}
+    for tag, env in (("single", {}), ("workers", {"NANOCALL_WORKER_DEVICES": ",".join(["0"] * workers)})):
+        fa, st, dp = tmp_path / f"{tag}.fa", tmp_path / f"{tag}.tsv", tmp_path / f"{tag}.params"
+        r = run_cli(base + ["-o", str(fa), "--stats", str(st), "--dump-params", str(dp)] + files, env=env)
+        outs[tag] = (fa.read_text(), st.read_text(), dp.read_text(), r.stderr)
+    assert outs["single"][0].count(">") >= 30
+    for i, what in enumerate(("FASTA", "--stats", "--dump-params")):
+        assert outs["workers"][i] == outs["single"][i], what
+    err = outs["workers"][3]
+    assert f"workers={workers} devices=[{','.join(['0'] * workers)}]" in err
+    c1 = [l for l in outs["single"][3].splitlines() if "counters reads=" in l][-1]
+    cw = [l for l in err.splitlines() if "counters reads=" in l and "worker_counters" not in l][-1]
+    for k in ("reads", "bases", "strands_decoded", "events_decoded", "fb_windows", "fb_event_rounds"):
+        assert _pick(c1, k) == _pick(cw, k), k
+    assert _pick(cw, "workers") == str(workers) and _pick(cw, "gathered_by") == "host_sum"      # (workers on one device cannot form a communicator)
+    # every worker reported its stages; the parent's own stages are the merge and the input list -- no device stage
+    assert sum("stage_wall_secs" in l and l.startswith("= nanocall info: worker ") for l in err.splitlines()) == workers
+    parent_stages = [l for l in err.splitlines() if l.startswith("= nanocall info: stage_wall_secs")][-1]
+    assert "merge_output_s=" in parent_stages and "device_init_s" not in parent_stages and "basecalling_total_s" not in parent_stages
+    # stdout instead of -o: the same bytes
+    r = run_cli(base + files, env={"NANOCALL_WORKER_DEVICES": ",".join(["0"] * workers)})
+    assert r.stdout == outs["single"][0]
+
+
+def test_one_worker_process_reduces_its_counters_through_rccl(tmp_path):
+    """The cross-process reduction itself -- ncclGetUniqueId in rank 0, the id relayed through the parent's pipes,
+    ncclCommInitRank + one ncclAllReduce in every worker (nchmm_rccl_unique_id / nchmm_counters_allreduce) -- on the one device a
+    test box has: one worker, NCHMM_POOL_FORCE_RCCL=1.  And its fall-back when librccl cannot be loaded."""
+    files = [os.path.join(G, n + ".fast5") for n in ("r73_2d_a", "r73_1d_b", "r73_2d_e")]
+    base = ["--pore", "r73", "--no-train"] + files
+    ref = run_cli(base)
+    c_ref = [l for l in ref.stderr.splitlines() if "counters reads=" in l][-1]
+    got = run_cli(base, env={"NANOCALL_WORKER_DEVICES": "0", "NCHMM_POOL_FORCE_RCCL": "1"})
+    c = [l for l in got.stderr.splitlines() if "counters reads=" in l and "worker_counters" not in l][-1]
+    assert got.stdout == ref.stdout and "counters_through=rccl_allreduce" in got.stderr
+    assert _pick(c, "gathered_by") == "rccl_allreduce", c
+    for k in ("reads", "bases", "strands_decoded", "events_decoded"):
+        assert _pick(c, k) == _pick(c_ref, k), k
+    got = run_cli(base, env={"NANOCALL_WORKER_DEVICES": "0", "NCHMM_POOL_FORCE_RCCL": "1", "NCHMM_RCCL_LIB": str(tmp_path / "no_such_librccl.so")})
+    c = [l for l in got.stderr.splitlines() if "counters reads=" in l and "worker_counters" not in l][-1]
+    assert got.stdout == ref.stdout and _pick(c, "gathered_by") == "host_sum" and _pick(c, "events_decoded") == _pick(c_ref, "events_decoded")
+
+
+def test_a_worker_process_that_dies_is_reported_and_the_others_records_are_all_there(tmp_path):
+    """A worker that fails (here: aborts before its first record, NANOCALL_TEST_WORKER_ABORT) is reported with the number of reads it
+    leaves undone and is not started again; the run ends with a failure code and the records of every other worker's reads, in
+    input order."""
+    files = _worker_inputs(tmp_path, n=12)
+    base = ["--pore", "r73", "--no-train"] + files
+    ref = split_fasta(run_cli(base).stdout)
+    bad = run_cli(base, env={"NANOCALL_WORKER_DEVICES": "0,0,0", "NANOCALL_TEST_WORKER_ABORT": "1"}, expect_rc=1)
+    assert "worker 1 (device 0) failed with signal 6" in bad.stderr and "reads are not in the output" in bad.stderr
+    got = split_fasta(bad.stdout)
+    assert 0 < len(got) < len(ref) and all(ref[k] == v for k, v in got.items())
+    assert list(got) == [k for k in ref if k in got]                 # input order kept
+    lost = int(bad.stderr.split("failed with signal 6: ")[1].split()[0])
+    assert lost >= 1 and "workers=3" in bad.stderr

@@ -78,14 +78,11 @@ def oracle_decode(batch):
 
 
 def _decode(batch, form, **env):
-    for k, v in env.items():
+    for k, v in env.items():           # (the budgets are read when a workspace is first sized, not when the context is created)
         os.environ[k] = v
+    ctx = None
     try:
         ctx = na.Context(0)
-    finally:
-        for k in env:
-            del os.environ[k]
-    try:
         ctx.set_sweep(form)
         for s, (t, p) in enumerate(zip(batch["tables"], batch["params"])):
             ctx.put_model(s, na.scaled_model_table(t, p))
@@ -97,7 +94,10 @@ def _decode(batch, form, **env):
         info = dict(launches=int(ctx.counters()[3]) - launches0, ticks=[int(x) for x in ctx.profile_ticks()[:8]], sweep=list(ctx.sweep_stats()),
                     ahead=list(ctx.ahead_stats()), peak_mb=int(ctx.mem_stats()[1]) >> 20)
     finally:
-        ctx.close()
+        for k in env:
+            del os.environ[k]
+        if ctx is not None:
+            ctx.close()
     return states, logp, status, info
 
 

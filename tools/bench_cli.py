@@ -6,6 +6,9 @@ split into the stages the CLI reports.  Prints one JSON line.
   READS=2000 EVENTS=3000 THREADS=32 python tools/bench_cli.py [extra nanocall options]
   RAGGED=1: read lengths log-normal around EVENTS (sigma 0.8, 600 .. 8 x EVENTS events; 48 distinct reads), what real runs
   look like -- a launch lasts as long as its longest read
+  WORKERS=N: one worker process per GPU as `nanocall --gpus N` starts them, all N on GPU 0 here (NANOCALL_WORKER_DEVICES): the line
+  then carries every worker's stage clock and the rate at which its HOST stages (summary pass, event loading + packing, FASTA) take
+  its share of the input -- what one worker's host side sustains beside the others, i.e. whether N GPUs would be fed
 """
 import json
 import os
@@ -53,15 +56,19 @@ try:
     cmd = [cli, "--pore", "r73", "-t", str(threads), "-o", out] + sys.argv[1:] + [d]
     t0 = time.perf_counter()
     e0 = time.time()
-    p = subprocess.run(cmd, capture_output=True, text=True)
+    n_workers = int(os.environ.get("WORKERS", 0))
+    env = dict(os.environ)
+    if n_workers:
+        env["NANOCALL_WORKER_DEVICES"] = ",".join(["0"] * n_workers)
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
     wall = time.perf_counter() - t0
     e1 = time.time()
     assert p.returncode == 0, p.stderr[-2000:]
     if os.environ.get("NCHMM_DEBUG"):
         sys.stderr.write("".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("[nchmm")))
-    line = [l for l in p.stderr.splitlines() if "counters reads=" in l][-1]
+    line = [l for l in p.stderr.splitlines() if "counters reads=" in l and "worker_counters" not in l][-1]
     kv = dict(tok.split("=") for tok in line.split() if "=" in tok)
-    stages = [l for l in p.stderr.splitlines() if "stage_wall_secs" in l][-1].split("stage_wall_secs")[1].split()
+    stages = [l for l in p.stderr.splitlines() if l.startswith("= nanocall info: stage_wall_secs")][-1].split("stage_wall_secs")[1].split()
     stages = {t.split("=")[0]: round(float(t.split("=")[1]), 3) for t in stages}
     n_rec = sum(1 for l in open(out) if l.startswith(">"))
     marks = {k: float(l.split(k + "=")[1].split()[0]) for l in p.stderr.splitlines() for k in ("epoch_at_main", "epoch_at_exit") if k + "=" in l}
@@ -69,12 +76,27 @@ try:
                if len(marks) == 2 else None)
     reserve = [l.split("reserve_viterbi_workspace", 1)[1].strip() for l in p.stderr.splitlines() if "reserve_viterbi_workspace" in l]
     ev_in = int(sum(int(lens[r % distinct]) for r in range(int(kv["reads"]))))
+    # one worker process per GPU: each worker's stage clock, and what its host stages sustain on its share of the input
+    workers = []
+    for l in p.stderr.splitlines():
+        if l.startswith("= nanocall info: worker ") and "stage_wall_secs" in l:
+            head, tail = l.split("stage_wall_secs")
+            w = head.split()
+            st = {t.split("=")[0]: float(t.split("=")[1]) for t in tail.split()}
+            share = ev_in * int(w[8]) / max(1, int(kv["reads"]))
+            rate = lambda k: (round(share / st[k] / 1e6, 1) if st.get(k) else None)
+            workers.append({"worker": int(w[4]), "device": int(w[6]), "reads": int(w[8]), "input_events": int(share),
+                            "stages": {k: round(v, 3) for k, v in st.items()},
+                            "host_Mevents_per_s": {"summary_pass": rate("init_reads_s"), "load_events": rate("load_events_s"), "soa_and_jobs": rate("soa_and_jobs_s"),
+                                                   "fasta": rate("fasta_s")},
+                            "gpu_Mevents_per_s_of_input": (round(share / (st.get("training_total_s", 0.0) + st.get("basecalling_total_s", 0.0)) / 1e6, 1)
+                                                           if st.get("basecalling_total_s") else None)})
     print(json.dumps({"reads": int(kv["reads"]), "events_per_read": n_events, "ragged": ragged, "longest_read_events": int(lens.max()), "input_events": ev_in, "fasta_records": n_rec, "bases": int(kv["bases"]),
                       "wall_s": round(wall, 3), "training_s": float(kv["training_secs"]), "basecalling_s": float(kv["basecalling_secs"]),
                       "other_s_(summaries, event loading, FASTA)": round(wall - float(kv["training_secs"]) - float(kv["basecalling_secs"]), 3),
                       "reads_per_s": round(int(kv["reads"]) / wall, 1), "input_Mevents_per_s_end_to_end": round(ev_in / wall / 1e6, 2),
                       "events_decoded": int(kv["events_decoded"]), "decoded_Mevents_per_s_in_basecalling": round(int(kv["events_decoded"]) / float(kv["basecalling_secs"]) / 1e6, 1),
-                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages, "viterbi_workspace_reserved": reserve[-1] if reserve else None, "outside_main": outside, "stderr_bytes": len(p.stderr), "memory_at_exit": ([l.split("memory_at_exit", 1)[1].strip() for l in p.stderr.splitlines() if "memory_at_exit" in l] or [None])[-1],
+                      "fb_event_rounds": int(kv["fb_event_rounds"]), "host_threads": threads, "gathered_by": kv["gathered_by"], "fixture_generation_s": round(t_gen, 1), "stages": stages, "workers": workers or None, "viterbi_workspace_reserved": reserve[-1] if reserve else None, "outside_main": outside, "stderr_bytes": len(p.stderr), "memory_at_exit": ([l.split("memory_at_exit", 1)[1].strip() for l in p.stderr.splitlines() if "memory_at_exit" in l] or [None])[-1],
                       "cmd": " ".join(cmd[:1] + cmd[1:-1])}))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
