@@ -36,6 +36,7 @@
 #include <deque>
 #include <exception>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <list>
 #include <mutex>
@@ -1271,12 +1272,17 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
     if (link) {
         // ---- a worker: the rest of its records, its --stats rows, its counters; then the reduction with the other workers ----
         link->emit_rest();
-        if (!opts::stats_fn.get().empty())
+        if (!opts::stats_fn.get().empty()) {
+            // (the rows are written as ONE stream would write them: the parameter columns leave std::fixed / precision 5 set on
+            // the stream, Pore_Model.hpp:72-76, so only the very first row of the file has its abasic level in the default format)
+            std::ostringstream row;
             for (size_t j = 0; j < reads.size(); ++j) {
-                std::ostringstream row;
+                if (link->global_index[j] != 0) row << std::fixed << std::setprecision(5);
+                row.str(std::string());
                 reads[j].write_tsv(row);
                 link->send('S', link->global_index[j], row.str());
             }
+        }
         unsetenv("NCHMM_POOL_FORCE_RCCL");          // (this worker's own figures: a plain read-out; the reduction is across the workers)
         check(nchmm_pool_counters(pool, dev, nullptr), "nchmm_pool_counters");
         if (link->use_rccl && link->rank == 0) {
