@@ -365,8 +365,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
         auto pm_add = [&](int u, float p) {
             const float t0 = p * r2[u], l0 = p * lq[u];
             const float t1 = t0 * mu[u], l1 = l0 * eta[u];
-            ps[0] += t0; ps[1] += t1; ps[2] += t1 * mu[u];
-            ps[5] += l0; ps[4] += l1; ps[3] += l1 * eta[u];
+            ps[0] += t0; ps[1] += t1; ps[2] = __builtin_fmaf(t1, mu[u], ps[2]);
+            ps[5] += l0; ps[4] += l1; ps[3] = __builtin_fmaf(l1, eta[u], ps[3]);
         };
         // the six sums of an event wait in `ps` until the next producer phase, where they share one hand-scheduled
         // 7-way wave reduction with that phase's column total; lane 63 then files them under their event's parity
@@ -400,6 +400,9 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             // otherwise spills and reloads (each reload also waits for the alpha-row prefetch in flight).
             unsigned tl = tau;
             asm volatile("" : "+v"(tl));
+            // producer phase at raised priority, back to 0 at the barrier: the waves of a block reach their barrier sooner when the
+            // co-resident block's consumers do not take their issue slots (backward sweep 1.86 -> 1.80 ms, profiles/r06_fb_backward_session.md)
+            __builtin_amdgcn_s_setprio(2);
             const unsigned buf = (unsigned)i & 1u;
             const float x = nx_x, sry = __builtin_amdgcn_rsqf(nx_y), ysry = nx_y * sry;
             rowp -= kStates;
@@ -417,7 +420,10 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const int q = 2 * pr + v;
-                    g[q] = ex2(k02[v] - xs(x, ysry, sry, mu[q], r2[q], eta[q], lq[q])) * bh[q];
+                    {   // k0 - xs folded into the two FMAs of xs: one VALU op less per cell
+                        const float dx = x - mu[q], dyp = __builtin_fmaf(-eta[q], sry, ysry);
+                        g[q] = ex2(__builtin_fmaf(-(dx * dx), r2[q], __builtin_fmaf(-(dyp * dyp), lq[q], k02[v]))) * bh[q];
+                    }
                 }
             }
             const float a = (g[0] + g[1]) + (g[2] + g[3]);
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             }
             asm volatile("" :: "s"(nx_ia));     // the scalar load must have landed by here (hipcc otherwise sinks it to its use
                                                 // right after the barrier, where its latency is exposed)
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             publish((unsigned)i, tl);    // the barrier made every wave's sums of event i visible
             const float4 z0 = *reinterpret_cast<const float4*>(&sZ[buf][0]);
