@@ -70,7 +70,7 @@ if "viterbi_kernel" in traffic and "FETCH_SIZE_KiB" in traffic["viterbi_kernel"]
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("viterbi_kernel.hip", "viterbi_common.hpp", "nchmm_device.h"):      # (= bench.py kernel_source_hash)
+    for f in ("viterbi_kernel.hip", "viterbi_ll_kernel.hip", "emission_kernel.hip", "viterbi_common.hpp", "nchmm_device.h"):      # (= bench.py kernel_source_hash)
         h.update(open(os.path.join(root, "nanocall_amd", "csrc", f), "rb").read())
     reads, events = int(os.environ.get("PROF_READS", 1024)), int(os.environ.get("PROF_EVENTS", 5000))
     doc = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_INSTS_VALU (separate passes, tools/gpu_profile.sh), per-dispatch means. "
