@@ -1363,6 +1363,25 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
 // ---------------------------------------------------------------------------------------------------------------
 // How many devices a process of this environment would see -- asked by a short-lived child, so that THIS process has not touched
 // the HIP runtime when it forks its workers (and never does: the parent of a multi-GPU run only moves bytes).
+// GPUs this process could open at all: the render nodes under /dev/dri it may open read-write (a container is given the nodes of
+// its GPUs only).  An upper bound that costs microseconds and no runtime: with fewer than two there is nothing to fan out over
+// and the count itself is left to run_reads; with two or more the exact number (the runtime's, which honours HIP_VISIBLE_DEVICES
+// and its relatives) is asked by the child below.
+static int openable_render_nodes()
+{
+    int n = 0;
+    if (DIR* d = opendir("/dev/dri")) {
+        while (const dirent* e = readdir(d)) {
+            if (std::strncmp(e->d_name, "renderD", 7) != 0) continue;
+            const std::string path = std::string("/dev/dri/") + e->d_name;
+            const int fd = open(path.c_str(), O_RDWR | O_CLOEXEC);
+            if (fd >= 0) { ++n; close(fd); }
+        }
+        closedir(d);
+    }
+    return n;
+}
+
 struct Device_Probe {
     pid_t pid = -1;
     int fd = -1;
@@ -1663,7 +1682,7 @@ static int real_main()
     int probed = -2;
     const bool may_fan_out = !opts::single_process && !std::getenv("NANOCALL_DEVICE_IDS");
     Device_Probe probe;
-    if (may_fan_out && worker_devices.empty() && opts::gpus.get() != 1) probe.start();
+    if (may_fan_out && worker_devices.empty() && opts::gpus.get() != 1 && openable_render_nodes() >= 2) probe.start();
     { STAGE("init_files_s"); init_files(files); }
     if (probe.pid >= 0) { STAGE("device_count_s"); probed = probe.finish(); }
     if (may_fan_out && worker_devices.empty() && probed >= 2) {
