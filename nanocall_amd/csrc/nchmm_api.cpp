@@ -316,6 +316,7 @@ int nchmm_create(nchmm_ctx** out, int device_id)
         c->fb_force_log = f && f[0] == '1';
         if (const char* w = std::getenv("NCHMM_VIT_SWEEP"))     // wide | ll | auto: which form of the sweep launches take
             c->sweep_mode = !std::strcmp(w, "wide") ? kSweepWide : !std::strcmp(w, "ll") ? kSweepLl : !std::strcmp(w, "ahead") ? kSweepAhead : kSweepAuto;
+        if (const char* k = std::getenv("NCHMM_PLAN_CLOCK_MHZ")) c->plan_clock_mhz = std::atof(k);      // the sustained shader clock the sweep plan prices with
         const char* b = std::getenv("NCHMM_FB_BUDGET_MB");
         if (b) c->fb_budget = std::max<size_t>((size_t)std::strtoull(b, nullptr, 10) << 20, (size_t)16 << 20);
     }
@@ -911,7 +912,7 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
                 if (n_in)
                     rc = launch_viterbi_range(c, nullptr, 0, n_in, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, d_in,
                                               d_out_state, d_out_logp, d_out_status, nullptr,
-                                              choose_sweep_bounds(n_in, longest_in, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, true));
+                                              choose_sweep_bounds(n_in, longest_in, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, true, rates_at_clock(c->plan_clock_mhz)));
                 return rc;
             }
         }
@@ -928,7 +929,7 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
         }
         return launch_viterbi_range(c, nullptr, 0, n_reads, total_events, d_off, d_cmean, d_stdv, d_lstdv, d_model_slot, d_trans_slot, n_out ? d_out : d_in,
                                     d_out_state, d_out_logp, d_out_status, nullptr,
-                                    choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming));
+                                    choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming, rates_at_clock(c->plan_clock_mhz)));
     }
     if ((rc = viterbi_ws_prepare(c, max_events, n_reads))) return rc;
     c->counters[0] += n_reads;
@@ -947,7 +948,7 @@ int viterbi_dev_enqueue(nchmm_ctx* c, bool streaming, size_t n_reads, size_t max
     // the lengths are on the device: the form of the sweep follows from what the caller states (reads, longest, total); emissions
     // ahead = of every read of the batch (row of read r's event i: off[r] + i), when that fits the buffer
     const uint64_t em_rows = viterbi_em_budget_rows(c);
-    int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming, SweepRates(), em_rows);
+    int sweep = choose_sweep_bounds(n_reads, max_events, total_events, (size_t)c->n_cu, (size_t)c->vit_slots, streaming, rates_at_clock(c->plan_clock_mhz), em_rows);
     if (c->sweep_mode == kSweepAhead && !streaming && total_events <= em_rows && n_reads <= kMaxAheadReads) sweep = kSweepAhead;
     AheadArgs ahead;
     if (sweep == kSweepAhead) { ahead.n = n_reads; ahead.rows = total_events; ahead.longest = max_events; ahead.d_row0 = nullptr; }
@@ -1401,6 +1402,7 @@ int nchmm_shader_clock_mhz(nchmm_ctx* c, double* out_mhz)
     HIP_TRY(c, e);
     if (h[1] == 0) return NCHMM_E_HIP;
     *out_mhz = (double)h[0] / (double)h[1] * (double)wall_khz * 1e-3;
+    if (!std::getenv("NCHMM_PLAN_CLOCK_MHZ")) c->plan_clock_mhz = *out_mhz;      // (the sweep plan prices with the clock the device was last seen to hold under load)
     return NCHMM_OK;
 }
 

@@ -80,6 +80,7 @@ struct nchmm_ctx {
     float* d_em = nullptr;
     size_t em_bytes = 0, em_budget = 0;      // NCHMM_EM_BUDGET_MB (default 256)
     hipEvent_t ev_em = nullptr;     // behind the most recent sweep that read d_em
+    double plan_clock_mhz = 0.0;    // the sustained shader clock the sweep plan prices with (0: the clock its rates were measured at): NCHMM_PLAN_CLOCK_MHZ, or the last nchmm_shader_clock_mhz
     size_t tight_skip_reads = 0, tight_skip_longest = 0;   // nchmm_viterbi_dev*: the batch shape whose device-side plan found most reads long
     bool em_pending = false;
     unsigned* d_slot_owner = nullptr;   // [kXcds][slots_per_xcd]

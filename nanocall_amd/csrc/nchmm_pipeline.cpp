@@ -156,7 +156,7 @@ int pipe_begin(nchmm_ctx* c, size_t n, const uint64_t* off, size_t total, const 
             for (size_t r = 0; r < n; ++r) lens[r] = off[r + 1] - off[r];
             const uint64_t em_rows = viterbi_em_budget_rows(c);
             if (c->sweep_mode == kSweepAuto) {
-                batch_sweep = choose_sweep(lens, (size_t)c->n_cu, (size_t)c->vit_slots, false, SweepRates(), em_rows, &n_ahead);
+                batch_sweep = choose_sweep(lens, (size_t)c->n_cu, (size_t)c->vit_slots, false, rates_at_clock(c->plan_clock_mhz), em_rows, &n_ahead);
             } else {
                 // a forced low-latency form: "ahead" takes as many of the longest reads ahead as the buffer holds
                 batch_sweep = c->sweep_mode;

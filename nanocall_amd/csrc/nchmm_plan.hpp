@@ -114,13 +114,31 @@ inline OutlierPlan plan_outliers(const uint64_t* off, size_t n, const std::vecto
 // Microseconds per event, measured (profiles/r05_ll_sweep.md): a wide block with a busy neighbour on its CU, a wide block
 // alone on its CU, an ll block.
 enum Sweep : int { kSweepAuto = 0, kSweepWide = 1, kSweepLl = 2, kSweepAhead = 3 };
+constexpr double kRatesClockMHz = 2100.0;      // the shader clock the event rates below were measured at (boxes at 2.0-2.15 GHz)
 // kSweepAhead: the low-latency form with the emissions of the launch's longest reads computed ahead by the whole device
 // (emission_kernel.hip): their columns carry the recurrence only.  us per event of a read: ahead; CU-us per event of the
 // emission kernel: em_cu (it runs on every CU at once, before the sweep: rows * em_cu / n_cu of wall time).
-struct SweepRates { double wide_shared = 1.55, wide_alone = 1.15, ll = 0.85, ahead = 0.60, em_cu = 0.85; double per_read_us = 60.0; };
+// em_launch_us: what a second kernel in front of the sweep costs (launch + its tail).
+// The event rates follow the shader clock (the kernels are VALU-issue bound) and the boxes of the pool sustain 1.9-2.35 GHz; the
+// decision is a comparison of durations, so a common factor cancels, and what does not scale with the clock -- em_cu on rows
+// from HBM, the per-read and per-launch constants -- only matters near the break-even: tools/plan_props.cpp walks 20 000 batch
+// shapes with every group of rates scaled by 0.8-1.25 on its own and finds no decision that costs more than 5 % of the best
+// form's duration under the scaled rates (tests/test_host_prep.py).
+struct SweepRates { double wide_shared = 1.55, wide_alone = 1.15, ll = 0.85, ahead = 0.60, em_cu = 0.85; double per_read_us = 60.0; double em_launch_us = 30.0; };
 // A read whose emissions are ahead streams 16 KiB per event back in (27 GB/s per block at 0.6 us per event; 256 such streams are the device's whole bandwidth).  Beyond ~100 such
 // blocks at once the sweep is HBM-bound and slower than computing the emissions in place (256 x 5000 events: 4.85 ms against 4.23).
 constexpr size_t kMaxAheadReads = 96;
+// The rates on a device whose sustained shader clock is known (nchmm_shader_clock_mhz has measured it under load, or
+// NCHMM_PLAN_CLOCK_MHZ states it): the sweeps are VALU-issue bound and follow the clock; rows from HBM (em_cu) and the fixed costs do not.
+inline SweepRates rates_at_clock(double mhz)
+{
+    SweepRates r;
+    if (mhz > 0.0) {
+        const double f = kRatesClockMHz / std::min(std::max(mhz, 800.0), 3000.0);
+        r.wide_shared *= f; r.wide_alone *= f; r.ll *= f; r.ahead *= f;
+    }
+    return r;
+}
 
 // makespan (us) of `lens` (events per read, any order) handed out longest first to `slots` blocks at `us_per_event`
 inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double us_per_event, double per_read_us)
@@ -152,18 +170,23 @@ inline double lpt_makespan_us(std::vector<uint64_t> lens, size_t slots, double u
 // lens: the launch's reads LONGEST FIRST.  Candidates: the first K reads, K = 0, 1, 2, 4, ... (and all), as far as `budget_rows`
 // (16 KiB per event) reaches; each is priced as the emission kernel's wall time plus the longest-processing-time schedule of
 // the sweep on n_cu blocks, and the cheapest wins.  Returns K; *t_us = its duration.
+// duration (us) of a low-latency launch of `lens_desc` (longest first) whose first K reads have their emissions ahead
+inline double price_ahead_us(const std::vector<uint64_t>& lens_desc, size_t K, size_t n_cu, const SweepRates& R)
+{
+    n_cu = std::max<size_t>(n_cu, 1);
+    uint64_t rows = 0;
+    for (size_t k = 0; k < K; ++k) rows += lens_desc[k];
+    // (times, not lengths, go through the scheduler: scale the ahead reads' lengths by ahead / ll)
+    std::vector<uint64_t> eff(lens_desc);
+    for (size_t k = 0; k < K; ++k) eff[k] = (uint64_t)((double)eff[k] * (R.ahead / R.ll));
+    return (double)rows * R.em_cu / (double)n_cu + (K ? R.em_launch_us : 0.0) + lpt_makespan_us(std::move(eff), n_cu, R.ll, R.per_read_us);
+}
+
 inline size_t plan_ahead(const std::vector<uint64_t>& lens_desc, size_t n_cu, uint64_t budget_rows, double* t_us, const SweepRates& R = SweepRates())
 {
     const size_t n = lens_desc.size();
     n_cu = std::max<size_t>(n_cu, 1);
-    auto price = [&](size_t K) {
-        uint64_t rows = 0;
-        for (size_t k = 0; k < K; ++k) rows += lens_desc[k];
-        // (times, not lengths, go through the scheduler: scale the ahead reads' lengths by ahead / ll)
-        std::vector<uint64_t> eff(lens_desc);
-        for (size_t k = 0; k < K; ++k) eff[k] = (uint64_t)((double)eff[k] * (R.ahead / R.ll));
-        return (double)rows * R.em_cu / (double)n_cu + (K ? 30.0 : 0.0) + lpt_makespan_us(std::move(eff), n_cu, R.ll, R.per_read_us);
-    };
+    auto price = [&](size_t K) { return price_ahead_us(lens_desc, K, n_cu, R); };
     size_t best_k = 0;
     double best = price(0);
     uint64_t rows = 0;
@@ -211,15 +234,24 @@ inline Sweep choose_sweep_bounds(size_t n_reads, uint64_t longest, uint64_t tota
     if (n_reads == 0 || n_cu == 0) return kSweepWide;
     if (busy && n_reads * 3 >= wide_slots) return kSweepWide;
     if (longest == 0 || longest > total) longest = total / n_reads + 1;
+    // (the two lower bounds of the longest-first schedule, every read with its fixed cost -- as lpt_makespan_us beyond kSimReads;
+    // round 5 charged the fixed cost once per launch, which put batches of many very short reads on the low-latency form:
+    // 455 reads of 64 events 229 us there against 159 us wide, tools/plan_props.cpp)
+    // Reads of (nearly) one length -- the longest within a quarter of the mean -- go through in whole rounds: 264 reads on 256
+    // blocks take two rounds, not 1.03 (the averaged bound had such batches on the low-latency form at 219 us against 150 wide).
+    const bool uniform = (double)longest * (double)n_reads <= 1.25 * (double)total;
     auto bound = [&](size_t slots, double us) {
-        const double par = n_reads <= slots ? 0.0 : (double)total * us / (double)slots;
-        return std::max((double)longest * us, par) + R.per_read_us;
+        double par = 0.0;
+        if (n_reads > slots)
+            par = uniform ? (double)((n_reads + slots - 1) / slots) * ((double)total / (double)n_reads * us + R.per_read_us)
+                          : ((double)total * us + (double)n_reads * R.per_read_us) / (double)slots;
+        return std::max((double)longest * us + R.per_read_us, par);
     };
     const double t_ll = bound(n_cu, R.ll);
     const double t_wide = n_reads <= n_cu ? bound(n_cu, R.wide_alone) : bound(wide_slots, R.wide_shared);
     // every read ahead (the lengths are not known here): worth it when the batch is a few reads -- idle CUs compute the emissions
     const double t_ahead = !busy && ahead_budget_rows && total <= ahead_budget_rows && n_reads <= kMaxAheadReads
-                               ? (double)total * R.em_cu / (double)n_cu + 30.0 + bound(n_cu, R.ahead) : 1e300;
+                               ? (double)total * R.em_cu / (double)n_cu + R.em_launch_us + bound(n_cu, R.ahead) : 1e300;
     if (t_ahead < 0.97 * std::min(t_ll, t_wide)) return kSweepAhead;
     return t_ll < t_wide ? kSweepLl : kSweepWide;
 }

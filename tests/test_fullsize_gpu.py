@@ -1,5 +1,7 @@
 """Full-size cases (BASELINE.json configs 2 and 5) through size-independent properties, plus one
 50 000-event read against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -216,9 +218,23 @@ def _config3(gpu_ctx, api, reference_train_job):
     got = out["pm"][k]
     for q in (0, 4):
         assert abs(got[q] - pm[q]) <= 2e-4 * abs(pm[q]), (q, got, pm)
-    for q in (3, 5):                                                   # var, var_sd: the reference's own fp32 noise (test_fwbw_gpu.py)
-        assert abs(got[q] - pm[q]) <= 1.5e-3 * abs(pm[q]), (q, got, pm)
     assert np.allclose(out["st"][k], st, rtol=5e-4, atol=0), (out["st"][k], st)
+    # var and var_sd (Parameter_Trainer.hpp:406-426: differences of large sums) carry fp32 noise of ~1e-4 per round in the
+    # reference's own arithmetic, and four free-running rounds compound it.  They are held to the same 5e-4 as in
+    # tests/test_fwbw_gpu.py -- against the REAL-NUMBER answer: the same four rounds evaluated in float64 from the same fp32
+    # inputs (tools/fb_truth.py --config3-read -> tests/golden/config3_read511_truth64.json; the fp32 oracle sits 1.5e-4 / 6e-5
+    # from it for this pair).  Everything else against that answer too, at the tolerances above.
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_read511_truth64.json")))
+    truth, orc = doc["truth64_rounds"][-1], doc["oracle_fp32_rounds"][-1]
+    assert doc["read"] == r and np.allclose(orc["pm"], pm, rtol=1e-6, atol=1e-7), (orc["pm"], pm)       # the fixture is this pair's oracle loop
+    t_pm, t_st = np.array(truth["pm"]), np.array(truth["st"])
+    for q, tol in ((0, 2e-4), (4, 2e-4), (3, 5e-4), (5, 5e-4)):
+        assert abs(got[q] - t_pm[q]) <= tol * abs(t_pm[q]), (q, got, t_pm)
+        assert abs(pm[q] - t_pm[q]) <= tol * abs(t_pm[q]), ("oracle", q, pm, t_pm)
+    assert abs(got[1] - t_pm[1]) <= 2e-4 * 60 and abs(got[2] - t_pm[2]) <= 2e-4 * 60 / float(start[int(so[2 * r + 1]) - 1])
+    assert np.allclose(out["st"][k], t_st, rtol=5e-4, atol=0), (out["st"][k], t_st)
+    assert abs(out["fit"][k] - truth["fit"]) <= 1e-4 * abs(truth["fit"])
     # (4) decode with the trained parameters
     bc = gpu_ctx.basecall_reads(opts, states, so, mean, stdv, start, jr, j0, j1, out["pm"], out["st"])
     assert (bc["best_job"] >= 0).all() and (bc["best_job"][:, 0] == bc["best_job"][:, 1]).all()

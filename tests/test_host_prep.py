@@ -109,3 +109,29 @@ def test_host_abi_under_sanitizers():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "host ABI under ASan/UBSan: ok" in r.stdout and "batch plans: ok" in r.stdout and "combiner:" in r.stdout
     assert "sweep choice: ok" in r.stdout
+
+
+def test_sweep_plan_holds_on_machines_that_run_at_other_rates(tmp_path):
+    """tools/plan_props.cpp: the choice between the forms of the Viterbi sweep (nchmm_plan.hpp: choose_sweep / plan_ahead /
+    choose_sweep_bounds) prices them with event rates measured at one clock (2.1 GHz); the boxes of the pool sustain 1.9-2.35 GHz.
+    Over 600 random batch shapes x four scale factors x eight groups of rates: a common factor changes nothing; on a machine whose
+    compute rates are 0.9-1.1 x the built-in ones the decision costs at most 5 % of the best form's duration (10 % at 0.8 / 1.25),
+    and changes only near the break-even; with the clock known to 5 % (rates_at_clock: a context that has measured it, or
+    NCHMM_PLAN_CLOCK_MHZ) at most 5 % everywhere; the three-number form of device-pointer callers is within 5 % of the best form it
+    can be given on equal-length batches.  Built with UBSan (the same functions run under ASan in test_host_abi_under_sanitizers)."""
+    import json
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "plan_props"
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(root, "nanocall_amd", "csrc"),
+                        os.path.join(root, "tools", "plan_props.cpp"), "-o", str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), "600"], capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and d["ok"], d
+    g = d["groups"]
+    assert g["uniform"]["form_changes"] == 0 and g["clock"]["worst_regret_within_10_percent"] <= 0.05 and g["clock_known"]["worst_regret"] <= 0.05
+    assert all(v["changes_away_from_break_even"] == 0 for v in g.values())

@@ -180,7 +180,149 @@ def truth_all_rounds():
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 3, one read's pair, FREE-RUNNING: four EM rounds in float64, each from the float64 result of the one before --
+# scaling AND transitions (Parameter_Trainer.hpp:230-427, :434-532) -- beside the same loop on the fp32 oracle.  What
+# tests/test_fullsize_gpu.py holds the GPU's var / var_sd of that pair to: the reference's own fp32 arithmetic compounds its
+# per-round noise over the rounds, and the distance of the oracle to this real-number answer is the yardstick.
+# ------------------------------------------------------------------------------------------------
+GOLDEN_C3 = os.path.join(ROOT, "tests", "golden", "config3_read511_truth64.json")
+
+
+def scaled_t6_f64(unscaled, pm):
+    """Pore_Model::scale (Pore_Model.hpp:190-201) in float64 -> the columns emission64 reads (0 mu, 1 sigma, 3 eta, 4 lambda)"""
+    scale, shift, drift, var, scale_sd, var_sd = (float(v) for v in pm)
+    t6 = np.zeros((S, 6))
+    t6[:, 0] = unscaled[:, 0] * scale + shift
+    t6[:, 1] = unscaled[:, 1] * var
+    t6[:, 3] = unscaled[:, 2] * scale_sd
+    t6[:, 4] = unscaled[:, 4] * var_sd
+    return t6
+
+
+def emission64_tab(t6, x, y):
+    mu, sg, eta, lam = t6[:, 0], t6[:, 1], t6[:, 3], t6[:, 4]
+    a = (x - mu) / sg
+    return (-np.log(sg) - (LOG_2PI + a * a) / 2.0) + (np.log(lam) - LOG_2PI - 3.0 * np.log(y) - lam * (y - eta) ** 2 / (eta * eta * y)) / 2.0
+
+
+def train_st64(al, be, lpd, E, kmers, p_stay, p_skip):
+    """the three log-sums of train_st_params (Parameter_Trainer.hpp:451-515) over one window, float64 -> (denom, stay, skip) as lists of log terms"""
+    lp_stay, lp_step4 = np.log(p_stay), np.log((1.0 - p_stay - p_skip) / 4.0)
+    j1 = kmers
+    n = al.shape[0]
+    lp = al[:-1][:, j1] + be[:-1][:, j1] - lpd                                   # log P(S_i = j1)
+    tail = E[1:] + be[1:]                                                          # emis(j2, e_{i+1}) + beta_{i+1}(j2)
+    stay = np.minimum(al[:-1][:, j1] + lp_stay + tail[:, j1] - lpd, lp)            # :470-488
+    terms = [stay]
+    for b in range(4):
+        j2 = ((j1 << 2) | b) & 4095
+        terms.append(al[:-1][:, j1] + lp_step4 + tail[:, j2] - lpd)
+    d01 = np.minimum(lse(np.stack(terms, 0), 0), lp)                               # :489-510
+    with np.errstate(divide="ignore"):
+        skip = np.log(np.exp(lp) - np.exp(d01))                                    # :511-512
+    return lp.ravel(), stay.ravel(), skip.ravel()
+
+
+def em_free_running64(tabs_unscaled, windows, strands, rounds, train_drift):
+    """windows: [(mean, stdv, start)] raw fp32 events; strands: their strand.  -> per round {fit, pm[6], st[4]} in float64"""
+    kmers = np.asarray(na.st_train_kmers(), np.int64)
+    pm = np.array([1, 0, 0, 1, 1, 1], np.float64)
+    st = np.array([[0.1, 0.3], [0.1, 0.3]], np.float64)                             # (p_stay, p_skip) per strand
+    out = []
+    for _ in range(rounds):
+        t6 = [scaled_t6_f64(u, pm) for u in tabs_unscaled]
+        tr = [na.transitions_fast(float(st[s, 1]), float(st[s, 0])) for s in range(2)]
+        fit = 0.0
+        sums, xs, ys, ts = [], [], [], []
+        logs = {0: [[], [], []], 1: [[], [], []]}
+        for (mean, stdv, start), s in zip(windows, strands):
+            x, y, t = mean.astype(np.float64), stdv.astype(np.float64), start.astype(np.float64)
+            cm = x - pm[2] * t
+            n = len(x)
+            rp, pred, logw = tr[s]
+            E = np.stack([emission64_tab(t6[s], cm[i], y[i]) for i in range(n)])
+            # forward-backward on these emissions (fwbw64's recursions)
+            deg = np.diff(rp.astype(np.int64)); dmax = int(deg.max())
+            if "P" not in em_free_running64.__dict__:
+                P = np.zeros((S, dmax), np.int64); SP = [[] for _ in range(S)]
+                for j in range(S):
+                    a, b = int(rp[j]), int(rp[j + 1])
+                    P[j, : b - a] = pred[a:b]
+                    for k in range(a, b): SP[int(pred[k])].append((j, k))
+                smax = max(len(v) for v in SP)
+                Q = np.zeros((S, smax), np.int64); QK = np.full((S, smax), -1, np.int64)
+                for p_, v in enumerate(SP):
+                    for k, (j, kk) in enumerate(v): Q[p_, k] = j; QK[p_, k] = kk
+                em_free_running64.P, em_free_running64.Q, em_free_running64.QK = P, Q, QK           # (the topology does not depend on the weights)
+            P, Q, QK = em_free_running64.P, em_free_running64.Q, em_free_running64.QK
+            W = np.full(P.shape, -np.inf)
+            for j in range(S):
+                a, b = int(rp[j]), int(rp[j + 1]); W[j, : b - a] = logw[a:b]
+            V = np.where(QK >= 0, logw.astype(np.float64)[np.maximum(QK, 0)], -np.inf)
+            al = np.empty((n, S)); be = np.zeros((n, S))
+            al[0] = E[0] - np.log(float(S))
+            for i in range(1, n): al[i] = E[i] + lse(W + al[i - 1][P], 1)
+            for i in range(n - 2, -1, -1): be[i] = lse(V + (E[i + 1] + be[i + 1])[Q], 1)
+            lpd = lse(al[n - 1], 0)
+            fit += lpd
+            p = np.exp(al + be - lpd)
+            u = tabs_unscaled[s]
+            u0 = 1.0 / (u[:, 1] ** 2)
+            sm = np.stack([p @ u0, p @ (u0 * u[:, 0]), p @ (u0 * u[:, 0] ** 2), p @ u[:, 4], p @ (u[:, 4] / u[:, 2]), p @ (u[:, 4] / u[:, 2] ** 2)], 1)
+            sums.append(sm); xs.append(x); ys.append(y); ts.append(t)
+            for acc, v in zip(logs[s], train_st64(al, be, lpd, E, kmers, st[s, 0], st[s, 1])): acc.append(v)
+        new_pm = finish64(np.concatenate(sums), np.concatenate(xs), np.concatenate(ys), np.concatenate(ts), pm, train_drift)
+        new_st = st.copy()
+        for s in (0, 1):
+            if not logs[s][0]: continue
+            denom, stay, skip = (lse(np.concatenate(v), 0) for v in logs[s])
+            new_st[s] = np.clip([np.exp(stay - denom), np.exp(skip - denom)], 0.05, 0.4)      # :516-530
+        out.append({"fit": float(fit), "pm": [float(v) for v in new_pm], "st": [float(v) for v in new_st.ravel()]})
+        pm, st = new_pm, new_st
+    return out
+
+
+def config3_read_truth(read=511, n_ev=5000, half=100):
+    """the pair (r73.t, r73.c.p1) of read `read` of BASELINE config 3 as tests/test_fullsize_gpu.py and bench.py make it"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nc_oracle as oracle
+    from nanocall_amd import synth
+    tabs = [na.builtin_model("r73.t"), na.builtin_model("r73.c.p1")]
+    unscaled = [na.model_load(t).astype(np.float64) for t in tabs]
+    e = [synth.generate(tabs[0], 1, n_ev, first_read=read), synth.generate(tabs[1], 1, n_ev, first_read=10 ** 6 + read)]
+    windows, strands = [], []
+    for s in (0, 1):
+        m, sd, t = e[s]["mean"][0], e[s]["stdv"][0], e[s]["start"][0]
+        _, sd, _ = na.events_prepare(m, sd, None, 0.0)
+        for sl in (slice(0, half), slice(n_ev - half, n_ev)):
+            windows.append((m[sl], sd[sl], t[sl])); strands.append(s)
+    truth = em_free_running64(unscaled, windows, strands, 4, True)
+    # the same loop on the fp32 oracle (the reference's arithmetic), free-running from its own results
+    off = np.concatenate([[0], np.cumsum([len(w[0]) for w in windows])]).astype(np.uint64)
+    cat = lambda k: np.concatenate([w[k] for w in windows])
+    pm, st = np.float32([1, 0, 0, 1, 1, 1]), np.float32([0.1, 0.3, 0.1, 0.3])
+    orc = []
+    for _ in range(4):
+        r = oracle.train_one_round(off, np.asarray(strands, np.uint32), cat(0), cat(1), cat(2), tabs[0], tabs[1], pm, st, 0.1, 0.3, 1, True, True)
+        orc.append({"fit": float(r["fit"]), "pm": [float(v) for v in r["pm"]], "st": [float(v) for v in r["st"]]})
+        pm, st = r["pm"], r["st"]
+    return {"made_by": "tools/fb_truth.py --config3-read", "read": read, "events_per_strand": n_ev, "window_events": half,
+            "pair": ["r73.t", "r73.c.p1"], "truth64_rounds": truth, "oracle_fp32_rounds": orc}
+
+
 def main():
+    if "--config3-read" in sys.argv:
+        doc = config3_read_truth()
+        names = ["scale", "shift", "drift", "var", "scale_sd", "var_sd"]
+        t, o = doc["truth64_rounds"][-1], doc["oracle_fp32_rounds"][-1]
+        doc["oracle_rel_distance_after_4_rounds"] = {n: abs(o["pm"][k] - t["pm"][k]) / {1: 60.0, 2: 60.0 / 100.0}.get(k, abs(t["pm"][k])) for k, n in enumerate(names)}
+        doc["oracle_rel_distance_after_4_rounds"]["st"] = [abs(a - b) / abs(b) for a, b in zip(o["st"], t["st"])]
+        with open(GOLDEN_C3, "w") as f:
+            json.dump(doc, f, indent=1)
+        print(json.dumps(doc["oracle_rel_distance_after_4_rounds"]))
+        print("wrote", GOLDEN_C3)
+        return
     if "--golden-all" in sys.argv:
         with open(GOLDEN_ALL, "w") as f:
             json.dump({"made_by": "tools/fb_truth.py --golden-all", "rounds": truth_all_rounds()}, f, indent=1)
