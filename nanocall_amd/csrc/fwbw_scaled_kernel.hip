@@ -173,6 +173,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                         ah[q] = ex2(k0[q] - xs(ev.x, ev.y, ev.z, mu[q], r2[q], eta[q], lq[q]));
                 } else {
                     // Forward_Backward.hpp:72-89: group sums of the previous column
+                    // (producer phase at raised priority, as in the backward sweep: 1.35 -> 1.29 ms; profiles/r06_fb_backward_session.md)
+                    __builtin_amdgcn_s_setprio(2);
                     const float a = (ah[0] + ah[2]) + (ah[4] + ah[6]);   // y = h
                     const float b = (ah[1] + ah[3]) + (ah[5] + ah[7]);   // y = h + 2
                     const float s8 = a + b;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                     if (h == 0) sG2[buf][t] = s16 * W2;
                     const float z = wave_sum_lane63(s8);
                     if (lane == 63) sZ[buf][wave] = z;
+                    __builtin_amdgcn_s_setprio(0);
                     __syncthreads();
                     const float4 z0 = *reinterpret_cast<const float4*>(&sZ[buf][0]);
                     const float4 z1 = *reinterpret_cast<const float4*>(&sZ[buf][4]);
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_scaled_kernel(FwbwAr
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float E = ex2(k0[q] - xs(ev.x, ev.y, ev.z, mu[q], r2[q], eta[q], lq[q]));
+                        const float dx = ev.x - mu[q], dyp = __builtin_fmaf(-eta[q], ev.z, ev.y);
+                        const float E = ex2(__builtin_fmaf(-(dx * dx), r2[q], __builtin_fmaf(-(dyp * dyp), lq[q], k0[q])));
                         ah[q] = E * __builtin_fmaf(W1[q], in1[q], __builtin_fmaf(T0[q], ah[q], in2[q])) * sc;
                     }
                 }
