@@ -356,7 +356,13 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             sCoef[tau][0] = k_a; sCoef[tau][1] = k_b; sCoef[tau][2] = k_c;   // read back by the same thread only
         }
         const int Iaf = iexp[n - 1];
-        const float rZ = 1.0f / P.ws_zfin[w];
+        // 1 / Z as an exact power of two times a factor in (1/2, 1]: Z may be as small as 2^-100 (below that the forward sweep has
+        // flagged the window), and kappa = 2^(Ia + Ib - Ia_final) / Z must not be formed as a product of two factors of up to 2^100
+        // each -- round 5 did, and a window with an abasic stretch came back with infinite sums (tools/fb_sweep.py, round 6)
+        const float Zfin = P.ws_zfin[w];
+        const int ez = exponent_of(Zfin);
+        const float rZm = pow2i(ez) / Zfin;
+        const float rZ = 1.0f / Zfin;
         int Ib = 0;
         bool bad = false;
         float acc_p = 0, acc_stay = 0, acc_p01 = 0;
@@ -456,13 +462,13 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_scaled_kernel(FwbwA
             const float4 z1 = *reinterpret_cast<const float4*>(&sZ[buf][4]);
             const float Zg = ((z0.x + z0.y) + (z0.z + z0.w)) + ((z1.x + z1.y) + (z1.z + z1.w));
             // statistics of event i-1 are in units of (ahat_{i-1} g): kappa = 2^(Ia_{i-1} + Ib_i - Ia_{n-1}) / Z
-            const int kx = nx_ia + Ib - Iaf;
+            const int kx = nx_ia + Ib - Iaf - ez;
             float sc = 1.0f, kappa = 0.0f;
             if (Zg >= kMinTotal && kx >= -kMaxKappaExp && kx <= kMaxKappaExp) {
                 const int eg = exponent_of(Zg);
                 sc = pow2i(-eg);
                 Ib += eg;
-                kappa = pow2i(kx) * rZ;
+                kappa = pow2i(kx) * rZm;
             } else {
                 bad = true;
             }

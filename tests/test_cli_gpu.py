@@ -567,3 +567,23 @@ def test_a_worker_process_that_dies_is_reported_and_the_others_records_are_all_t
     assert list(got) == [k for k in ref if k in got]                 # input order kept
     lost = int(bad.stderr.split("failed with signal 6: ")[1].split()[0])
     assert lost >= 1 and "workers=3" in bad.stderr
+
+
+def test_more_worker_processes_than_input_files(tmp_path):
+    """Four workers, two files: two workers have nothing to decode -- they still answer the counter reduction, and the output is the
+    single-process one."""
+    files = [os.path.join(G, n + ".fast5") for n in ("r73_2d_a", "r73_1d_b")]
+    base = ["--pore", "r73", "--no-train", "--stats", str(tmp_path / "s.tsv")] + files
+    ref = run_cli(base)
+    st_ref = (tmp_path / "s.tsv").read_text()
+    got = run_cli(base, env={"NANOCALL_WORKER_DEVICES": "0,0,0,0"})
+    assert got.stdout == ref.stdout and (tmp_path / "s.tsv").read_text() == st_ref
+    assert "files_per_worker=[1,1,0,0]" in got.stderr
+    c = [l for l in got.stderr.splitlines() if "counters reads=" in l and "worker_counters" not in l][-1]
+    c_ref = [l for l in ref.stderr.splitlines() if "counters reads=" in l][-1]
+    assert _pick(c, "events_decoded") == _pick(c_ref, "events_decoded") and _pick(c, "workers") == "4"
+
+
+def test_gpus_option_beyond_the_visible_devices_is_refused():
+    p = run_cli(["--pore", "r73", "--no-train", "--gpus", "64", os.path.join(G, "r73_1d_b.fast5")], expect_rc=1)
+    assert "--gpus 64 requested but only" in p.stderr

@@ -550,3 +550,26 @@ def test_forward_backward_budget_cuts_batches_into_ranges(r73t):
         assert np.array_equal(fb1[k], fb2[k]), k
     for k in ("log_pr_data", "alpha", "beta"):                     # log-space pair with matrices: 3 x 16 KiB per event
         assert np.array_equal(fbm1[k], fbm2[k]), k
+
+
+def test_windows_with_an_abasic_stretch_keep_finite_statistics():
+    """Round 6 (tools/fb_sweep.py with the event kinds of tests/adversarial.py): a window whose final column total is ~2^-60 and
+    whose forward / backward exponents are ~+60 apart made the rescaled backward sweep form kappa = 2^kx / Z as a product of two
+    factors that overflows -- infinite per-event sums, NaN transition sums, and a log-likelihood 1.3e-4 off, unflagged.  kappa is
+    now one exact power of two times a factor in (1/2, 1], and the range test covers the combined exponent (such windows are redone
+    in log space).  Configurations 10 and 31 of that sweep (seed 424242) are the two windows that showed it."""
+    import fb_sweep
+    from nanocall_amd import models
+    meta, tables = models._load()
+    with na.Context(0) as ctx:
+        for c in (10, 31):
+            cfg = fb_sweep.make_config(c)
+            assert "abasic" in cfg["kinds"]
+            ctx.put_model(0, na.scaled_model_table(tables[cfg["model"]], cfg["params"]))
+            ctx.put_transitions(0, *na.transitions_fast(*cfg["trans"]))
+            out = ctx.fwbw(cfg["off"], cfg["cm"], cfg["sd"], cfg["ls"], pm_params=cfg["params"],
+                           st_params=np.tile(np.float32([cfg["trans"][1], cfg["trans"][0]]), (fb_sweep.N_WIN, 1)))
+            assert np.isfinite(out["pm_sums"]).all() and not np.isnan(out["st_sums"]).any(), c
+            lpd = cfg["lpd"]
+            assert np.isfinite(lpd).all()
+            assert (np.abs(out["log_pr_data"].astype(np.float64) - lpd) <= 1e-4 * np.abs(lpd)).all(), (c, out["log_pr_data"], lpd)

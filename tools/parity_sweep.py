@@ -114,6 +114,7 @@ def main():
     line = json.dumps(out)
     print(line)
     if os.environ.get("OUT"):
+        os.makedirs(os.path.dirname(os.path.abspath(os.environ["OUT"])), exist_ok=True)
         with open(os.environ["OUT"], "w") as fh:
             fh.write(line + "\n")
     return 1 if out["mismatches"] else 0
