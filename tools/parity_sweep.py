@@ -13,7 +13,11 @@ by the tie rule) -- the contract (Viterbi.hpp:79-89,125-132) rests on them.
 The inputs and the oracle's decode of a configuration are made by worker PROCESSES (they never touch the GPU); the parent decodes.
 
   CONFIGS=500 READS=6 LONGEST=30000 FORMS=wide,ll,ahead WORKERS=48 OUT=gpurun_out/parity_sweep.json python tools/parity_sweep.py
-  KINDS=matched  LONGEST=2500 reproduces the round-5 sweep's distribution."""
+  KINDS=matched  LONGEST=2500 reproduces the round-5 sweep's distribution.
+  APIS=host,raw,dev,strand: which entry points decode every configuration (default host = nchmm_viterbi):
+    raw     nchmm_viterbi_raw: raw events in, drift correction + log(stdv) on the device (the glibc logf port)
+    dev     nchmm_viterbi_dev: device pointers, the plan made on the device from the offsets (longest-first order, outliers)
+    strand  nchmm_viterbi_strand: one strand per call from a thread per read, combined into launches by the library"""
 import json
 import multiprocessing as mp
 import os
@@ -50,11 +54,11 @@ def make_config(c):
     lens = adversarial.log_uniform_lengths(rng, N_READS, LONGEST)
     read_kinds = [kinds[int(rng.integers(len(kinds)))] for _ in lens]
     other = tables[(m + 1 + int(rng.integers(len(tables) - 1))) % len(tables)]
-    cms, sds, lss = [], [], []
+    cms, sds, lss, raws = [], [], [], []
     for r, (n, kind) in enumerate(zip(lens, read_kinds)):
         mean, stdv, start = adversarial.events(kind, table, params, n, seed=1000 * c + r, other_table=other)
         cm, sd, ls = na.events_prepare(mean, stdv, start, params[2])
-        cms.append(cm); sds.append(sd); lss.append(ls)
+        cms.append(cm); sds.append(sd); lss.append(ls); raws.append((mean, stdv, start))
     om, ot = oracle.Model(table, params), oracle.Transitions(p_skip, p_stay)
     want = []
     for cm, sd, ls in zip(cms, sds, lss):
@@ -62,7 +66,8 @@ def make_config(c):
         want.append((s, np.float32(lp)))
     return dict(c=c, model=m, name=meta["names"][m], params=params, trans=(p_skip, p_stay), lens=lens, kinds=read_kinds,
                 off=np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64), cm=np.concatenate(cms), sd=np.concatenate(sds),
-                ls=np.concatenate(lss), want=want)
+                ls=np.concatenate(lss), want=want, raw_mean=np.concatenate([x[0] for x in raws]), raw_stdv=np.concatenate([x[1] for x in raws]),
+                raw_start=np.concatenate([x[2] for x in raws]))
 
 
 def main():
@@ -81,31 +86,70 @@ def main():
         ctxs[f] = na.Context(0)
         ctxs[f].set_sweep(f)
     del os.environ["NCHMM_PROFILE"]
+    apis = [a for a in os.environ.get("APIS", "host").split(",") if a]
+    if "dev" in apis:
+        import torch
+        dev = torch.device("cuda", 0)
+    if "strand" in apis:
+        from concurrent.futures import ThreadPoolExecutor
+        strand_pool = ThreadPoolExecutor(max(8, N_READS))
+
+    def decode(ctx, api, cfg, table):
+        """-> (states, logp, status) of every read of the configuration through one entry point"""
+        off = cfg["off"]
+        n = len(off) - 1
+        lens = np.diff(off.astype(np.int64))
+        if api == "host":
+            return ctx.viterbi(off, cfg["cm"], cfg["sd"], cfg["ls"])
+        if api == "raw":
+            return ctx.viterbi_raw(cfg["raw_mean"], cfg["raw_stdv"], cfg["raw_start"], off[:-1].astype(np.uint64), lens.astype(np.uint32), np.full(n, cfg["params"][2], np.float32))
+        if api == "dev":
+            d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (off.astype(np.int64), cfg["cm"], cfg["sd"], cfg["ls"])]
+            total = int(off[-1])
+            d_state = torch.empty(max(total, 1), dtype=torch.int16, device=dev)
+            d_logp = torch.empty(n, dtype=torch.float32, device=dev)
+            d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.viterbi_dev(n, int(lens.max()), total, *d, d_state, d_logp, d_status)
+            torch.cuda.synchronize()
+            ctx.use_own_stream()
+            return d_state.cpu().numpy().view(np.uint16)[:total], d_logp.cpu().numpy(), d_status.cpu().numpy()
+        if api == "strand":
+            t6 = na.scaled_model_table(table, cfg["params"])
+            futs = [strand_pool.submit(ctx.viterbi_strand, t6, cfg["trans"][0], cfg["trans"][1], cfg["cm"][int(off[r]):int(off[r + 1])],
+                                       cfg["sd"][int(off[r]):int(off[r + 1])], cfg["ls"][int(off[r]):int(off[r + 1])]) for r in range(n)]
+            got = [f.result() for f in futs]
+            return (np.concatenate([g[0] for g in got]), np.array([g[1] for g in got], np.float32), np.array([0 if g[2] == 0 else 1 for g in got], np.int32))
+        raise ValueError(api)
+
     stats = {f: dict(mismatches=0, rescans=0, tie_rule_cells=0) for f in forms}
+    api_reads = {a: 0 for a in apis}
     by_kind = {}
     events = reads = longest_seen = 0
     for cfg in todo:
         table = tables[cfg["model"]]
         for f in forms:
             ctx = ctxs[f]
-            ctx.put_model(0, na.scaled_model_table(table, cfg["params"]))
-            ctx.put_transitions(0, *na.transitions_fast(*cfg["trans"]))
-            states, logp, status = ctx.viterbi(cfg["off"], cfg["cm"], cfg["sd"], cfg["ls"])
-            tk = ctx.profile_ticks()
-            stats[f]["rescans"] += int(tk[6]); stats[f]["tie_rule_cells"] += int(tk[7])
-            for r, (n, (s, lp)) in enumerate(zip(cfg["lens"], cfg["want"])):
-                a, b = int(cfg["off"][r]), int(cfg["off"][r + 1])
-                ok = status[r] == 0 and np.array_equal(s, states[a:b]) and np.float32(lp).tobytes() == np.float32(logp[r]).tobytes()
-                if not ok:
-                    stats[f]["mismatches"] += 1
-                    print(f"MISMATCH form {f} config {cfg['c']} model {cfg['name']} params {cfg['params']} trans {cfg['trans']} read {r} "
-                          f"kind {cfg['kinds'][r]} len {n}", flush=True)
+            for api in apis:
+                ctx.put_model(0, na.scaled_model_table(table, cfg["params"]))
+                ctx.put_transitions(0, *na.transitions_fast(*cfg["trans"]))
+                states, logp, status = decode(ctx, api, cfg, table)
+                tk = ctx.profile_ticks()
+                stats[f]["rescans"] += int(tk[6]); stats[f]["tie_rule_cells"] += int(tk[7])
+                api_reads[api] += len(cfg["lens"])
+                for r, (n, (s, lp)) in enumerate(zip(cfg["lens"], cfg["want"])):
+                    a, b = int(cfg["off"][r]), int(cfg["off"][r + 1])
+                    ok = status[r] == 0 and np.array_equal(s, states[a:b]) and np.float32(lp).tobytes() == np.float32(logp[r]).tobytes()
+                    if not ok:
+                        stats[f]["mismatches"] += 1
+                        print(f"MISMATCH form {f} api {api} config {cfg['c']} model {cfg['name']} params {cfg['params']} trans {cfg['trans']} read {r} "
+                              f"kind {cfg['kinds'][r]} len {n}", flush=True)
         for n, k in zip(cfg["lens"], cfg["kinds"]):
             by_kind[k] = by_kind.get(k, 0) + 1
             events += n; reads += 1; longest_seen = max(longest_seen, n)
     pool.close(); pool.join()
     out = {"configs": n_cfg, "reads_per_config": N_READS, "reads_checked_per_form": reads, "events_per_form": events, "longest_read": longest_seen,
-           "length_distribution": f"log-uniform over [1, {LONGEST}]", "reads_by_kind": by_kind, "forms": stats,
+           "length_distribution": f"log-uniform over [1, {LONGEST}]", "reads_by_kind": by_kind, "forms": stats, "read_decodes_by_entry_point": api_reads,
            "launches_wide_ll_reads_wide_ll": {f: list(ctxs[f].sweep_stats()) for f in forms},
            "ahead_launches_reads_events": {f: list(ctxs[f].ahead_stats()) for f in forms},
            "mismatches": sum(s["mismatches"] for s in stats.values()), "seed": SEED, "oracle_workers": workers, "seconds": round(time.time() - t0, 1)}
