@@ -79,7 +79,7 @@ def check_free_running(o, inputs, dump, fasta):
         pm, got = info["pm"], d["pm"]
         assert abs(got[0] - pm[0]) <= 2e-4 * abs(pm[0]) and abs(got[4] - pm[4]) <= 2e-4 * abs(pm[4]), (name, got, pm)
         assert abs(got[1] - pm[1]) <= 2e-4 * 60 and abs(got[2] - pm[2]) <= 2e-4 * 60 / 5.0, (name, got, pm)
-        assert abs(got[3] - pm[3]) <= 1.5e-3 * abs(pm[3]) and abs(got[5] - pm[5]) <= 1.5e-3 * abs(pm[5]), (name, got, pm)
+        assert abs(got[3] - pm[3]) <= 1e-3 * abs(pm[3]) and abs(got[5] - pm[5]) <= 1e-3 * abs(pm[5]), (name, got, pm)  # (free-running rounds against the fp32 ORACLE: 1e-3 -- 48 full-size jobs measured at most 6.9e-4 / 2.1e-4, profiles/r06_notes.md section 4; against a float64 evaluation the bound is 5e-4, tests/test_fullsize_gpu.py)
         assert np.allclose(d["st"], info["st"], rtol=5e-4, atol=0), (name, d["st"], info["st"])
         assert abs(d["logp"] - info["logp"]) <= 1e-4 * abs(info["logp"]), (name, d["logp"], info["logp"])
     for r in reads:

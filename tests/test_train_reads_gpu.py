@@ -86,7 +86,7 @@ def test_train_reads_matches_reference_loop(gpu_ctx):
         # var, var_sd: ill-conditioned (fp32 reference noise ~1e-4 per round, test_fwbw_gpu.py) and this loop
         # runs free, each round starting from its own previous parameters
         for q in (3, 5):
-            assert abs(got[q] - pm[q]) <= 1.5e-3 * abs(pm[q]), (k, q, got, pm)
+            assert abs(got[q] - pm[q]) <= 1e-3 * abs(pm[q]), (k, q, got, pm)  # (free-running rounds against the fp32 ORACLE: 1e-3 -- 48 full-size jobs measured at most 6.9e-4 / 2.1e-4, profiles/r06_notes.md section 4; against a float64 evaluation the bound is 5e-4, tests/test_fullsize_gpu.py)
         assert abs(got[1] - pm[1]) <= 2e-4 * 60 and abs(got[2] - pm[2]) <= 2e-4 * 60 / max(float(start.max()), 1.0)
         assert np.allclose(out["st"][k], st, rtol=5e-4, atol=0), (k, out["st"][k], st)
     # selection: read 0's pair trained on the matching complement model must win by > threshold or not at all,

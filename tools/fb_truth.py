@@ -311,7 +311,34 @@ def config3_read_truth(read=511, n_ev=5000, half=100):
             "pair": ["r73.t", "r73.c.p1"], "truth64_rounds": truth, "oracle_fp32_rounds": orc}
 
 
+GOLDEN_CPP = os.path.join(ROOT, "tests", "golden", "cpp_layer_read900_truth64.json")
+
+
+def cpp_layer_truth():
+    """the 2D read of tests/test_cpp_layer_gpu.py (template 420 events from r73.t, complement 380 from r73.c.p2, windows of 60 events),
+    four free-running rounds in float64, with and without drift training"""
+    from nanocall_amd import synth
+    names = ["r73.t.006.ont.model", "r73.c.p2.006.ont.model"]
+    tabs = [na.builtin_model(n) for n in names]
+    unscaled = [na.model_load(t).astype(np.float64) for t in tabs]
+    evs = [synth.generate(tabs[0], 1, 420, first_read=900), synth.generate(tabs[1], 1, 380, first_read=901)]
+    windows, strands = [], []
+    for s_, e in enumerate(evs):
+        m, sd, t = e["mean"][0], na.events_prepare(e["mean"][0], e["stdv"][0], None, 0.0)[1], e["start"][0]
+        n = len(m)
+        half = min(120, n) // 2
+        for sl in (slice(0, half), slice(n - half, n)):
+            windows.append((m[sl], sd[sl], t[sl])); strands.append(s_)
+    return {"made_by": "tools/fb_truth.py --cpp-layer-read", "models": names, "scaling_num_events": 120,
+            "rounds_by_train_drift": {str(d): em_free_running64(unscaled, windows, strands, 4, bool(d)) for d in (1, 0)}}
+
+
 def main():
+    if "--cpp-layer-read" in sys.argv:
+        with open(GOLDEN_CPP, "w") as f:
+            json.dump(cpp_layer_truth(), f, indent=1)
+        print("wrote", GOLDEN_CPP)
+        return
     if "--config3-read" in sys.argv:
         doc = config3_read_truth()
         names = ["scale", "shift", "drift", "var", "scale_sd", "var_sd"]
