@@ -174,13 +174,19 @@ public:
                 // initial model scalings, :223-278
                 t.events.resize(num_ed_events);
                 ed_events_ptr.reset(new std::vector<nchmm_ed_event>(std::move(t.events)));
-                load_events();
+                // The reference loads the strands' Event objects here (load_events(), three logs per event) only to take the mean and
+                // stdv of their levels (:223-234) and drops them again (:317).  The same numbers come from the filtered level means
+                // alone -- nchmm_read_load_events is what load_events() fills its Events from -- at a third of the summary pass's cost.
                 std::array<std::array<float, 2>, 2> r{};
+                std::array<size_t, 2> n_events{{0, 0}};
                 for (unsigned st = 0; st < 2; ++st) {
-                    if (events(st).size() < min_ed_events()) continue;
-                    std::vector<float> mv(events(st).size());
-                    for (size_t i = 0; i < mv.size(); ++i) mv[i] = events(st)[i].mean;
-                    check(nchmm_mean_stdv(mv.size(), mv.data(), &r[st][0], &r[st][1]), "nchmm_mean_stdv");
+                    const size_t cap = strand_bounds[2 * st + 1] > strand_bounds[2 * st] ? strand_bounds[2 * st + 1] - strand_bounds[2 * st] : 0;
+                    if (cap == 0) continue;
+                    std::vector<float> buf(4 * cap);
+                    check(nchmm_read_load_events(&s, ed_events_ptr->data(), sampling_rate, (int)st, buf.data(), buf.data() + cap, buf.data() + 2 * cap,
+                                                 buf.data() + 3 * cap, &n_events[st]), "nchmm_read_load_events");
+                    if (n_events[st] < min_ed_events()) continue;
+                    check(nchmm_mean_stdv(n_events[st], buf.data(), &r[st][0], &r[st][1]), "nchmm_mean_stdv");
                 }
                 if (scale_strands_together) {
                     for (const auto& p0 : models) {
@@ -198,7 +204,7 @@ public:
                     }
                 } else {
                     for (unsigned st = 0; st < 2; ++st) {
-                        if (events(st).size() < min_ed_events()) continue;
+                        if (n_events[st] < min_ed_events()) continue;
                         for (const auto& p : models) {
                             if (!(p.second.strand() == st || p.second.strand() == 2)) continue;
                             std::array<std::string, 2> m_name;

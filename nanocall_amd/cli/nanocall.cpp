@@ -1166,9 +1166,13 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
     }
     uint64_t counters[4] = {0, 0, 0, 0};   // reads, bases, training us, basecalling us
     // is there a device at all?  (before any file is read: a machine without one fails at once)
+    // (nothing to train and nothing to decode -- `--no-train --no-basecall --stats f`: segmentation and initial scalings only, as
+    // the reference allows -- is host work: no device is asked for)
+    const bool need_device = opts::train || opts::basecall;
     int use = 0, n_dev = 0;
-    int dc_rc;
-    { STAGE("device_count_s"); dc_rc = nchmm_device_count(&n_dev); }
+    int dc_rc = NCHMM_OK;
+    if (need_device) { STAGE("device_count_s"); dc_rc = nchmm_device_count(&n_dev); }
+    else { n_dev = 1; LOG(info) << "devices=0 (no training, no basecalling: the summary pass only)" << std::endl; }
     if (dc_rc != NCHMM_OK || n_dev < 1) {
         LOG(error) << "no usable GPU: this build of nanocall decodes on MI355X only (there is no CPU path)" << std::endl;
         return EXIT_FAILURE;
@@ -1252,7 +1256,7 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
         return EXIT_SUCCESS;
     };
     try {
-        const int rc = open_devices();
+        const int rc = need_device ? open_devices() : EXIT_SUCCESS;
         if (rc != EXIT_SUCCESS) { summary_pass.join(); return rc; }
     } catch (...) {
         summary_pass.join();
@@ -1284,10 +1288,11 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
             }
         }
         unsetenv("NCHMM_POOL_FORCE_RCCL");          // (this worker's own figures: a plain read-out; the reduction is across the workers)
-        check(nchmm_pool_counters(pool, dev, nullptr), "nchmm_pool_counters");
+        std::fill(dev, dev + 8, (uint64_t)0);
+        if (pool) check(nchmm_pool_counters(pool, dev, nullptr), "nchmm_pool_counters");
         if (link->use_rccl && link->rank == 0) {
             uint8_t id[NCHMM_RCCL_ID_BYTES];
-            const bool have = nchmm_rccl_unique_id(id) == NCHMM_OK;
+            const bool have = need_device && nchmm_rccl_unique_id(id) == NCHMM_OK;
             link->send('U', 0, have ? std::string(reinterpret_cast<const char*>(id), sizeof(id)) : std::string());
         }
         uint64_t mine[12] = {counters[0], counters[1], counters[2], counters[3]};
@@ -1301,9 +1306,9 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
             STAGE("counter_allreduce_s");
             used_rccl = nchmm_counters_allreduce(link->device, link->n_ranks, link->rank, id, red) == NCHMM_OK;
         }
+        if (pool) { STAGE("device_release_s"); nchmm_pool_destroy(pool); pool = nullptr; }
         LOG(info) << "worker_counters reads=" << counters[0] << " bases=" << counters[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
                   << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " training_secs=" << counters[2] / 1e6 << " basecalling_secs=" << counters[3] / 1e6 << std::endl;
-        { STAGE("device_release_s"); nchmm_pool_destroy(pool); }
         delete whole;
         LOG(info) << "worker_stage_wall_secs" << stage_clock.str() << std::endl;
         std::string g(1, used_rccl ? '\1' : '\0');
@@ -1314,11 +1319,12 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
         std::cout.flush(); std::cerr.flush(); std::clog.flush();
         std::_Exit(EXIT_SUCCESS);
     }
-    check(nchmm_pool_counters(pool, dev, &used_rccl), "nchmm_pool_counters");
+    std::fill(dev, dev + 8, (uint64_t)0);
+    if (pool) check(nchmm_pool_counters(pool, dev, &used_rccl), "nchmm_pool_counters");
     LOG(info) << "counters reads=" << counters[0] << " bases=" << counters[1] << " strands_decoded=" << dev[0] << " events_decoded=" << dev[1]
               << " fb_windows=" << dev[4] << " fb_event_rounds=" << dev[5] << " gathered_by=" << (used_rccl ? "rccl_allreduce" : "host_sum")
               << " training_secs=" << counters[2] / 1e6 << " basecalling_secs=" << counters[3] / 1e6 << std::endl;
-    { STAGE("device_release_s"); nchmm_pool_destroy(pool); }
+    if (pool) { STAGE("device_release_s"); nchmm_pool_destroy(pool); }
     delete whole;
     LOG(info) << "stage_wall_secs" << stage_clock.str() << std::endl;
     if (!opts::stats_fn.get().empty()) {   // nanocall.cpp:893-903
