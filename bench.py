@@ -64,6 +64,36 @@ def fb_kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time this process's cgroup allows (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited.  A container may
+    show 256 CPUs and be allowed the time of 16: threads beyond that are only throttled (measured on the boxes this runs on: 128
+    spinning processes do less work per second than 32)."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else -(-int(q) // int(p))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else -(-q // p)
+    except (OSError, ValueError):
+        return None
+
+
+def baseline_threads(cpu_threads, cap=None):
+    """threads of a CPU baseline: --cpu-threads if given, else one per physical core -- but no more than the cgroup's CPU quota, which
+    is what the host can actually run at once ("T = number of physical host cores used")"""
+    if cpu_threads:
+        return cpu_threads
+    logical, physical = physical_cores()
+    t = max(1, min(physical, logical))
+    q = cpu_quota_cores()
+    if q:
+        t = min(t, q)
+    return min(t, cap) if cap else t
+
+
 def physical_cores():
     """(logical CPUs usable by this process, physical cores behind them) from /proc/cpuinfo."""
     try:
@@ -122,10 +152,11 @@ def cpu_baseline(table, n_events, threads, n_reads):
         oracle.viterbi(om, ot, *prepped[r])
     dt1 = time.perf_counter() - t1
     logical, physical = physical_cores()
+    quota = cpu_quota_cores()
     return dict(value=n_reads * n_events / dt / 1e6, unit="Mevents/s", cores=threads, kind="port",
-                host_logical_cpus=logical, host_physical_cores=physical,
+                host_logical_cpus=logical, host_physical_cores=physical, host_cpu_quota_cores=quota,
                 sample=f"{n_reads} reads x {n_events} events of the same synthetic workload on {threads} read-parallel threads "
-                       f"(host: {logical} usable logical CPUs, {physical} physical cores; {-(-n_reads // threads)} read(s) per thread), "
+                       f"(host: {logical} usable logical CPUs, {physical} physical cores, cgroup CPU quota {quota if quota else 'none'}; {-(-n_reads // threads)} read(s) per thread), "
                        f"oracle/nc_oracle.c (reference matrix layout, 8 B per cell), {dt:.1f} s wall = {dt * threads:.0f} CPU-seconds; "
                        f"single_thread_value = {n_single} of those reads on one thread, {dt1:.1f} s",
                 single_thread_value=round(n_single * n_events / dt1 / 1e6, 5)), results, prepped
@@ -396,9 +427,8 @@ def fwbw_leg(ctx, dev, steps, cpu_threads=0, with_cpu=True):
         traffic_src = pmc["_file"]
     base = None
     if with_cpu:
-        logical, physical = physical_cores()
-        # bounded sample: 128 windows, two per thread on 64 threads (~10 s of wall; with every core busy a window takes 10 x as long)
-        threads = cpu_threads or max(1, min(physical, logical, 64))
+        # bounded sample: 128 windows over the threads the host may run at once (at most 64)
+        threads = baseline_threads(cpu_threads, cap=64)
         base = fwbw_cpu_baseline((t0, t1), off, cm, sd, ls, strand, lpd, threads, 128)
         base["gpu_over_cpu"] = round(total * steps / dt / 1e6 / base["value"], 1)
     return {"metric": "FB + EM-statistics event-rounds/s", "value": round(total * steps / dt / 1e6, 3), "unit": "Mevent-rounds/s",
@@ -500,10 +530,9 @@ def config3_leg(ctx, host_threads, cpu_threads, with_cpu, n_reads=1024, n_ev=500
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nc_oracle as oracle
-        logical, physical = physical_cores()
         # bounded sample: 16 jobs on 16 threads -- a job is 4 rounds x 4 windows of the oracle's forward-backward (~0.5 s per window on
-        # an idle host, 6 s with 128 of them running at once: the port allocates per cell like the reference's logsumset): ~15 s of wall
-        threads = cpu_threads or max(1, min(physical, logical, 16))
+        # an idle host, 6 s with 128 of them running at once on a 16-CPU quota): ~15 s of wall
+        threads = baseline_threads(cpu_threads, cap=16)
         pick = np.unique(np.linspace(0, nj - 1, max(16, threads)).astype(np.int64))
         got = [None] * len(pick)
 
@@ -1017,10 +1046,9 @@ def main():
                 sys.stderr.write(f"bench.py: ragged leg failed: {e}\n")
                 result["ragged"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
-            logical, physical = physical_cores()
-            threads = args.cpu_threads or max(1, min(physical, logical))      # T = physical cores
+            threads = baseline_threads(args.cpu_threads)      # T = physical cores the host may actually run at once
             if n_events <= 10000:
-                # bounded sample: 256 reads (2 per thread on a 128-core host) -- ~10-20 s of wall, 164 MB of matrix per thread
+                # bounded sample: 256 reads (2 per thread on a 128-core host, 16 on a 16-CPU quota) -- ~10-20 s of wall, 164 MB of matrix per thread
                 n_cpu_reads = max(256, threads)
             else:
                 # long reads (config 5): 8 reads on 8 threads -- 1.6 GB of matrix per 50 000-event read

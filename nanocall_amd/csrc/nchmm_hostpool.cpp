@@ -8,9 +8,12 @@
 // only for its own chunks.
 #include "nchmm_internal.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <thread>
 
@@ -84,16 +87,45 @@ void worker(Pool* P)
     }
 }
 
+// CPUs' worth of time the process's cgroup allows per period (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us); 0 = no limit.
+// A container may show 256 CPUs in its affinity mask and be allowed the time of 16: threads beyond the quota only get throttled
+// (the test boxes of this repository are such containers: 128 spinning processes do LESS work per second there than 32).
+unsigned cgroup_cpu_quota()
+{
+    auto read2 = [](const char* path, long long* a, long long* b) {
+        FILE* f = std::fopen(path, "r");
+        if (!f) return 0;
+        char tok[64] = {0};
+        int n = 0;
+        if (std::fscanf(f, "%63s", tok) == 1) {
+            if (std::strcmp(tok, "max") == 0) { *a = -1; n = 1; }
+            else { *a = std::atoll(tok); n = 1; }
+            if (b && std::fscanf(f, "%lld", b) == 1) n = 2;
+        }
+        std::fclose(f);
+        return n;
+    };
+    long long quota = -1, period = 100000;
+    if (read2("/sys/fs/cgroup/cpu.max", &quota, &period) >= 1) {
+        if (quota > 0 && period > 0) return (unsigned)((quota + period - 1) / period);
+        return 0;
+    }
+    if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, nullptr) >= 1 && quota > 0
+        && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, nullptr) >= 1 && period > 0)
+        return (unsigned)((quota + period - 1) / period);
+    return 0;
+}
+
 unsigned usable_cpus()
 {
+    unsigned n = 0;
     cpu_set_t set;
     CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-        const int n = CPU_COUNT(&set);
-        if (n > 0) return (unsigned)n;
-    }
-    const unsigned hc = std::thread::hardware_concurrency();
-    return hc ? hc : 4;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+    if (!n) n = std::thread::hardware_concurrency();
+    if (!n) n = 4;
+    const unsigned q = cgroup_cpu_quota();
+    return q ? std::min(n, q) : n;
 }
 
 }  // namespace
