@@ -1694,7 +1694,10 @@ static int real_main()
     if (may_fan_out && worker_devices.empty() && probed >= 2) {
         const int use = opts::gpus.get() > 0 ? opts::gpus.get() : probed;
         if (use > probed) { LOG(error) << "--gpus " << use << " requested but only " << probed << " visible" << std::endl; return EXIT_FAILURE; }
-        if (use >= 2) for (int k = 0; k < use; ++k) worker_devices.push_back(k);
+        // (no more workers than input files: a run over three files on an eight-GPU node is three workers, over one file this process)
+        const int n_workers = (int)std::min<size_t>((size_t)use, files.size());
+        if (n_workers >= 2) for (int k = 0; k < n_workers; ++k) worker_devices.push_back(k);
+        else if (use >= 2) opts::gpus.get() = 1;
     }
     if (may_fan_out && !worker_devices.empty()) return fan_out(models, files, worker_devices, whole);
     return run_reads(models, files, whole, nullptr);
