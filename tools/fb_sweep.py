@@ -24,6 +24,17 @@ SEED = int(os.environ.get("SEED", 424242))
 KINDS = tuple(k for k in os.environ.get("KINDS", "").split(",") if k)
 
 
+def default_workers():
+    """oracle worker processes: the CPUs the box allows (its cgroup quota, when it has one), at most 48"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, min(48, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(48, (os.cpu_count() or 2) // 2))
+
+
 def make_config(c):
     """(worker process) the windows of configuration c and the oracle's log Pr(data) of each"""
     import nanocall_amd as na
@@ -54,7 +65,7 @@ def make_config(c):
 
 def main():
     n_cfg = int(os.environ.get("CONFIGS", 60))
-    workers = int(os.environ.get("WORKERS", max(1, min(48, (os.cpu_count() or 2) // 2))))
+    workers = int(os.environ.get("WORKERS", default_workers()))
     t0 = time.time()
     pool = mp.get_context("spawn").Pool(workers)
     todo = pool.imap(make_config, range(n_cfg), chunksize=1)

@@ -37,6 +37,17 @@ SEED = int(os.environ.get("SEED", 20260606))
 KINDS = tuple(k for k in os.environ.get("KINDS", "").split(",") if k)
 
 
+def default_workers():
+    """oracle worker processes: the CPUs the box allows (its cgroup quota, when it has one), at most 48"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, min(48, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(48, (os.cpu_count() or 2) // 2))
+
+
 def make_config(c):
     """(worker process) inputs of configuration c and the oracle's decode of every read"""
     import nanocall_amd as na
@@ -73,7 +84,7 @@ def make_config(c):
 def main():
     n_cfg = int(os.environ.get("CONFIGS", 40))
     forms = [f for f in os.environ.get("FORMS", os.environ.get("SWEEP", "auto")).split(",") if f]
-    workers = int(os.environ.get("WORKERS", max(1, min(48, (os.cpu_count() or 2) // 2))))
+    workers = int(os.environ.get("WORKERS", default_workers()))
     t0 = time.time()
     pool = mp.get_context("spawn").Pool(workers)          # before anything here touches the GPU; spawn: no forked HIP state either way
     todo = pool.imap(make_config, range(n_cfg), chunksize=1)
