@@ -342,3 +342,18 @@ def test_strands_and_training_windows_at_once_on_one_context(r73t):
     for (cm, sd, ls), (st, lp, rc) in zip(strands, got_s):
         s, mv, olp = oracle.viterbi(om, ot, cm, sd, ls)
         assert rc == 0 and np.array_equal(st, s) and np.float32(lp).tobytes() == np.float32(olp).tobytes()
+
+
+def test_cross_process_counter_reduction_on_a_communicator_of_one():
+    """nchmm_rccl_unique_id + nchmm_counters_allreduce (what the worker processes of `nanocall --gpus N` call, one rank per process):
+    ncclGetUniqueId, ncclCommInitRank and one ncclAllReduce(sum) of eight uint64 -- with one rank the sums are the inputs.  Invalid
+    arguments are refused before anything is initialised."""
+    from nanocall_amd import api
+    from nanocall_amd._lib import lib
+    uid = api.rccl_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    mine = np.array([3, 1 << 40, 0, 7, 11, 13, 17, (1 << 63) + 5], np.uint64)
+    assert np.array_equal(api.counters_allreduce(0, 1, 0, uid, mine), mine)
+    assert lib().nchmm_counters_allreduce(0, 2, 2, uid.ctypes.data, mine.ctypes.data) == -1          # rank outside [0, n_ranks)
+    assert lib().nchmm_counters_allreduce(-1, 1, 0, uid.ctypes.data, mine.ctypes.data) == -1
+    assert lib().nchmm_rccl_unique_id(None) == -1
