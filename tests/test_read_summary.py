@@ -108,3 +108,43 @@ def test_pore_presets():
     assert na.api.segment_opts("r73").abasic_level_top_offset == 5.0     # :956-957
     with pytest.raises(api.NchmmError):
         na.api.segment_opts("r10")
+
+
+def test_randomised_tables_islands_and_options_equal_the_oracle():
+    """1500 random EventDetection tables: any number of abasic islands (3-60 events long: either side of the five-in-a-row rule,
+    Fast5_Summary.hpp:545-571) anywhere, gaps either side of the merge reach (:665-676), tables from below the minimum to past the cap,
+    random trim margins / minimum / cap, constant stretches and NaN-free outliers in the levels; summaries and the filtered events of
+    both strands bit-identical to the oracle's restatement."""
+    rng = np.random.default_rng(20260607)
+    shapes = set()
+    for case in range(1500):
+        n = int(rng.choice([int(rng.integers(60, 400)), int(rng.integers(400, 3000)), int(rng.integers(3000, 9000))]))
+        level, abasic = float(rng.uniform(40, 90)), float(rng.uniform(95, 160))
+        isl = []
+        for _ in range(int(rng.integers(0, 7))):
+            a = int(rng.integers(0, max(1, n - 3)))
+            isl.append((a, min(n, a + int(rng.integers(3, 61)))))
+        if rng.random() < 0.5 and n > 200:                 # one near the middle, so that 2D shapes are common
+            a = n // 2 + int(rng.integers(-n // 5, n // 5))
+            isl.append((a, min(n, a + int(rng.integers(5, 40)))))
+        ed = synth_ed(rng, n, hairpin=None, level=level, abasic=abasic, extra_islands=isl, zero_stdv=bool(rng.random() < 0.5))
+        if rng.random() < 0.2:                              # a constant stretch (a stalled pore)
+            a = int(rng.integers(0, n - 20)); ed["mean"][a:a + int(rng.integers(5, 200))] = ed["mean"][a]
+        if rng.random() < 0.2:                              # a few wild levels
+            ed["mean"][rng.integers(0, n, 3)] = rng.choice([-50.0, 0.0, 1.0, 500.0], 3)
+        trim = tuple(int(x) for x in rng.choice([0, 1, 10, 50, 80, 200], 4))
+        mn, mx = int(rng.choice([1, 10, 40, 150])), int(rng.choice([100, 1000, 5000, 100000]))
+        pore, one_d, sst = str(rng.choice(["r73", "r9"])), bool(rng.random() < 0.2), bool(rng.random() < 0.7)
+        po = na.api.segment_opts(pore, template_only=int(one_d), max_ed_events=mx, min_ed_events=mn)
+        po.trim_margins[:] = list(trim)
+        oo = oracle.f5_opts(pore, template_only=one_d, max_ed_events=mx, min_ed_events=mn, trim=trim)
+        rate = float(rng.choice([4000.0, 3012.5, 999.0, 10000.0]))
+        ps, os_ = api.read_summarize(po, ed, rate, sst), oracle.f5_summarize(oo, ed, rate, sst)
+        assert same_summary(ps, os_), (case, n, isl, trim, mn, mx, list(ps.strand_bounds), list(os_.strand_bounds))
+        for st in (0, 1):
+            pe, oe = api.read_load_events(ps, ed, rate, st), oracle.f5_load_events(os_, ed, rate, st)
+            for a, b in zip(pe, oe):
+                assert a.tobytes() == b.tobytes(), (case, st)
+        sb = list(ps.strand_bounds)
+        shapes.add("skipped" if ps.num_ed_events == 0 else ("2d" if sb[3] > sb[2] else "1d"))
+    assert shapes == {"skipped", "1d", "2d"}
