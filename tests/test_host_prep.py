@@ -135,3 +135,32 @@ def test_sweep_plan_holds_on_machines_that_run_at_other_rates(tmp_path):
     g = d["groups"]
     assert g["uniform"]["form_changes"] == 0 and g["clock"]["worst_regret_within_10_percent"] <= 0.05 and g["clock_known"]["worst_regret"] <= 0.05
     assert all(v["changes_away_from_break_even"] == 0 for v in g.values())
+
+
+def test_randomised_scalings_and_transitions_bit_exact():
+    """300 random scaling-parameter sets (scale 0.5-2, shift +-30, var / scale_sd / var_sd over 0.1-10: wider than any trained read) on
+    every builtin table, applied once and twice, and 200 random (p_skip, p_stay) pairs down to 1e-4 and up to a sum of 0.999: the
+    scaled model images and the transition CSRs bit-identical to the oracle's (Pore_Model.hpp:126-138,190-201; State_Transitions.hpp:125-224)."""
+    rng = np.random.default_rng(99)
+    tabs = [na.builtin_model(m) for m in range(6)]
+    loaded = [na.model_load(t) for t in tabs]
+    lu = lambda lo, hi: float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+    for k in range(300):
+        m = int(rng.integers(6))
+        p = (rng.uniform(0.5, 2.0), rng.uniform(-30, 30), rng.uniform(-0.05, 0.05), lu(0.1, 10), lu(0.1, 10), lu(0.1, 10))
+        p = tuple(float(np.float32(x)) for x in p)
+        a, b = na.model_scale(loaded[m], p), oracle.Model(tabs[m], p)
+        assert np.array_equal(a.view(np.uint32), b.states().view(np.uint32)), (k, p)
+        assert np.array_equal(na.model_pack6(a).view(np.uint32), b.table6().view(np.uint32)), (k, p)
+        assert np.array_equal(na.scaled_model_table(tabs[m], p).view(np.uint32), b.table6().view(np.uint32))
+        if k % 10 == 0:
+            q = tuple(float(np.float32(x)) for x in (rng.uniform(0.8, 1.2), rng.uniform(-5, 5), 0.0, lu(0.5, 2), lu(0.5, 2), lu(0.5, 2)))
+            b.scale(q)
+            assert np.array_equal(na.model_scale(a, q).view(np.uint32), b.states().view(np.uint32)), (k, p, q)
+    for k in range(200):
+        p_stay = lu(1e-4, 0.6)
+        p_skip = min(lu(1e-4, 0.6), 0.999 - p_stay)
+        rp, pred, w = na.transitions_fast(p_skip, p_stay)
+        rp2, idx2, w2 = oracle.Transitions(p_skip, p_stay).from_csr()
+        assert np.array_equal(rp, rp2) and np.array_equal(pred, idx2.astype(np.uint16)), (k, p_skip, p_stay)
+        assert np.array_equal(w.view(np.uint32), w2.view(np.uint32)), (k, p_skip, p_stay)
