@@ -16,6 +16,15 @@
 // hardware exp2/log2 (v_exp_f32 / v_log_f32) are used without per-term scaling; rows written to HBM
 // and all outputs are natural logs again.
 //
+// NORM (round 6): plain fp32 log space loses digits with the MAGNITUDE of alpha and beta -- a window with an abasic stretch has
+// log Pr(data) ~ -2e4, where one ulp is 2e-3: the posteriors exp(alpha + beta - log Pr) came out 2 % off (the reference's own
+// fp32 log space: 0.8 %; tools/ubench/fb_log_noise.py), and those are exactly the windows the rescaled kernels hand over.  When the
+// caller does not ask for the matrices, every column is kept RELATIVE to an integer offset (in base-2 units: the floor of the
+// previous column's maximum, accumulated; exact to apply, exact to undo): the registers, the rows in HBM and the exchange values
+// stay within one event's emission of zero, the offsets travel as int32 per event (FwbwArgs::ws_exp) and are combined in integer
+// arithmetic, and log2 posterior = a + b + (A_i + B_i - A_last) - l with every term small.  With the matrices requested
+// (alpha_natural) the rows ARE the caller's output and stay absolute: the arithmetic of rounds 1-5.
+//
 // Two kernels, one window per 512-thread block each (persistent blocks + work queue), both within
 // 128 VGPRs so that two blocks share a CU (4 waves/SIMD): fwbw_forward_kernel writes the alpha rows
 // and log_pr_data, fwbw_backward_kernel reads them back one event ahead of use.  The emission is regrouped
@@ -47,6 +56,8 @@
 #include "nchmm_device.h"
 #include "fwbw_common.hpp"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace nchmm {
@@ -54,11 +65,24 @@ namespace nchmm {
 using namespace fb;
 
 // ================================================ forward ================================================
+namespace {
+// floor of the largest of the eight wave maxima at `p` (block-uniform); 0 when there is no finite maximum to take out
+__device__ __forceinline__ float block_floor_max(const float* p)
+{
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w)),
+                                    __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w)));
+    return (m > -1.0e9f && m < 1.0e9f) ? __builtin_floorf(m) : 0.0f;
+}
+}  // namespace
+
+template <bool NORM>
 __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
 {
     __shared__ __attribute__((aligned(16))) float sG1[2][1024];
     __shared__ __attribute__((aligned(16))) float sG2[2][256];
     __shared__ __attribute__((aligned(16))) float4 sEv[kFbChunk];     // x, y, log2e * 3 log(y) / 2, 1/y
+    __shared__ __attribute__((aligned(16))) float sMax[2][kThreads / 64];   // NORM: the waves' maxima of the previous column
     __shared__ float sRed[16];
     __shared__ unsigned sWork;
 
@@ -109,6 +133,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
         // the skip coefficient c2[j] is the group weight w2[j >> 4] for every state: the producer of group t adds it
         const float w2 = P.trans[(size_t)ts * kTransFloats + kStates + 1024 + t] * kLog2e;
         const unsigned r1_base = (h << 6) + (t >> 2), q_base = (h << 4) + (t >> 4);
+        int A = 0;      // NORM: alpha_i[j] (base 2) = alpha[q] + A -- the offset of the column in the registers
 
         for (unsigned base = 0; base < n; base += kFbChunk) {
             const unsigned ie = base + tau;
@@ -131,19 +156,30 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
                     sG1[buf][(h << 8) | t] = a.m + lg2(a.s);
                     sG1[buf][((2u + h) << 8) | t] = b.m + lg2(b.s);
                     if (h == 0) sG2[buf][t] = s8.m + lg2(s8.s) + w2;
+                    if (NORM) {
+                        const float wm = wave_max(__builtin_fmaxf(a.m, b.m));     // (a.m, b.m: the maxima of this thread's eight cells)
+                        if (lane == 0) sMax[buf][wave] = wm;
+                    }
                     __syncthreads();
                 }
                 const float* pa = &sG1[buf][r1_base];
                 const float* pb = &sG2[buf][q_base];
+                // NORM: the previous column's maximum comes out of this column (the same for every state: an exact shift)
+                float shift = 0.0f;
+                if (NORM && i > 0) {
+                    shift = block_floor_max(&sMax[buf][0]);
+                    A += (int)shift;
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const unsigned kc = 4u * (unsigned)(q >> 1) + 2u * (unsigned)(q & 1);
                     const float e = emission2(ev.x, ev.y, ev.w, ev.z, mu[q], r2[q], eta[q], lq[q], k0[q]);
                     if (i == 0) alpha[q] = e - P.log_n_states * kLog2e;                   // Forward_Backward.hpp:58-68
-                    else alpha[q] = e + lse3(c0[q] + alpha[q], c1[q] + pa[kc << 6], pb[kc << 4]);
+                    else alpha[q] = e + (lse3(c0[q] + alpha[q], c1[q] + pa[kc << 6], pb[kc << 4]) - shift);
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) arow[(uint64_t)i * kStates + jj[q]] = alpha[q] * store_scale;
+                if (NORM && tau == 0) P.ws_exp[e0 + i] = A;
             }
             __syncthreads();
         }
@@ -168,8 +204,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
         for (int q = 0; q < kThreads / 64; ++q) bs += sRed[8 + q];
         if (tau == 0) {
             const float l2 = bm + lg2(bs);
-            P.ws_lpd2[w] = l2;
-            P.out_log_pr_data[w] = l2 * kLn2;
+            P.ws_lpd2[w] = l2;                       // NORM: relative to the last column's offset A (= ws_exp[e0 + n - 1])
+            P.out_log_pr_data[w] = NORM ? (float)(((double)A + (double)l2) * 0.69314718055994530942) : l2 * kLn2;
         }
         } while (0);
     }
@@ -184,11 +220,13 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_forward_kernel(FwbwArgs P)
 // (r2, lq are the emission constants already in registers).  The six block sums are mapped back by one thread
 // each, in double:  s0 = cU S0, s1 = cU (S1 - shift S0) / scale, s2 = cU (S2 - 2 shift S1 + shift^2 S0) / scale^2,
 // l0 = cL S3, l1 = cL scale_sd S4, l2 = cL scale_sd^2 S5,  cU = 2 ln2 var^2, cL = 2 ln2 / var_sd.
+template <bool NORM>
 __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
 {
     __shared__ __attribute__((aligned(16))) float sTab[3][kStates];   // c0b log2 | c1b log2 | emission constant k0
     __shared__ __attribute__((aligned(16))) float sG1[2][1024];
     __shared__ __attribute__((aligned(16))) float sG2[2][256];
+    __shared__ __attribute__((aligned(16))) float sMax[2][kThreads / 64];   // NORM: the waves' maxima of g
     __shared__ float sRed[16];
     __shared__ __attribute__((aligned(16))) float sAcc[2][kThreads / 64][8];   // per-event sums of each wave, by event parity
     __shared__ float sCoef[6][4];   // per window: how output q is formed from the block sums {k_a, k_b, k_c}
@@ -225,8 +263,11 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
         const float* __restrict__ ey = P.stdv + e0;
         const float* __restrict__ el = P.lstdv + e0;
         const float* const arow = P.ws_alpha + e0 * (uint64_t)kStates;
-        const float lpd = P.ws_lpd2[w];   // base 2
+        const float lpd = P.ws_lpd2[w];   // base 2; NORM: relative to the last column's offset
         const float load_scale = P.alpha_natural ? kLog2e : 1.0f;
+        const int32_t* __restrict__ aexp = P.ws_exp + e0;        // NORM: the offset A_i of every alpha row
+        const int A_last = NORM ? aexp[n - 1] : 0;
+        int B = 0;                                               // NORM: beta_i[j] (base 2) = beta[u] + B
 
         float mu[8], r2[8], eta[8], lq[8], beta[8];
 #pragma unroll
@@ -334,6 +375,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
             nx_lo = *reinterpret_cast<const float4*>(rowp + j0);
             nx_hi = *reinterpret_cast<const float4*>(rowp + j0 + 4);
             nx_x = ex[i - 1]; nx_y = ey[i - 1]; nx_l = el[i - 1];
+            const int A_prev = NORM ? aexp[i - 1] : 0;
             // g = emission(event i) + beta_i; H1/H2 over consecutive successor groups (Forward_Backward.hpp:107-125)
             float g[8];
 #pragma unroll
@@ -352,8 +394,21 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
             sG1[buf][2 * tau] = a.m + lg2(a.s);
             sG1[buf][2 * tau + 1] = b.m + lg2(b.s);
             if (h == 0) sG2[buf][t] = s8.m + lg2(s8.s) + w2;
+            if (NORM) {
+                const float wm = wave_max(__builtin_fmaxf(a.m, b.m));
+                if (lane == 0) sMax[buf][wave] = wm;
+            }
             __syncthreads();
             publish((unsigned)i);    // the barrier made every wave's sums of event i visible
+            // log2 of the posterior of (i-1, u) = alpha + beta + kp; of the joint terms with g / H1 of event i = ... + kq.
+            // NORM: g's maximum comes out of beta_{i-1}; the integer offsets of the two columns and of the total combine exactly
+            float shift = 0.0f, kp = -lpd, kq = -lpd;
+            if (NORM) {
+                shift = block_floor_max(&sMax[buf][0]);
+                kq = (float)(A_prev + B - A_last) - lpd;
+                B += (int)shift;
+                kp = (float)(A_prev + B - A_last) - lpd;
+            }
             const float al[8] = {nx_lo.x, nx_lo.y, nx_lo.z, nx_lo.w, nx_hi.x, nx_hi.y, nx_hi.z, nx_hi.w};
             const float* ph1 = &sG1[buf][j0 & 1023u];
             const float* ph2 = &sG2[buf][j0 & 255u];
@@ -370,13 +425,13 @@ __global__ __launch_bounds__(kThreads, 4) void fwbw_backward_kernel(FwbwArgs P)
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     const int u = 2 * pr + v;
-                    beta[u] = lse3(c02[v] + g[u], c12[v] + h1[v], h2[v]);
+                    beta[u] = lse3(c02[v] + g[u], c12[v] + h1[v], h2[v]) - shift;
                     const float a2 = al[u] * load_scale;
-                    const float p = ex2(a2 + beta[u] - lpd);             // exp(Forward_Backward::log_posterior)
+                    const float p = ex2(a2 + beta[u] + kp);               // exp(Forward_Backward::log_posterior)
                     pm_add(u, p);
                     const float pm = ((train >> u) & 1u) ? p : 0.0f;      // only transition-training k-mers count
-                    const float pst = __builtin_fminf(ex2(a2 + lps + g[u] - lpd), pm);
-                    const float pstep = ex2(a2 + lps4 + h1[v] - lpd);
+                    const float pst = __builtin_fminf(ex2(a2 + lps + g[u] + kq), pm);
+                    const float pstep = ex2(a2 + lps4 + h1[v] + kq);
                     const float p01 = __builtin_fminf(pst + pstep, pm);
                     acc_p += pm; acc_stay += pst; acc_skip += pm - p01;
                 }
@@ -424,14 +479,20 @@ void launch_fwbw(const FwbwArgs& a, int grid, hipStream_t stream, bool scaled)
     } else {
         f.queue = a.queue; b.queue = a.queue + 1;
     }
-    hipLaunchKernelGGL(fwbw_forward_kernel, dim3(grid), dim3(kThreads), 0, stream, f);
-    hipLaunchKernelGGL(fwbw_backward_kernel, dim3(grid), dim3(kThreads), 0, stream, b);
+    // the matrices requested: absolute rows in the caller's buffers; else columns relative to integer offsets (NORM, see the top)
+    if (f.alpha_natural || f.out_beta) {
+        hipLaunchKernelGGL(fwbw_forward_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, f);
+        hipLaunchKernelGGL(fwbw_backward_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, b);
+    } else {
+        hipLaunchKernelGGL(fwbw_forward_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, f);
+        hipLaunchKernelGGL(fwbw_backward_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, b);
+    }
 }
 
 int fwbw_blocks_per_cu()
 {
-    const int f = fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_forward_kernel));
-    const int b = fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_backward_kernel));
+    const int f = std::min(fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_forward_kernel<false>)), fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_forward_kernel<true>)));
+    const int b = std::min(fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_backward_kernel<false>)), fb_blocks_per_cu(reinterpret_cast<const void*>(fwbw_backward_kernel<true>)));
     const int s = fwbw_scaled_blocks_per_cu();
     return f < b ? (f < s ? f : s) : (b < s ? b : s);
 }
