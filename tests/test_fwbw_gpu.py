@@ -573,3 +573,43 @@ def test_windows_with_an_abasic_stretch_keep_finite_statistics():
             lpd = cfg["lpd"]
             assert np.isfinite(lpd).all()
             assert (np.abs(out["log_pr_data"].astype(np.float64) - lpd) <= 1e-4 * np.abs(lpd)).all(), (c, out["log_pr_data"], lpd)
+
+
+def test_log_space_statistics_keep_their_digits_on_windows_no_state_explains():
+    """The log-space kernels (the redo path of windows the rescaled kernels flag; NCHMM_FB_FORCE_LOG) keep every column relative to
+    an integer base-2 offset when the matrices are not requested (fwbw_kernel.hip, NORM): on a training window with an abasic
+    stretch (log Pr(data) ~ -1e4 and below, where one fp32 ulp of alpha is 1e-3) the per-event sums of train_pm_params are within
+    1e-4 of a float64 evaluation -- absolute fp32 columns, which rounds 1-5 used and the reference's own arithmetic uses, are 1-2 %
+    off there (tools/ubench/fb_log_noise.py).  The log-likelihood within 1e-6 relative of the float64 one."""
+    import adversarial
+    import fb_truth
+    t = na.builtin_model("r73.t")
+    ident = np.float32([1, 0, 0, 1, 1, 1])
+    mean, stdv, start = adversarial.events("abasic", t, ident, 400, seed=50250)
+    cm, sd, ls = na.events_prepare(mean, stdv, None, 0.0)
+    t6 = na.scaled_model_table(t, ident)
+    tr = na.transitions_fast(0.3, 0.1)
+    u = na.model_load(t).astype(np.float64)
+    u0 = 1.0 / (u[:, 1] ** 2)
+    os.environ["NCHMM_FB_FORCE_LOG"] = "1"
+    try:
+        ctx = na.Context(0)
+    finally:
+        del os.environ["NCHMM_FB_FORCE_LOG"]
+    lowest = 0.0
+    with ctx:
+        ctx.put_model(0, t6)
+        ctx.put_transitions(0, *tr)
+        off = np.array([0, 100, 200, 300, 400], np.uint64)
+        got = ctx.fwbw(off, cm, sd, ls, pm_params=ident, st_params=np.tile(np.float32([0.1, 0.3]), (4, 1)))
+        for w in range(4):
+            a, b = 100 * w, 100 * (w + 1)
+            lpd64, al, be = fb_truth.fwbw64(t6, *tr, cm[a:b], sd[a:b])
+            lowest = min(lowest, lpd64)
+            p = np.exp(al + be - lpd64)
+            want = np.stack([p @ u0, p @ (u0 * u[:, 0]), p @ (u0 * u[:, 0] ** 2), p @ u[:, 4], p @ (u[:, 4] / u[:, 2]), p @ (u[:, 4] / u[:, 2] ** 2)], 1)
+            sums = got["pm_sums"].reshape(-1, 6)[a:b].astype(np.float64)
+            rel = np.abs(sums - want) / np.maximum(np.abs(want), 1e-3)
+            assert rel.max() <= 1e-4, (w, lpd64, rel.max())
+            assert abs(float(got["log_pr_data"][w]) - lpd64) <= 1e-6 * abs(lpd64), (w, got["log_pr_data"][w], lpd64)
+    assert lowest < -5000.0          # (the read does have a window in the regime the test is about)
