@@ -587,3 +587,54 @@ def test_more_worker_processes_than_input_files(tmp_path):
 def test_gpus_option_beyond_the_visible_devices_is_refused():
     p = run_cli(["--pore", "r73", "--no-train", "--gpus", "64", os.path.join(G, "r73_1d_b.fast5")], expect_rc=1)
     assert "--gpus 64 requested but only" in p.stderr
+
+
+def _adversarial_ed_table(rng, k):
+    """an EventDetection table whose strands are NOT draws from the models they will be decoded with (tests/adversarial.py kinds),
+    with a hairpin plateau between them in two reads of three"""
+    import adversarial
+    import nanocall_amd as na
+    from nanocall_amd import api
+    t_tab, c_tab = na.builtin_model("r73.t"), na.builtin_model("r73.c.p1" if k % 2 else "r73.c.p2")
+    params = (float(rng.uniform(0.95, 1.06)), float(rng.uniform(-4, 4)), 0.0, 1.0, 1.0, 1.0)
+    parts = []
+    kinds = []
+    for s, tab in enumerate((t_tab, c_tab) if k % 3 else (t_tab,)):
+        kind = adversarial.KINDS[int(rng.integers(len(adversarial.KINDS)))]
+        kinds.append(kind)
+        n = int(rng.integers(200, 3500))
+        mean, stdv, _ = adversarial.events(kind, tab, params, n, seed=9100 + 10 * k + s, other_table=t_tab if s else c_tab)
+        parts.append((mean, stdv))
+        if s == 0 and k % 3:
+            hp = int(rng.integers(6, 20))
+            parts.append((np.float32(rng.normal(float(np.asarray(t_tab).reshape(4096, 4)[:, 0].max()) + 40.0, 2.0, hp)), np.float32(rng.uniform(0.5, 2.0, hp))))
+    lead = (np.float32(rng.normal(60, 5, 60)), np.float32(rng.uniform(0.5, 2.0, 60)))
+    parts = [lead] + parts + [lead]
+    mean = np.concatenate([p[0] for p in parts]); stdv = np.concatenate([p[1] for p in parts])
+    ed = np.zeros(len(mean), api.ED_DTYPE)
+    ed["mean"], ed["stdv"] = mean, stdv
+    ed["length"] = rng.integers(8, 120, len(mean))
+    ed["start"] = 1000 + np.cumsum(ed["length"]) - ed["length"]
+    return ed, kinds
+
+
+def test_no_train_adversarial_reads_byte_identical(tmp_path):
+    """Twenty-four reads whose strands are runs of identical events, spikes, uniform levels, another model's stream, heavy-tailed or
+    zero stdv, abasic stretches (tests/adversarial.py) -- segmentation (stretches at the abasic level inside a strand are islands
+    too), initial scalings, every candidate model decoded, the better one chosen, bases and FASTA: byte-identical to the oracle
+    pipeline, in one batch and in many small ones."""
+    rng = np.random.default_rng(20260608)
+    inputs, all_kinds = [], set()
+    for k in range(24):
+        ed, kinds = _adversarial_ed_table(rng, k)
+        all_kinds.update(kinds)
+        path = tmp_path / f"adv_{k:02d}.events"
+        op.write_events_table(str(path), ed, 4000.0, f"adv-{k}")
+        inputs.append((str(path), dict(sampling_rate=4000.0, read_id=f"adv-{k}", events=ed)))
+    assert len(all_kinds) >= 6
+    exp, reads, recs = op.run(op.Opts(pore="r73", train=False), inputs)
+    assert len(recs) >= 20
+    files = [i[0] for i in inputs]
+    base = ["--pore", "r73", "--no-train"]
+    assert run_cli(base + files).stdout == exp
+    assert run_cli(base + ["--chunk-events", "4000", "-t", "4"] + files).stdout == exp
