@@ -638,3 +638,25 @@ def test_no_train_adversarial_reads_byte_identical(tmp_path):
     base = ["--pore", "r73", "--no-train"]
     assert run_cli(base + files).stdout == exp
     assert run_cli(base + ["--chunk-events", "4000", "-t", "4"] + files).stdout == exp
+
+
+def test_trained_adversarial_reads_teacher_forced_byte_identical(tmp_path):
+    """Twelve of the adversarial reads through the DEFAULT pipeline (EM of every model pair, selection, decode): the EM may take the
+    parameters anywhere (scale 2, var 8 on a strand with an abasic stretch), and whatever it reports (--dump-params, hex floats)
+    the oracle decoding with exactly those parameters must give the same FASTA byte for byte and the same path log-probabilities
+    bit for bit -- the Viterbi path under parameters no well-behaved read produces (true division outside the validated range)."""
+    rng = np.random.default_rng(20260609)
+    inputs = []
+    for k in range(12):
+        ed, kinds = _adversarial_ed_table(rng, k)
+        path = tmp_path / f"advt_{k:02d}.events"
+        op.write_events_table(str(path), ed, 4000.0, f"advt-{k}")
+        inputs.append((str(path), dict(sampling_rate=4000.0, read_id=f"advt-{k}", events=ed)))
+    dump = tmp_path / "params.tsv"
+    p = run_cli(["--pore", "r73", "-t", "4", "--chunk-events", "6000", "--dump-params", str(dump)] + [i[0] for i in inputs])
+    d = op.read_dump(str(dump))
+    assert len(d) >= 10
+    for v in d.values():
+        assert np.isfinite(v["pm"]).all() and np.isfinite(v["st"]).all() and np.isfinite(v["logp"]), v
+    recs = check_teacher_forced(op.Opts(pore="r73"), inputs, p.stdout, d)
+    assert len(recs) == len(d)
