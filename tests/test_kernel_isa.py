@@ -246,3 +246,23 @@ def test_no_scratch_traffic_in_the_forward_backward_event_loops(asm):
         kernel, label, seg = min(big, key=lambda t: len(t[2]))
         spills = [x for x in seg if x.startswith("scratch_") or "accvgpr" in x]
         assert not spills, f"{pat} {label}: {spills[:4]}"
+
+
+def test_forward_backward_event_loops_raise_their_priority_up_to_the_barrier(asm):
+    """Round 6 (profiles/r06_fb_backward_session.md): the producer phase of an event runs at `s_setprio 2`, back to 0 right in front
+    of the block barrier, in both rescaled sweeps -- 3-6 % of each sweep that no parity test would notice losing.  In the event loop:
+    one raise and one drop, the drop after the raise, the barrier after the drop."""
+    for pat in ("fwbw_forward_scaled_kernel", "fwbw_backward_scaled_kernel"):
+        loops = isa_lint.event_loops(asm["fwbw_scaled_kernel"], pat)
+        big = [t for t in loops if len(t[2]) > 150 and any(x.startswith("v_permlane") or "_dpp" in x for x in t[2])]
+        kernel, label, seg = min(big, key=lambda t: len(t[2]))
+        ops = [x.split()[0] + " " + " ".join(x.split()[1:2]) for x in seg if x.startswith(("s_setprio", "s_barrier"))]
+        raises = [i for i, x in enumerate(ops) if x.startswith("s_setprio 2")]
+        drops = [i for i, x in enumerate(ops) if x.startswith("s_setprio 0")]
+        bars = [i for i, x in enumerate(ops) if x.startswith("s_barrier")]
+        assert len(raises) >= 1 and len(drops) >= 1 and bars, (pat, ops)
+        # (the loop is rotated by the compiler: what matters is the cyclic order raise -> drop -> barrier)
+        r, d = raises[0], drops[0]
+        b = next((i for i in bars if i > d), bars[0])
+        cyc = lambda a, b_: (b_ - a) % len(ops)
+        assert 0 < cyc(r, d) and cyc(d, b) == 1, (pat, ops)
