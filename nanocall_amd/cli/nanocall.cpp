@@ -1500,6 +1500,9 @@ static int fan_out(const Pore_Model_Dict_Type& models, const std::list<std::stri
             signal(SIGPIPE, SIG_IGN);              // (a parent that has gone shows as a failed write: Worker_Link::send leaves)
             close(up[0]); close(down[1]);
             for (const auto& o : ws) { close(o->data_fd); close(o->ctl_fd); }
+            // (a worker's records travel up its pipe: nothing it or a library it loads -- RCCL's banner, a runtime's notice -- prints
+            // on standard output may reach the FASTA stream the parent is writing there)
+            (void)dup2(STDERR_FILENO, STDOUT_FILENO);
             logger::tag() = "[w" + std::to_string(k) + "] ";
             Worker_Link link;
             link.rank = k; link.n_ranks = W; link.device = devices[(size_t)k]; link.data_fd = up[1]; link.ctl_fd = down[0]; link.use_rccl = use_rccl;
