@@ -614,22 +614,37 @@ int viterbi_ws_prepare(nchmm_ctx* c, uint64_t longest, size_t count, size_t budg
         c->counters[6] -= c->ws_bytes;
         c->d_ws = nullptr; c->ws_bytes = 0; c->slot_bytes = 0; c->ws_regions = 0; c->ws_per_xcd = 0;
     }
-    size_t slot = need, regions = (size_t)kXcds * per_xcd_new;
-    if (want_pooled && std::max(need, keep_slot) <= budget / regions) {
-        slot = std::max(need, keep_slot);
-        slot = std::min(slot + slot / 8, budget / regions);   // head-room so slowly growing batches do not reallocate every call
-    } else if (want_pooled) {
-        regions = (size_t)kXcds * per_xcd;                    // (the pool had grown past what this read length allows)
-    } else {
-        regions = std::min<size_t>(std::max<size_t>(budget / need, 1), (size_t)std::max(c->vit_slots, 1));
+    // The budget was taken from the memory that was free when the context first sized a workspace.  Other contexts and other
+    // processes on the device (four worker processes sharing one GPU; four contexts in one test process) may have taken it since:
+    // an allocation that does not fit is retried with what is free NOW -- fewer regions, down to one -- instead of failing the
+    // batch (round 6: a sweep with four contexts of 60 000-event reads in one process ended in NCHMM_E_NOMEM).
+    for (int attempt = 0;; ++attempt) {
+        const bool pooled = need <= budget / ((size_t)kXcds * per_xcd);
+        size_t slot = need, regions = (size_t)kXcds * per_xcd_new;
+        if (pooled && std::max(need, keep_slot) <= budget / regions) {
+            slot = std::max(need, keep_slot);
+            slot = std::min(slot + slot / 8, budget / regions);   // head-room so slowly growing batches do not reallocate every call
+        } else if (pooled) {
+            regions = (size_t)kXcds * per_xcd;                    // (the pool had grown past what this read length allows)
+        } else {
+            regions = std::min<size_t>(std::max<size_t>(budget / need, 1), (size_t)std::max(c->vit_slots, 1));
+        }
+        slot = (slot + 4095) & ~(size_t)4095;
+        void* p = nullptr;
+        rc = dev_alloc(c, &p, slot * regions);
+        if (rc == NCHMM_OK) {
+            c->d_ws = (uint8_t*)p; c->ws_bytes = slot * regions; c->slot_bytes = slot; c->ws_regions = (unsigned)regions;
+            c->ws_pooled = pooled;
+            c->ws_per_xcd = pooled ? (unsigned)(regions / kXcds) : 0;
+            return NCHMM_OK;
+        }
+        if (rc != NCHMM_E_NOMEM || attempt >= 4 || slot * regions <= need + 4096) return rc;      // (one region did not fit either)
+        (void)hipGetLastError();
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = slot * regions / 2;
+        budget = std::max<size_t>(need, std::min<size_t>(slot * regions / 2, free_b / 10 * 8));
+        if (!budget_share) c->ws_budget = std::min(c->ws_budget, budget);     // (later batches start from what the device really has)
     }
-    slot = (slot + 4095) & ~(size_t)4095;
-    void* p = nullptr;
-    if ((rc = dev_alloc(c, &p, slot * regions))) return rc;
-    c->d_ws = (uint8_t*)p; c->ws_bytes = slot * regions; c->slot_bytes = slot; c->ws_regions = (unsigned)regions;
-    c->ws_pooled = want_pooled;
-    c->ws_per_xcd = want_pooled ? (unsigned)(regions / kXcds) : 0;
-    return NCHMM_OK;
 }
 
 // rows (events) the buffer of emissions computed ahead may hold: NCHMM_EM_BUDGET_MB, default 256 MiB = 16 384 events -- what the
@@ -710,10 +725,12 @@ int launch_on_next_lane(nchmm_ctx* c, bool pooled, uint8_t* ws, size_t slot_byte
     const bool ll = form == kSweepLl || form == kSweepAhead;
     // emissions ahead: only where the caller planned them (a forced "ahead" without a plan is the plain low-latency form), and
     // not when the context is forced to another form
-    const bool em = ahead && ahead->n && form == kSweepAhead;
+    bool em = ahead && ahead->n && form == kSweepAhead;
     if (em) {
+        // (no memory for the rows: the reads compute their emissions in place -- the same bits, a slower launch)
         const int rc = viterbi_em_prepare(c, ahead->rows);
-        if (rc != NCHMM_OK) return rc;
+        if (rc == NCHMM_E_NOMEM) { (void)hipGetLastError(); em = false; }
+        else if (rc != NCHMM_OK) return rc;
     }
     ViterbiArgs a;
     a.cmean = d_cmean; a.stdv = d_stdv; a.lstdv = d_lstdv; a.off = d_off;
