@@ -251,3 +251,31 @@ def _config3(gpu_ctx, api, reference_train_job):
         one = gpu_ctx.basecall_reads(opts, states, so1, mean[a:b], stdv[a:b], start[a:b], jr1, j01, j11, out["pm"][2 * r:2 * r + 2], out["st"][2 * r:2 * r + 2])
         assert np.array_equal(one["states"], bc["states"][a:b]) and one["best_logp"].tobytes() == bc["best_logp"][r:r + 1].tobytes()
         assert one["best_job"][0, 0] == bc["best_job"][r, 0] - 2 * r
+
+
+def test_contexts_that_find_the_device_memory_taken_shrink_their_workspace(r9t):
+    """Four contexts in one process, each decoding twelve 60 000-event reads: the first three take 70 GB of back-pointer regions each
+    (288 regions of 246 MB), so what the fourth sized its budget from is gone when it allocates.  It retries with what is free -- fewer
+    regions, the same decode -- instead of failing the batch with NCHMM_E_NOMEM (round 6: four worker processes on one GPU, or a test
+    harness with a context per sweep form, ran into exactly that)."""
+    n_reads, n_events = 12, 60000
+    ev = synth.generate(r9t, n_reads, n_events, first_read=4100)
+    off, mean, stdv, start = synth.flat_batch(ev)
+    cm, sd, ls = na.events_prepare(mean, stdv, start, 0.0)
+    ctxs, outs = [], []
+    try:
+        for k in range(4):
+            ctx = na.Context(0)
+            ctxs.append(ctx)
+            ctx.put_model(0, na.scaled_model_table(r9t, IDENT))
+            ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+            outs.append(ctx.viterbi(off, cm, sd, ls))
+        peaks = [c.mem_stats()[1] >> 30 for c in ctxs]
+    finally:
+        for c in ctxs:
+            c.close()
+    for s, lp, st in outs[1:]:
+        assert np.array_equal(s, outs[0][0]) and lp.tobytes() == outs[0][1].tobytes() and (st == 0).all()
+    assert peaks[0] >= 60 and min(peaks) < peaks[0], peaks          # (somebody did have to make do with less)
+    score, ok = rescore_path(r9t, IDENT, 0.3, 0.1, cm[:n_events], sd[:n_events], ls[:n_events], outs[3][0][:n_events])
+    assert ok and np.float32(score).tobytes() == outs[3][1][0].tobytes()
