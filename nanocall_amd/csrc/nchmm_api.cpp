@@ -1094,9 +1094,10 @@ size_t fb_budget_events(nchmm_ctx* c, size_t bytes_per_event)
 {
     if (c->fb_budget == 0) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { total_b = (size_t)64 << 30; free_b = total_b; }
         const char* e = std::getenv("NCHMM_FB_BUDGET_MB");
-        c->fb_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : total_b / 4;
+        // (a quarter of the device, but no more than most of what is free now: other contexts and processes may hold the rest)
+        c->fb_budget = e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : std::min(total_b / 4, free_b / 10 * 8);
         if (c->fb_budget < ((size_t)16 << 20)) c->fb_budget = (size_t)16 << 20;
     }
     return std::max<size_t>(c->fb_budget / bytes_per_event, 1);
