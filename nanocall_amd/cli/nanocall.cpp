@@ -1209,7 +1209,7 @@ static int run_reads(const Pore_Model_Dict_Type& models, const std::list<std::st
         setenv("NCHMM_FB_BUDGET_MB", "16384", 0);
         std::vector<int> ids;
         if (link) ids.push_back(link->device);
-        else if (const char* e = std::getenv("NANOCALL_DEVICE_IDS")) {   // e.g. "0,0": several contexts on one GPU (test hook)
+        else if (const char* e = std::getenv("NANOCALL_DEVICE_IDS"); e && *e) {   // e.g. "0,0": several contexts on one GPU (test hook)
             std::istringstream is(e);
             std::string tok;
             while (std::getline(is, tok, ',')) ids.push_back(std::atoi(tok.c_str()));
@@ -1683,13 +1683,14 @@ static int real_main()
     // worker process per GPU, forked below while this process is still single-threaded and has not touched the HIP runtime --
     // so even the device count is asked by a child (started here, answered while the input list is being made).
     std::vector<int> worker_devices;
-    if (const char* e = std::getenv("NANOCALL_WORKER_DEVICES")) {      // e.g. "0,0,0,0": four workers on GPU 0 (test hook; one entry: one worker)
+    if (const char* e = std::getenv("NANOCALL_WORKER_DEVICES"); e && *e) {      // e.g. "0,0,0,0": four workers on GPU 0 (test hook; one entry: one worker)
         std::istringstream is(e);
         std::string tok;
         while (std::getline(is, tok, ',')) worker_devices.push_back(std::atoi(tok.c_str()));
     }
     int probed = -2;
-    const bool may_fan_out = !opts::single_process && !std::getenv("NANOCALL_DEVICE_IDS");
+    const char* in_process_ids = std::getenv("NANOCALL_DEVICE_IDS");
+    const bool may_fan_out = !opts::single_process && !(in_process_ids && *in_process_ids);
     Device_Probe probe;
     if (may_fan_out && worker_devices.empty() && opts::gpus.get() != 1 && openable_render_nodes() >= 2) probe.start();
     { STAGE("init_files_s"); init_files(files); }
