@@ -1456,7 +1456,9 @@ struct Worker_Stream {
         std::unique_lock<std::mutex> lk(m);
         auto ready = [&] { return !q.empty() || eof; };
         if (timeout_s < 0) cv.wait(lk, ready);
-        else if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), ready)) return false;
+        // (a deadline on the system clock: pthread_cond_timedwait, which GCC 11's ThreadSanitizer follows -- it does not know the
+        // pthread_cond_clockwait behind wait_for and would take this thread to hold the mutex while it waits)
+        else if (!cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long long)(timeout_s * 1e6)), ready)) return false;
         if (q.empty()) return false;
         f = std::move(q.front());
         q.pop_front();

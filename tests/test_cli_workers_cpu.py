@@ -77,10 +77,10 @@ def test_more_workers_than_files_and_one_file(tmp_path):
 
 
 def test_worker_machinery_under_sanitizers():
-    """tools/asan_cli.py: the command line's translation unit built with -fsanitize=address,undefined (host C++ only) and the
+    """tools/asan_cli.py: the command line's translation unit built with -fsanitize=address,undefined, then with -fsanitize=thread (host C++ only), and the
     scenarios above run against it -- pipes, frames, the merge, a worker that aborts, the ranks with nothing to do."""
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_cli.py")], capture_output=True, text=True, timeout=900)
     if r.returncode != 0 and "cannot find -lasan" in (r.stderr + r.stdout):
         pytest.skip("libasan not installed")
-    assert r.returncode == 0 and "no sanitizer report" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and r.stdout.count("no sanitizer report") == 2, (r.stdout[-3000:], r.stderr[-3000:])      # ASan+UBSan, TSan

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The command line's worker-process machinery (nanocall_amd/cli/nanocall.cpp: fan_out, Worker_Link, Worker_Stream, Device_Probe)
-under AddressSanitizer + UndefinedBehaviorSanitizer, on CPU.
+under AddressSanitizer + UndefinedBehaviorSanitizer, then under ThreadSanitizer (the parent's pump threads and the merge), on CPU.
 
 Builds the CLI's translation unit with g++ -fsanitize=address,undefined against the shipped libnanocall_hip.so (host C++ only: no HIP
 in that file) and runs the scenarios of tests/test_cli_workers_cpu.py against the instrumented binary: 1 / 2 / 5 worker processes
@@ -19,21 +19,21 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 
 
-def main():
+def one_pass(sanitizers):
     out = tempfile.mkdtemp(prefix="asan_cli_")
     exe = os.path.join(out, "nanocall")
     lib = os.path.join(ROOT, "nanocall_amd")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"),
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizers, "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"),
                     "-I" + os.path.join(lib, "csrc"), "-pthread", os.path.join(lib, "cli", "nanocall.cpp"), "-L" + lib, "-lnanocall_hip", "-lz",
                     "-Wl,-rpath," + lib, "-o", exe], check=True)
     import test_cli_workers_cpu as t
     t.CLI = exe
-    os.environ.update(ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", NANOCALL_FULL_EXIT="1")
-    plain = t._run
+    os.environ.update(ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="report_signal_unsafe=0", NANOCALL_FULL_EXIT="1")
+    plain = PLAIN_RUN[0] = PLAIN_RUN[0] or t._run
 
     def run(args, env=None, expect_rc=0):
         p = plain(args, env, expect_rc)
-        if "AddressSanitizer" in p.stderr or "runtime error" in p.stderr:
+        if "Sanitizer" in p.stderr or "runtime error" in p.stderr:
             print(p.stderr[-6000:])
             raise SystemExit(1)
         return p
@@ -46,7 +46,15 @@ def main():
         t.test_a_worker_that_dies_costs_its_own_reads_only(pathlib.Path(d))
     with tempfile.TemporaryDirectory() as d:
         t.test_more_workers_than_files_and_one_file(pathlib.Path(d))
-    print("asan_cli: 5 scenarios, no sanitizer report")
+    print(f"asan_cli: -fsanitize={sanitizers}: 5 scenarios, no sanitizer report")
+
+
+PLAIN_RUN = [None]
+
+
+def main():
+    one_pass("address,undefined")
+    one_pass("thread")
 
 
 if __name__ == "__main__":
