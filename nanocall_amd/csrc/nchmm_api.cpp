@@ -331,6 +331,8 @@ int nchmm_create(nchmm_ctx** out, int device_id)
     const int fill = std::getenv("NCHMM_TEST_POISON_POOL") ? 1 : 0;
     if (hipMemset(c->d_slot_owner, fill, sizeof(unsigned) * kXcds * c->slots_per_xcd) != hipSuccess) return fail(NCHMM_E_HIP);
     c->fb_slots = c->n_cu * fwbw_blocks_per_cu();
+    // NCHMM_FB_SLOTS (measurement hook, tools/ubench/fb_two_lanes.py): a smaller grid for the forward-backward kernels of this context
+    if (const char* e = std::getenv("NCHMM_FB_SLOTS")) { const int v = std::atoi(e); if (v > 0 && v < c->fb_slots) c->fb_slots = v; }
     *out = c;
     return NCHMM_OK;
 }
