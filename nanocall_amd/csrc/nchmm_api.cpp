@@ -203,6 +203,14 @@ namespace {
 
 int pinned(nchmm_ctx* c, size_t bytes, void** out)
 {
+    if (c->em_async) {
+        // work queued on this lane still reads what was handed out before: piecewise, from the arena em_lanes_prepare sized
+        const size_t a = (bytes + 255) & ~(size_t)255;
+        if (c->pin_cursor + a > c->h_pin_bytes) return NCHMM_E_INVALID;
+        *out = (char*)c->h_pin + c->pin_cursor;
+        c->pin_cursor += a;
+        return NCHMM_OK;
+    }
     if (c->h_pin_bytes < bytes) {
         if (c->h_pin) { HIP_TRY(c, hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_bytes = 0; }
         bytes += bytes / 8;
@@ -341,6 +349,7 @@ int nchmm_destroy(nchmm_ctx* c)
 {
     if (!c) return NCHMM_E_INVALID;
     if (c->device >= 0) (void)hipSetDevice(c->device);
+    em_lane_select(c, 0);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < kVitLanes; ++l)
         if (c->lane[l].stream) (void)hipStreamSynchronize(c->lane[l].stream);
@@ -370,6 +379,16 @@ int nchmm_destroy(nchmm_ctx* c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tab_stage) (void)hipFree(c->d_tab_stage);
+    {   // the second EM lane's set (its stream is Viterbi lane 1's)
+        EmLaneRes& o = c->em_other;
+        if (o.d_stage) (void)hipFree(o.d_stage);
+        if (o.d_fb_aux) (void)hipFree(o.d_fb_aux);
+        if (o.d_queue) (void)hipFree(o.d_queue);
+        if (o.d_tab_stage) (void)hipFree(o.d_tab_stage);
+        if (o.h_pin) (void)hipHostFree(o.h_pin);
+        if (o.ev_fb0) (void)hipEventDestroy(o.ev_fb0);
+        if (o.ev_fb1) (void)hipEventDestroy(o.ev_fb1);
+    }
     if (c->d_masks) (void)hipFree(c->d_masks);
     for (int l = 0; l < kVitLanes; ++l) {
         if (c->lane[l].ev0) (void)hipEventDestroy(c->lane[l].ev0);
@@ -517,7 +536,7 @@ int nchmm_put_models_scaled(nchmm_ctx* c, int first_slot, size_t n, const float*
     launch_scale_models((const float*)d, (const int32_t*)(d + al(b_states)), (const float*)(d + al(b_states) + al(b_idx)),
                         c->d_models, c->d_model_fast, first_slot, n, static_cast<float>(std::log(2.0 * M_PI)), st);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(st));   // the pinned staging buffer is reused by the next call
+    if (!c->em_async) HIP_TRY(c, hipStreamSynchronize(st));   // the pinned staging buffer is reused by the next call
     for (size_t k = 0; k < n; ++k) c->model_set[first_slot + k] = 1;
     return NCHMM_OK;
 }
@@ -546,7 +565,7 @@ int nchmm_put_transitions_fast(nchmm_ctx* c, int first_slot, size_t n, const flo
     HIP_TRY(c, hipMemcpyAsync(c->d_tab_stage, wm, sizeof(float) * 64 * n, hipMemcpyHostToDevice, c->stream));
     launch_expand_transitions((const float*)c->d_tab_stage, c->d_masks, c->d_trans, c->d_trans_fb, first_slot, n, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->em_async) HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t k = 0; k < n; ++k) c->trans_set[first_slot + k] = 1;
     return NCHMM_OK;
 }
@@ -1307,8 +1326,56 @@ int em_round_range(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const ui
                    const float* win_pm, const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params,
                    size_t n_jobs, const uint32_t* job_first_win, int train_drift, float* out_lpd, float* out_st, double* out_acc)
 {
-    std::vector<uint64_t> off(n_win + 1, 0);
+    EmPending pend;
+    int rc = em_round_enqueue(c, n_win, win_src, win_len, win_drift, win_pm, scaled_slot, trans_slot, st_params, n_jobs, job_first_win,
+                              train_drift, out_st != nullptr, &pend);
+    if (rc != NCHMM_OK) return rc;
+    return em_round_collect(c, pend, out_lpd, out_st, out_acc);
+}
+
+}  // namespace
+
+namespace nchmm {
+
+namespace {
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// the descriptors of a round, in one block (host pinned and device alike): off | src | drift | pm | scaled slot | trans slot | st params | job_first_win
+struct EmIn {
+    size_t off, src, dr, pm, ss, ts, sp, jf, bytes;
+    EmIn(size_t n_win, size_t n_jobs)
+    {
+        off = 0; src = off + al256(8 * (n_win + 1)); dr = src + al256(8 * n_win); pm = dr + al256(4 * n_win); ss = pm + al256(24 * n_win);
+        ts = ss + al256(4 * n_win); sp = ts + al256(4 * n_win); jf = sp + al256(8 * n_win); bytes = jf + al256(4 * (n_jobs + 1));
+    }
+};
+// ... and what comes back, in one block: log Pr(data) per window | the three transition sums per window | 13 doubles per job
+struct EmOut {
+    size_t lp, st, ac, bytes;
+    EmOut(size_t n_win, size_t n_jobs) { lp = 0; st = lp + al256(4 * n_win); ac = st + al256(12 * n_win); bytes = ac + al256(104 * std::max<size_t>(n_jobs, 1)); }
+};
+}  // namespace
+
+size_t em_round_pin_bytes(size_t n_win, size_t n_jobs)
+{
+    // the round's descriptors and results + the table uploads in front of it (nchmm_put_models_scaled: 40 B per slot in three
+    // pieces, nchmm_put_transitions_fast: 256 B per slot; two slots per job) + slack for the pieces' alignment
+    return EmIn(n_win, n_jobs).bytes + EmOut(n_win, n_jobs).bytes + al256(2 * n_jobs * 296) + 16 * 256;
+}
+
+int em_round_enqueue(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift, const float* win_pm,
+                     const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params, size_t n_jobs, const uint32_t* job_first_win,
+                     int train_drift, bool want_st, EmPending* pend)
+{
+    const EmIn I(n_win, n_jobs);
+    const EmOut O(n_win, n_jobs);
+    HIP_TRY(c, hipSetDevice(c->device));
+    void* hp = nullptr;
+    int rc = pinned(c, I.bytes + O.bytes, &hp);
+    if (rc != NCHMM_OK) return rc;
+    char* h = (char*)hp;
+    uint64_t* off = (uint64_t*)(h + I.off);
     size_t max_events = 0;
+    off[0] = 0;
     for (size_t w = 0; w < n_win; ++w) {
         if (win_src[w] + win_len[w] > c->em_n_events) return NCHMM_E_INVALID;
         off[w + 1] = off[w] + win_len[w];
@@ -1317,54 +1384,140 @@ int em_round_range(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const ui
         if (ms < 0 || ms >= c->n_slots || ts < 0 || ts >= c->n_slots || !c->model_set[ms] || !c->trans_set[ts]) return NCHMM_E_INVALID;
     }
     const size_t total = (size_t)off[n_win];
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o_off = 0, o_src = o_off + al(8 * (n_win + 1)), o_dr = o_src + al(8 * n_win), o_pm = o_dr + al(4 * n_win);
-    size_t o_ss = o_pm + al(24 * n_win), o_ts = o_ss + al(4 * n_win), o_sp = o_ts + al(4 * n_win), o_jf = o_sp + al(8 * n_win);
-    size_t o_cm = o_jf + al(4 * (n_jobs + 1)), o_sd = o_cm + al(4 * total), o_ls = o_sd + al(4 * total), o_lp = o_ls + al(4 * total);
-    size_t o_ps = o_lp + al(4 * n_win), o_st = o_ps + al(24 * total), o_ac = o_st + al(12 * n_win), need = o_ac + al(104 * std::max<size_t>(n_jobs, 1));
-    int rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
+    if (c->em_async && total * kStates > c->fb_ws_floats) return NCHMM_E_INVALID;      // (a lane's share of the alpha rows is fixed while rounds are in flight)
+    std::memcpy(h + I.src, win_src, 8 * n_win);
+    std::memcpy(h + I.dr, win_drift, 4 * n_win);
+    if (win_pm) std::memcpy(h + I.pm, win_pm, 24 * n_win);
+    if (scaled_slot) std::memcpy(h + I.ss, scaled_slot, 4 * n_win);
+    if (trans_slot) std::memcpy(h + I.ts, trans_slot, 4 * n_win);
+    if (st_params) std::memcpy(h + I.sp, st_params, 8 * n_win);
+    if (n_jobs) std::memcpy(h + I.jf, job_first_win, 4 * (n_jobs + 1));
+    // device staging: [descriptors, as above] [results, as above] cmean | stdv | log stdv | six pm sums per event
+    const size_t o_out = I.bytes, o_cm = o_out + O.bytes, o_sd = o_cm + al256(4 * total), o_ls = o_sd + al256(4 * total), o_ps = o_ls + al256(4 * total);
+    const size_t need = o_ps + al256(24 * total);
+    rc = ensure(c, &c->d_stage, &c->stage_bytes, need);
     if (rc != NCHMM_OK) return rc;
     char* d = (char*)c->d_stage;
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(d + o_off, off.data(), 8 * (n_win + 1), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d + o_src, win_src, 8 * n_win, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d + o_dr, win_drift, 4 * n_win, hipMemcpyHostToDevice, s));
-    if (win_pm) HIP_TRY(c, hipMemcpyAsync(d + o_pm, win_pm, 24 * n_win, hipMemcpyHostToDevice, s));
-    if (scaled_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ss, scaled_slot, 4 * n_win, hipMemcpyHostToDevice, s));
-    if (trans_slot) HIP_TRY(c, hipMemcpyAsync(d + o_ts, trans_slot, 4 * n_win, hipMemcpyHostToDevice, s));
-    if (st_params) HIP_TRY(c, hipMemcpyAsync(d + o_sp, st_params, 8 * n_win, hipMemcpyHostToDevice, s));
-    if (n_jobs) HIP_TRY(c, hipMemcpyAsync(d + o_jf, job_first_win, 4 * (n_jobs + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d, h, I.bytes, hipMemcpyHostToDevice, s));
     const size_t stride = (c->em_n_events + 63) & ~(size_t)63;
     const float* ev = (const float*)c->d_em_events;
     EmGatherArgs g;
     g.mean = ev; g.stdv = ev + stride; g.start = ev + 2 * stride; g.lstdv = ev + 3 * stride;
-    g.win_src = (const uint64_t*)(d + o_src); g.off = (const uint64_t*)(d + o_off); g.win_drift = (const float*)(d + o_dr);
+    g.win_src = (const uint64_t*)(d + I.src); g.off = (const uint64_t*)(d + I.off); g.win_drift = (const float*)(d + I.dr);
     g.cmean = (float*)(d + o_cm); g.out_stdv = (float*)(d + o_sd); g.out_lstdv = (float*)(d + o_ls);
     launch_em_gather(g, (unsigned)n_win, s, (unsigned)max_events);
     HIP_TRY(c, hipGetLastError());
-    rc = nchmm_fwbw_dev(c, n_win, max_events, total, (const uint64_t*)(d + o_off), (const float*)(d + o_cm), (const float*)(d + o_sd),
-                        (const float*)(d + o_ls), scaled_slot ? (const int32_t*)(d + o_ss) : nullptr,
-                        win_pm ? (const float*)(d + o_pm) : nullptr, trans_slot ? (const int32_t*)(d + o_ts) : nullptr,
-                        st_params ? (const float*)(d + o_sp) : nullptr, (float*)(d + o_lp), (float*)(d + o_ps), (float*)(d + o_st),
+    rc = nchmm_fwbw_dev(c, n_win, max_events, total, (const uint64_t*)(d + I.off), (const float*)(d + o_cm), (const float*)(d + o_sd),
+                        (const float*)(d + o_ls), scaled_slot ? (const int32_t*)(d + I.ss) : nullptr,
+                        win_pm ? (const float*)(d + I.pm) : nullptr, trans_slot ? (const int32_t*)(d + I.ts) : nullptr,
+                        st_params ? (const float*)(d + I.sp) : nullptr, (float*)(d + o_out + O.lp), (float*)(d + o_ps), (float*)(d + o_out + O.st),
                         nullptr, nullptr);
     if (rc != NCHMM_OK) return rc;
     if (n_jobs) {
         EmReduceArgs r;
         r.mean = g.mean; r.stdv = g.stdv; r.start = g.start; r.win_src = g.win_src; r.off = g.off;
-        r.job_first_win = (const uint32_t*)(d + o_jf); r.pm_sums = (const float*)(d + o_ps); r.train_drift = train_drift;
-        r.out = (double*)(d + o_ac);
+        r.job_first_win = (const uint32_t*)(d + I.jf); r.pm_sums = (const float*)(d + o_ps); r.train_drift = train_drift;
+        r.out = (double*)(d + o_out + O.ac);
         launch_em_reduce(r, (unsigned)n_jobs, s);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(out_acc, d + o_ac, 104 * n_jobs, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(c, hipMemcpyAsync(out_lpd, d + o_lp, 4 * n_win, hipMemcpyDeviceToHost, s));
-    if (out_st) HIP_TRY(c, hipMemcpyAsync(out_st, d + o_st, 12 * n_win, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    // (one copy back: the three result blocks are adjacent; a round without jobs leaves the last one unwritten and unread)
+    (void)want_st;
+    HIP_TRY(c, hipMemcpyAsync(h + I.bytes, d + o_out, O.bytes, hipMemcpyDeviceToHost, s));
+    pend->n_win = n_win; pend->n_jobs = n_jobs; pend->stream = (void*)s;
+    pend->h_lpd = (const float*)(h + I.bytes + O.lp); pend->h_st = (const float*)(h + I.bytes + O.st); pend->h_acc = (const double*)(h + I.bytes + O.ac);
     return NCHMM_OK;
 }
 
-}  // namespace
+int em_round_collect(nchmm_ctx* c, const EmPending& pend, float* out_lpd, float* out_st, double* out_acc)
+{
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)pend.stream));
+    std::memcpy(out_lpd, pend.h_lpd, 4 * pend.n_win);
+    if (out_st) std::memcpy(out_st, pend.h_st, 12 * pend.n_win);
+    if (pend.n_jobs && out_acc) std::memcpy(out_acc, pend.h_acc, 104 * pend.n_jobs);
+    return NCHMM_OK;
+}
+
+// The second lane computes on the stream of Viterbi lane 1 (idle while a context trains: its calls are one after the other) --
+// a stream of its own would be the fifth of the context, and the runtime maps streams onto four hardware queues in turn: it would
+// share the queue of the first lane and run behind it, not beside it (see kVitLanes).
+int em_lanes_prepare(nchmm_ctx* c, size_t pin_bytes, size_t events_lane0, size_t events_both)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    em_lane_select(c, 0);
+    EmLaneRes& o = c->em_other;
+    {
+        // the alpha rows of both lanes in the ONE workspace, lane 1's behind lane 0's share: a second workspace would be mapped on
+        // first use, 20 ms per GiB (nchmm_reserve_fb_workspace), which is more than the lanes save on a run of a few rounds
+        void* p = c->d_fb_ws;
+        size_t have = c->fb_ws_floats * sizeof(float);
+        const int rc = ensure(c, &p, &have, std::max<size_t>(events_both, 1) * kStates * sizeof(float));
+        c->d_fb_ws = (float*)p; c->fb_ws_floats = have / sizeof(float);
+        if (rc != NCHMM_OK) return rc;
+        o.d_fb_ws = c->d_fb_ws + events_lane0 * kStates;
+        o.fb_ws_floats = c->fb_ws_floats - events_lane0 * kStates;
+    }
+    if (!c->em_other_made) {
+        o.stream = c->lane[1].stream;
+        if (hipEventCreate(&o.ev_fb0) != hipSuccess || hipEventCreate(&o.ev_fb1) != hipSuccess) return NCHMM_E_HIP;
+        int rc = dev_alloc(c, (void**)&o.d_queue, sizeof(unsigned) * 16);
+        if (rc != NCHMM_OK) return rc;
+        HIP_TRY(c, hipMemset(o.d_queue, 0, sizeof(unsigned) * 16));
+        c->em_other_made = true;
+    }
+    // (nothing is in flight on either lane here: the arenas may move)
+    pin_bytes += pin_bytes / 8;
+    if (c->h_pin_bytes < pin_bytes) {
+        if (c->h_pin) { HIP_TRY(c, hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_bytes = 0; }
+        HIP_TRY(c, hipHostMalloc(&c->h_pin, pin_bytes, hipHostMallocDefault));
+        c->h_pin_bytes = pin_bytes;
+    }
+    if (o.h_pin_bytes < pin_bytes) {
+        if (o.h_pin) { HIP_TRY(c, hipHostFree(o.h_pin)); o.h_pin = nullptr; o.h_pin_bytes = 0; }
+        HIP_TRY(c, hipHostMalloc(&o.h_pin, pin_bytes, hipHostMallocDefault));
+        o.h_pin_bytes = pin_bytes;
+    }
+    return NCHMM_OK;
+}
+
+void em_lanes_async(nchmm_ctx* c, bool on) { c->em_async = on; }
+
+void em_lanes_end(nchmm_ctx* c)
+{
+    c->em_async = false;
+    (void)em_lanes_wait(c);
+    em_lane_select(c, 0);
+    c->em_other.d_fb_ws = nullptr; c->em_other.fb_ws_floats = 0;      // (a view into lane 0's workspace, which may move from here on)
+}
+
+void em_lane_rewind(nchmm_ctx* c) { c->pin_cursor = 0; }
+size_t em_fb_cap_events(nchmm_ctx* c) { return fb_budget_events(c, (size_t)kStates * sizeof(float)); }
+
+int em_lanes_wait(nchmm_ctx* c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->em_other_made && c->em_other.stream) HIP_TRY(c, hipStreamSynchronize(c->em_other.stream));
+    return NCHMM_OK;
+}
+
+void em_lane_select(nchmm_ctx* c, int lane)
+{
+    if (c->em_lane == lane) return;
+    EmLaneRes& o = c->em_other;
+    std::swap(c->stream, o.stream);
+    std::swap(c->d_stage, o.d_stage); std::swap(c->stage_bytes, o.stage_bytes);
+    std::swap(c->d_fb_ws, o.d_fb_ws); std::swap(c->fb_ws_floats, o.fb_ws_floats);
+    std::swap(c->d_fb_aux, o.d_fb_aux); std::swap(c->fb_aux_bytes, o.fb_aux_bytes);
+    std::swap(c->d_queue, o.d_queue);
+    std::swap(c->d_tab_stage, o.d_tab_stage); std::swap(c->tab_stage_bytes, o.tab_stage_bytes);
+    std::swap(c->h_pin, o.h_pin); std::swap(c->h_pin_bytes, o.h_pin_bytes); std::swap(c->pin_cursor, o.pin_cursor);
+    std::swap(c->ev_fb0, o.ev_fb0); std::swap(c->ev_fb1, o.ev_fb1); std::swap(c->fb_timed, o.fb_timed);
+    c->em_lane = lane;
+}
+
+}  // namespace nchmm
 
 extern "C" {
 

@@ -35,6 +35,21 @@ struct VitLaneState {
     bool joined = true;              // ... and a stream already waits for it (viterbi_join queued the stream wait on joined_to)
     hipStream_t joined_to = nullptr;
 };
+// What one EM round uses on the device and must keep to itself while it is in flight: a stream, the staging buffers, the alpha
+// rows, the work-queue words, a pinned host arena.  The context holds two sets -- its own fields and `em_other` -- and
+// em_lane_select swaps them, so that every function that queues forward-backward work runs unchanged on either.
+// nchmm_train_reads keeps the rounds of one half of its jobs on the device while the host finishes and prepares the other half's.
+struct EmLaneRes {
+    hipStream_t stream = nullptr;
+    void* d_stage = nullptr; size_t stage_bytes = 0;
+    float* d_fb_ws = nullptr; size_t fb_ws_floats = 0;
+    void* d_fb_aux = nullptr; size_t fb_aux_bytes = 0;
+    unsigned* d_queue = nullptr;
+    void* d_tab_stage = nullptr; size_t tab_stage_bytes = 0;
+    void* h_pin = nullptr; size_t h_pin_bytes = 0, pin_cursor = 0;
+    hipEvent_t ev_fb0 = nullptr, ev_fb1 = nullptr;
+    bool fb_timed = false;
+};
 }  // namespace nchmm
 
 struct nchmm_ctx {
@@ -115,8 +130,14 @@ struct nchmm_ctx {
     size_t tab_stage_bytes = 0;
     void* h_pin = nullptr;          // pinned host buffer for the batched table uploads (reused across calls)
     size_t h_pin_bytes = 0;
+    size_t pin_cursor = 0;          // em_async: what of the pinned buffer this round has handed out
     hipEvent_t ev_fb0 = nullptr, ev_fb1 = nullptr;
     bool vit_timed = false, fb_timed = false;
+    nchmm::EmLaneRes em_other;      // the resources of the EM lane that is NOT selected (lane 1 until em_lane_select(c, 1))
+    int em_lane = 0;                // which lane's resources the fields above are
+    bool em_other_made = false;
+    bool em_async = false;          // table uploads and EM rounds queue their work and return (nchmm_train_reads waits per lane);
+                                    // the pinned buffer is handed out piecewise, not reused, until the lane has been waited for
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int n_slots = 0;                // capacity of the model / transition slot tables (grows on demand)
     std::vector<char> model_set, trans_set;
@@ -157,6 +178,8 @@ int viterbi_join(nchmm_ctx* c, hipStream_t s);
 int viterbi_check_err(nchmm_ctx* c);
 int viterbi_ws_budget(nchmm_ctx* c, size_t* out);
 void mask_weights(float p_skip, float p_stay, float wm[64]);   // nchmm_api.cpp
+
+// (the EM lanes' functions: nchmm_internal.hpp -- their user, nchmm_train.cpp, is compiled without HIP)
 
 #define HIP_TRY(ctx, expr)                                  \
     do {                                                    \

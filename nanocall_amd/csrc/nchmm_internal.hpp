@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
+#include <cstdint>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -82,5 +84,30 @@ inline void step_params(float p_skip, float p_stay, float& p_step, float& p_skip
     p_skip_1 = static_cast<float>(p_skip / (p_skip + 1.0));
 }
 
+}  // namespace nchmm
+
+// ---- EM rounds on two lanes (nchmm_api.cpp; used by nchmm_train.cpp, which is compiled without HIP: no runtime types here) ----
+// A context holds two sets of what an EM round uses on the device (nchmm_ctx.hpp: EmLaneRes); every function that queues
+// forward-backward work runs on the selected one.  With `async` on, table uploads and rounds queue their work on the selected
+// lane and return; the lane's pinned arena is handed out piecewise until em_lane_rewind (after the lane has been waited for).
+struct nchmm_ctx;
+namespace nchmm {
+struct EmPending { size_t n_win = 0, n_jobs = 0; const float* h_lpd = nullptr; const float* h_st = nullptr; const double* h_acc = nullptr; void* stream = nullptr; };
+// make the second lane (first use): `pin_bytes` of arena on both, the alpha rows of `events_both` events with lane 1's share behind
+// the first `events_lane0`; lane 0 selected, nothing in flight
+int em_lanes_prepare(nchmm_ctx* c, size_t pin_bytes, size_t events_lane0, size_t events_both);
+void em_lanes_end(nchmm_ctx* c);                             // async off, both lanes waited for, lane 0 selected
+void em_lane_select(nchmm_ctx* c, int lane);                 // the context's forward-backward fields become those of `lane` (0 / 1)
+void em_lanes_async(nchmm_ctx* c, bool on);
+void em_lane_rewind(nchmm_ctx* c);                           // the selected lane's arena from its start again
+int em_lanes_wait(nchmm_ctx* c);                             // everything queued on either lane has finished
+size_t em_round_pin_bytes(size_t n_win, size_t n_jobs);      // arena one round with its table uploads takes
+size_t em_fb_cap_events(nchmm_ctx* c);                       // events whose alpha rows one launch may hold (the forward-backward budget)
+// One round of nchmm_em_round queued on the selected lane: inputs copied to its arena, results land there ...
+int em_round_enqueue(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift, const float* win_pm,
+                     const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params, size_t n_jobs, const uint32_t* job_first_win,
+                     int train_drift, bool want_st, EmPending* pend);
+// ... and copied out once the round's stream has been waited for.
+int em_round_collect(nchmm_ctx* c, const EmPending& pend, float* out_lpd, float* out_st, double* out_acc);
 }  // namespace nchmm
 #endif

@@ -163,71 +163,145 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     const bool dbg_time = std::getenv("NCHMM_DEBUG") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    std::vector<size_t> act;
     const auto t_rounds = now();
-    for (;;) {
+
+    // The jobs train in one part or in two.  Two (a call with enough jobs): each part keeps to one EM lane of the context
+    // (nchmm_internal.hpp), its rounds queued there without waiting -- while the device runs the round of one part, the host
+    // finishes the other part's previous round (the 3 x 3 solves, the stop rules) and queues its next one, so the device does not
+    // wait for the host between rounds (a seventh of a round's time at config-3 size, profiles/r06_notes.md section 13).  A job's
+    // rounds are the same in either arrangement: windows are independent in the kernels, jobs on the host.
+    struct Part {
+        std::vector<size_t> act;                     // its jobs that still train
+        int slot0 = 0;                               // its (job, strand) tables: model slots n_models + slot0 + ..., transition slots 1 + slot0 + ...
+        size_t na = 0, n_win = 0;                    // the round in flight
+        std::vector<uint32_t> first_win;
+        std::vector<size_t> job_events;
+        std::vector<float> lpd, st_sums;
+        std::vector<double> acc;
+        nchmm::EmPending pend;
+        bool in_flight = false;
+        double t_prep = 0, t_tables = 0, t_queue = 0;
+    };
+    Part part[2];
+    size_t n_act = 0, ev_act = 0;
+    for (size_t k = 0; k < n_jobs; ++k)
+        if (jobs[k].active) { ++n_act; for (const Window& w : jobs[k].win) ev_act += w.len; }
+    if (n_act == 0) goto rounds_done;
+    {
+    const char* lanes_env = std::getenv("NCHMM_EM_LANES");
+    const size_t cap = nchmm::em_fb_cap_events(ctx);
+    // (the two parts' alpha rows share the one workspace: a round over the budget trains in one part, cut by nchmm_em_round)
+    const bool two = (lanes_env ? std::atoi(lanes_env) >= 2 : true) && n_act >= 64 && ev_act <= cap;
+    {
+        // split by events, in job order
+        size_t ev = 0;
+        for (size_t k = 0; k < n_jobs; ++k) {
+            if (!jobs[k].active) continue;
+            Part& P = part[two && 2 * ev >= ev_act ? 1 : 0];
+            P.act.push_back(k);
+            for (const Window& w : jobs[k].win) ev += w.len;
+        }
+        part[1].slot0 = 2 * (int)part[0].act.size();
+    }
+    if ((rc = nchmm_reserve_slots(ctx, (int)std::max<size_t>(n_models, 1) + 2 * (int)n_act + 2))) return rc;
+    struct Lanes_Guard {       // whatever way this function is left: nothing in flight, lane 0 selected, calls wait again
+        nchmm_ctx* c; bool on;
+        ~Lanes_Guard() { if (on) nchmm::em_lanes_end(c); }
+    } guard{ctx, two};
+    if (two) {
+        size_t w_max = 0, j_max = 0, ev0 = 0;
+        for (const Part& P : part) {
+            size_t nw = 0;
+            for (size_t k : P.act) nw += jobs[k].win.size();
+            w_max = std::max(w_max, nw); j_max = std::max(j_max, P.act.size());
+        }
+        for (size_t k : part[0].act) for (const Window& w : jobs[k].win) ev0 += w.len;
+        if ((rc = nchmm::em_lanes_prepare(ctx, nchmm::em_round_pin_bytes(w_max, j_max), ev0, ev_act))) return rc;
+        nchmm::em_lanes_async(ctx, true);
+    }
+
+    // ---- Parameter_Trainer::fill_train_data (Parameter_Trainer.hpp:99-155), all the part's active jobs at once: queue one round ----
+    auto queue_round = [&](Part& P, int lane) -> int {
         const auto t_0 = now();
-        act.clear();
-        for (size_t k = 0; k < n_jobs; ++k) if (jobs[k].active) act.push_back(k);
-        if (act.empty()) break;
-        const size_t na = act.size();
-        // ---- Parameter_Trainer::fill_train_data (Parameter_Trainer.hpp:99-155), all active jobs at once ----
-        std::vector<int32_t> m_idx(2 * na, 0); std::vector<float> m_par(12 * na, 0.f);   // scaled models: slot n_models + 2p + s
+        const size_t na = P.act.size();
+        P.na = na;
+        std::vector<int32_t> m_idx(2 * na, 0); std::vector<float> m_par(12 * na, 0.f);   // scaled models: slot n_models + slot0 + 2p + s
         std::vector<float> t_skip(2 * na, o->default_p_skip), t_stay(2 * na, o->default_p_stay);
         // per-window descriptors (the drift correction and SoA packing of :130-140 happen on the device)
-        std::vector<uint32_t> first_win(na + 1, 0);
-        for (size_t p = 0; p < na; ++p) first_win[p + 1] = first_win[p] + (uint32_t)jobs[act[p]].win.size();
-        const size_t n_win = first_win[na];
+        P.first_win.assign(na + 1, 0);
+        for (size_t p = 0; p < na; ++p) P.first_win[p + 1] = P.first_win[p] + (uint32_t)jobs[P.act[p]].win.size();
+        const size_t n_win = P.first_win[na];
+        P.n_win = n_win;
         std::vector<uint64_t> w_src(n_win);
         std::vector<uint32_t> w_len(n_win);
         std::vector<float> w_drift(n_win), stp(2 * n_win), w_pm(6 * n_win);   // w_pm: the parameters behind the window's scaled model
         std::vector<int32_t> s_slot(n_win), t_slot(n_win);
-        std::vector<size_t> job_events(na, 0);
+        P.job_events.assign(na, 0);
         for (size_t p = 0; p < na; ++p) {
-            Job& j = jobs[act[p]];
+            Job& j = jobs[P.act[p]];
             std::memcpy(j.old_pm, j.pm, sizeof(j.pm)); std::memcpy(j.old_st, j.st, sizeof(j.st)); j.old_fit = j.fit;
             for (int s = 0; s < 2; ++s) {
                 m_idx[2 * p + s] = j.m[s] >= 0 ? j.m[s] : std::max(j.m[0], j.m[1]);
                 std::memcpy(&m_par[6 * (2 * p + s)], j.old_pm, sizeof(j.old_pm));
                 t_stay[2 * p + s] = j.old_st[2 * s]; t_skip[2 * p + s] = j.old_st[2 * s + 1];
             }
-            size_t wi = first_win[p];
+            size_t wi = P.first_win[p];
             for (const Window& w : j.win) {
                 w_src[wi] = w.begin; w_len[wi] = w.len; w_drift[wi] = j.old_pm[2];   // apply_drift_correction, Event.hpp:77-84
-                job_events[p] += w.len;
-                s_slot[wi] = (int32_t)(n_models + 2 * p + w.strand);
+                P.job_events[p] += w.len;
+                s_slot[wi] = (int32_t)(n_models + (size_t)P.slot0 + 2 * p + w.strand);
                 std::memcpy(&w_pm[6 * wi], j.old_pm, sizeof(j.old_pm));
                 // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
                 const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
-                t_slot[wi] = dflt ? 0 : (int32_t)(1 + 2 * p + w.strand);
+                t_slot[wi] = dflt ? 0 : (int32_t)(1 + (size_t)P.slot0 + 2 * p + w.strand);
                 stp[2 * wi] = j.old_st[2 * w.strand]; stp[2 * wi + 1] = j.old_st[2 * w.strand + 1];
                 ++wi;
             }
         }
         const auto t_1 = now();
-        if ((rc = nchmm_put_models_scaled(ctx, (int)n_models, 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
-        if ((rc = nchmm_put_transitions_fast(ctx, 1, 2 * na, t_skip.data(), t_stay.data()))) return rc;
+        int rc;
+        if (two) { nchmm::em_lane_select(ctx, lane); nchmm::em_lane_rewind(ctx); }
+        if ((rc = nchmm_put_models_scaled(ctx, (int)n_models + P.slot0, 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
+        if ((rc = nchmm_put_transitions_fast(ctx, 1 + P.slot0, 2 * na, t_skip.data(), t_stay.data()))) return rc;
         const auto t_2 = now();
         // forward-backward, inner and outer sums on the device: 13 doubles per job come back
-        std::vector<float> lpd(n_win), st_sums(3 * n_win);
-        std::vector<double> acc(13 * na);
-        rc = nchmm_em_round(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
-                            na, first_win.data(), o->train_drift, lpd.data(), st_sums.data(), acc.data());
+        P.lpd.resize(n_win); P.st_sums.resize(3 * n_win); P.acc.resize(13 * na);
+        if (two)
+            rc = nchmm::em_round_enqueue(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
+                                         na, P.first_win.data(), o->train_drift, true, &P.pend);
+        else
+            rc = nchmm_em_round(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
+                                na, P.first_win.data(), o->train_drift, P.lpd.data(), P.st_sums.data(), P.acc.data());
         if (rc != NCHMM_OK) return rc;
-        const auto t_3 = now();
-        // ---- finish the round per job (Parameter_Trainer.hpp:557-578) and apply the stop rules ----
+        P.in_flight = true;
+        P.t_prep = ms(t_0, t_1); P.t_tables = ms(t_1, t_2); P.t_queue = ms(t_2, now());
+        return NCHMM_OK;
+    };
+
+    // ---- wait for the part's round, finish it per job (Parameter_Trainer.hpp:557-578), apply the stop rules ----
+    auto finish_round = [&](Part& P, int lane) -> int {
+        const auto t_0 = now();
+        if (two) {
+            nchmm::em_lane_select(ctx, lane);
+            const int rc = nchmm::em_round_collect(ctx, P.pend, P.lpd.data(), P.st_sums.data(), P.acc.data());
+            if (rc != NCHMM_OK) return rc;
+        }
+        P.in_flight = false;
+        const auto t_1 = now();
+        const size_t na = P.na;
+        const std::vector<float>& lpd = P.lpd; const std::vector<float>& st_sums = P.st_sums; const std::vector<double>& acc = P.acc;
         std::atomic<int> first_err{NCHMM_OK};
         parallel_for(na, [&](size_t p_lo, size_t p_hi) {
         for (size_t p = p_lo; p < p_hi; ++p) {
-            Job& j = jobs[act[p]];
-            const size_t w0 = first_win[p], w1 = first_win[p + 1];
+            Job& j = jobs[P.act[p]];
+            const size_t w0 = P.first_win[p], w1 = P.first_win[p + 1];
             float fit = 0;
             for (size_t w = w0; w < w1; ++w) fit += lpd[w];   // data.fit += log_pr_data, :154
             j.fit = fit;
             bool done = false;
             if (o->train_scaling) {
                 int d = 0;
-                const int rc = nchmm_train_pm_solve(job_events[p], &acc[13 * p], o->train_drift, j.old_pm, j.pm, &d);
+                const int rc = nchmm_train_pm_solve(P.job_events[p], &acc[13 * p], o->train_drift, j.old_pm, j.pm, &d);
                 if (rc != NCHMM_OK) { first_err = rc; return; }
                 done = d != 0;
             }
@@ -257,10 +331,28 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         }
         });
         if (first_err != NCHMM_OK) return first_err;
+        // (the part's jobs keep their places relative to each other; its tables are rewritten from slot0 every round)
+        size_t kept = 0;
+        for (size_t p = 0; p < na; ++p) if (jobs[P.act[p]].active) P.act[kept++] = P.act[p];
+        P.act.resize(kept);
         if (dbg_time)
-            std::fprintf(stderr, "[nchmm_train_reads] round: %zu jobs, gather %.2f ms, tables %.2f ms, fwbw %.2f ms, finish %.2f ms\n", na,
-                         ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3), ms(t_3, now()));
+            std::fprintf(stderr, "[nchmm_train_reads] round%s: %zu jobs, gather %.2f ms, tables %.2f ms, %s %.2f ms, finish %.2f ms\n", two ? (lane ? " (lane 1)" : " (lane 0)") : "", na,
+                         P.t_prep, P.t_tables, two ? "queued in" : "fwbw", P.t_queue, ms(t_1, now()));
+        (void)t_0;
+        return NCHMM_OK;
+    };
+
+    for (int h = 0; h < 2; ++h)
+        if (!part[h].act.empty() && (rc = queue_round(part[h], h))) return rc;
+    while (part[0].in_flight || part[1].in_flight)
+        for (int h = 0; h < 2; ++h) {
+            Part& P = part[h];
+            if (!P.in_flight) continue;
+            if ((rc = finish_round(P, h))) return rc;
+            if (!P.act.empty() && (rc = queue_round(P, h))) return rc;
+        }
     }
+rounds_done:
     if (dbg_time)
         std::fprintf(stderr, "[nchmm_train_reads] %zu jobs of %zu reads: setup (windows, job table, events up) %.2f ms, rounds %.2f ms\n", n_jobs, n_reads,
                      ms(t_call, t_rounds), ms(t_rounds, now()));

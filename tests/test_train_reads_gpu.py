@@ -98,6 +98,54 @@ def test_train_reads_matches_reference_loop(gpu_ctx):
     assert out["preferred"][2, 1] == -1 and out["preferred"][0, 0] == -1
 
 
+def test_jobs_trained_in_two_parts_on_two_lanes_equal_the_one_part_run(gpu_ctx, monkeypatch):
+    """A call with 64 jobs or more trains them in two parts, each on its own EM lane of the context, so that the host's share of
+    one part's round hides behind the other part's kernels (nchmm_train.cpp).  A job's rounds do not depend on what it is batched
+    with: 60 reads -- 2D with two complement candidates, template only, of adversarial kinds (some of their jobs stop early, some
+    roll back, so the parts shrink unevenly) -- give bit-identical parameters, fits, round counts and preferences whether they
+    train in one part (NCHMM_EM_LANES=1) or two, and on a second call of the same context (the lanes' buffers reused)."""
+    import adversarial
+    opts = api.train_opts(scaling_max_rounds=3, scaling_num_events=160, scaling_select_threshold=5.0)
+    names = ["r73.c.p1", "r73.c.p2", "r73.t"]
+    strands = [1, 1, 0]
+    tables = [na.builtin_model(n) for n in names]
+    states = np.stack([na.model_load(t) for t in tables])
+    rng = np.random.default_rng(77)
+    mean, stdv, start, so, together = [], [], [], [0], []
+    params = (1.05, -2.0, 0.0004, 1.2, 0.95, 1.3)
+    for r in range(60):
+        two_d = r % 3 != 2
+        for s in range(2):
+            n = int(rng.integers(100, 900)) if (s == 0 or two_d) else 0
+            if n:
+                kind = adversarial.KINDS[(r + s) % len(adversarial.KINDS)] if r % 4 == 0 else "matched"
+                m, sd, t = adversarial.events(kind, tables[2] if s == 0 else tables[r % 2], params, n, seed=4000 + 2 * r + s, other_table=tables[1])
+                _, sd, _ = na.events_prepare(m, sd, t, 0.0)
+                mean.append(m); stdv.append(sd); start.append(t)
+            so.append(so[-1] + n)
+        together.append(1 if two_d else 0)
+    mean, stdv, start = np.concatenate(mean), np.concatenate(stdv), np.concatenate(start)
+    so = np.array(so, np.uint64)
+    jr, j0, j1 = api.train_enumerate(opts, strands, so, together)
+    assert len(jr) >= 64
+    monkeypatch.setenv("NCHMM_EM_LANES", "1")
+    one = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    monkeypatch.delenv("NCHMM_EM_LANES")
+    two = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    again = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    assert len(set(one["rounds"].tolist())) > 1                      # the jobs do not all stop together
+    for other in (two, again):
+        for k in ("pm", "st", "fit", "rounds", "preferred"):
+            assert one[k].tobytes() == other[k].tobytes(), k
+    # ... and a Viterbi launch behind it finds its lanes as they were (the second EM lane computes on Viterbi lane 1's stream)
+    cm, sd, ls = na.events_prepare(mean[:700], stdv[:700], start[:700], 0.0)
+    gpu_ctx.put_model(0, na.scaled_model_table(tables[2]))
+    gpu_ctx.put_transitions(0, *na.transitions_fast(0.3, 0.1))
+    s1, lp1, st1 = gpu_ctx.viterbi(np.array([0, 700], np.uint64), cm, sd, ls)
+    s2, lp2, st2 = gpu_ctx.viterbi(np.array([0, 700], np.uint64), cm, sd, ls)
+    assert st1[0] == 0 and np.array_equal(s1, s2) and lp1[0] == lp2[0]
+
+
 def test_basecall_reads_picks_best_model_and_matches_oracle(gpu_ctx):
     """basecall_reads: candidates decoded with their own parameters, winner by (summed) path log-prob."""
     opts = api.train_opts()
