@@ -98,7 +98,16 @@ def test_train_reads_matches_reference_loop(gpu_ctx):
     assert out["preferred"][2, 1] == -1 and out["preferred"][0, 0] == -1
 
 
-def test_jobs_trained_in_two_parts_on_two_lanes_equal_the_one_part_run(gpu_ctx, monkeypatch):
+@pytest.fixture
+def own_ctx():
+    """(a context of its own: a hundred jobs fill model / transition slots that tests of the shared context expect unset)"""
+    ctx = na.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def test_jobs_trained_in_two_parts_on_two_lanes_equal_the_one_part_run(own_ctx, monkeypatch):
+    gpu_ctx = own_ctx
     """A call with 64 jobs or more trains them in two parts, each on its own EM lane of the context, so that the host's share of
     one part's round hides behind the other part's kernels (nchmm_train.cpp).  A job's rounds do not depend on what it is batched
     with: 60 reads -- 2D with two complement candidates, template only, of adversarial kinds (some of their jobs stop early, some
