@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -165,14 +166,14 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_rounds = now();
 
-    // The jobs train in one part or in two.  Two (a call with enough jobs): each part keeps to one EM lane of the context
-    // (nchmm_internal.hpp), its rounds queued there without waiting -- while the device runs the round of one part, the host
-    // finishes the other part's previous round (the 3 x 3 solves, the stop rules) and queues its next one, so the device does not
-    // wait for the host between rounds (a seventh of a round's time at config-3 size, profiles/r06_notes.md section 13).  A job's
-    // rounds are the same in either arrangement: windows are independent in the kernels, jobs on the host.
+    // The jobs train in one part or in several.  Several (a call with enough jobs): parts of at most half the forward-backward
+    // budget's alpha rows, taking turns on the two EM lanes of the context (nchmm_internal.hpp); a part's round is queued on a lane
+    // without waiting -- while the device runs it, the host finishes the round of the part on the other lane (the 3 x 3 solves,
+    // the stop rules) and queues the next part there, so the device does not wait for the host between rounds (a seventh of a
+    // round's time at config-3 size, profiles/r06_notes.md section 13) and the workspace is two parts' rows however many jobs
+    // the call brings.  A job's rounds are the same in any arrangement: windows are independent in the kernels, jobs on the host.
     struct Part {
         std::vector<size_t> act;                     // its jobs that still train
-        int slot0 = 0;                               // its (job, strand) tables: model slots n_models + slot0 + ..., transition slots 1 + slot0 + ...
         size_t na = 0, n_win = 0;                    // the round in flight
         std::vector<uint32_t> first_win;
         std::vector<size_t> job_events;
@@ -182,7 +183,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         bool in_flight = false;
         double t_prep = 0, t_tables = 0, t_queue = 0;
     };
-    Part part[2];
+    std::vector<Part> part;
+    size_t lane_slot0[2] = {0, 0};                   // the (job, strand) tables of the part on lane h: model slots n_models + lane_slot0[h] + ..., transition slots 1 + lane_slot0[h] + ...
     size_t n_act = 0, ev_act = 0;
     for (size_t k = 0; k < n_jobs; ++k)
         if (jobs[k].active) { ++n_act; for (const Window& w : jobs[k].win) ev_act += w.len; }
@@ -190,33 +192,39 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
     {
     const char* lanes_env = std::getenv("NCHMM_EM_LANES");
     const size_t cap = nchmm::em_fb_cap_events(ctx);
-    // (the two parts' alpha rows share the one workspace: a round over the budget trains in one part, cut by nchmm_em_round)
-    const bool two = (lanes_env ? std::atoi(lanes_env) >= 2 : true) && n_act >= 64 && ev_act <= cap;
+    const bool two = (lanes_env ? std::atoi(lanes_env) >= 2 : true) && n_act >= 64;
+    // one part (few jobs: a round over the budget is cut by nchmm_em_round), or as many as it takes to keep each within half the
+    // budget, at least two, of about equal events, in job order
+    const size_t n_parts = two ? std::max<size_t>(2, (ev_act + cap / 2 - 1) / std::max<size_t>(cap / 2, 1)) : 1;
+    part.resize(n_parts);
+    size_t w_max = 0, j_max = 0, ev_max = 0;
     {
-        // split by events, in job order
         size_t ev = 0;
+        std::vector<size_t> part_ev(n_parts, 0), part_win(n_parts, 0);
         for (size_t k = 0; k < n_jobs; ++k) {
             if (!jobs[k].active) continue;
-            Part& P = part[two && 2 * ev >= ev_act ? 1 : 0];
-            P.act.push_back(k);
-            for (const Window& w : jobs[k].win) ev += w.len;
+            size_t mine = 0;
+            for (const Window& w : jobs[k].win) mine += w.len;
+            size_t q = std::min(n_parts - 1, (size_t)((unsigned __int128)ev * n_parts / std::max<size_t>(ev_act, 1)));
+            // (a job's windows stay together: one that would take its part over the lane's share opens the next part -- the parts were counted with room for that)
+            if (two && part_ev[q] && part_ev[q] + mine > cap / 2 && q + 1 < n_parts) ++q;
+            part[q].act.push_back(k);
+            part_ev[q] += mine; part_win[q] += jobs[k].win.size();
+            ev += mine;
         }
-        part[1].slot0 = 2 * (int)part[0].act.size();
+        for (size_t q = 0; q < n_parts; ++q) {
+            w_max = std::max(w_max, part_win[q]); j_max = std::max(j_max, part[q].act.size()); ev_max = std::max(ev_max, part_ev[q]);
+        }
     }
-    if ((rc = nchmm_reserve_slots(ctx, (int)std::max<size_t>(n_models, 1) + 2 * (int)n_act + 2))) return rc;
+    lane_slot0[1] = two ? 2 * j_max : 0;
+    if ((rc = nchmm_reserve_slots(ctx, (int)std::max<size_t>(n_models, 1) + (int)(two ? 4 * j_max : 2 * n_act) + 2))) return rc;
     struct Lanes_Guard {       // whatever way this function is left: nothing in flight, lane 0 selected, calls wait again
         nchmm_ctx* c; bool on;
         ~Lanes_Guard() { if (on) nchmm::em_lanes_end(c); }
     } guard{ctx, two};
     if (two) {
-        size_t w_max = 0, j_max = 0, ev0 = 0;
-        for (const Part& P : part) {
-            size_t nw = 0;
-            for (size_t k : P.act) nw += jobs[k].win.size();
-            w_max = std::max(w_max, nw); j_max = std::max(j_max, P.act.size());
-        }
-        for (size_t k : part[0].act) for (const Window& w : jobs[k].win) ev0 += w.len;
-        if ((rc = nchmm::em_lanes_prepare(ctx, nchmm::em_round_pin_bytes(w_max, j_max), ev0, ev_act))) return rc;
+        // (a part over the lane's share -- one job's windows alone can be -- still runs: the workspace grows to twice the largest part)
+        if ((rc = nchmm::em_lanes_prepare(ctx, nchmm::em_round_pin_bytes(w_max, j_max), ev_max, 2 * ev_max))) return rc;
         nchmm::em_lanes_async(ctx, true);
     }
 
@@ -225,6 +233,7 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         const auto t_0 = now();
         const size_t na = P.act.size();
         P.na = na;
+        const size_t slot0 = lane_slot0[lane];
         std::vector<int32_t> m_idx(2 * na, 0); std::vector<float> m_par(12 * na, 0.f);   // scaled models: slot n_models + slot0 + 2p + s
         std::vector<float> t_skip(2 * na, o->default_p_skip), t_stay(2 * na, o->default_p_stay);
         // per-window descriptors (the drift correction and SoA packing of :130-140 happen on the device)
@@ -249,11 +258,11 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             for (const Window& w : j.win) {
                 w_src[wi] = w.begin; w_len[wi] = w.len; w_drift[wi] = j.old_pm[2];   // apply_drift_correction, Event.hpp:77-84
                 P.job_events[p] += w.len;
-                s_slot[wi] = (int32_t)(n_models + (size_t)P.slot0 + 2 * p + w.strand);
+                s_slot[wi] = (int32_t)(n_models + slot0 + 2 * p + w.strand);
                 std::memcpy(&w_pm[6 * wi], j.old_pm, sizeof(j.old_pm));
                 // is_default(): compares against the CLI defaults (State_Transitions.hpp:34-37)
                 const bool dflt = j.old_st[2 * w.strand] == o->default_p_stay && j.old_st[2 * w.strand + 1] == o->default_p_skip;
-                t_slot[wi] = dflt ? 0 : (int32_t)(1 + (size_t)P.slot0 + 2 * p + w.strand);
+                t_slot[wi] = dflt ? 0 : (int32_t)(1 + slot0 + 2 * p + w.strand);
                 stp[2 * wi] = j.old_st[2 * w.strand]; stp[2 * wi + 1] = j.old_st[2 * w.strand + 1];
                 ++wi;
             }
@@ -261,8 +270,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         const auto t_1 = now();
         int rc;
         if (two) { nchmm::em_lane_select(ctx, lane); nchmm::em_lane_rewind(ctx); }
-        if ((rc = nchmm_put_models_scaled(ctx, (int)n_models + P.slot0, 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
-        if ((rc = nchmm_put_transitions_fast(ctx, 1 + P.slot0, 2 * na, t_skip.data(), t_stay.data()))) return rc;
+        if ((rc = nchmm_put_models_scaled(ctx, (int)(n_models + slot0), 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
+        if ((rc = nchmm_put_transitions_fast(ctx, (int)(1 + slot0), 2 * na, t_skip.data(), t_stay.data()))) return rc;
         const auto t_2 = now();
         // forward-backward, inner and outer sums on the device: 13 doubles per job come back
         P.lpd.resize(n_win); P.st_sums.resize(3 * n_win); P.acc.resize(13 * na);
@@ -342,15 +351,27 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         return NCHMM_OK;
     };
 
-    for (int h = 0; h < 2; ++h)
-        if (!part[h].act.empty() && (rc = queue_round(part[h], h))) return rc;
-    while (part[0].in_flight || part[1].in_flight)
-        for (int h = 0; h < 2; ++h) {
-            Part& P = part[h];
-            if (!P.in_flight) continue;
-            if ((rc = finish_round(P, h))) return rc;
-            if (!P.act.empty() && (rc = queue_round(P, h))) return rc;
-        }
+    // the parts take turns: whichever lane comes free takes the part that has waited longest for its next round
+    std::deque<size_t> waiting;
+    for (size_t q = 0; q < n_parts; ++q) if (!part[q].act.empty()) waiting.push_back(q);
+    long on_lane[2] = {-1, -1};
+    auto fill = [&](int lane) -> int {
+        if (waiting.empty()) return NCHMM_OK;
+        const size_t q = waiting.front();
+        waiting.pop_front();
+        on_lane[lane] = (long)q;
+        return queue_round(part[q], lane);
+    };
+    const int n_lanes = two ? 2 : 1;
+    for (int h = 0; h < n_lanes; ++h) if ((rc = fill(h))) return rc;
+    for (int h = 0; on_lane[0] >= 0 || on_lane[1] >= 0; h = (h + 1) % n_lanes) {
+        if (on_lane[h] < 0) continue;
+        Part& P = part[(size_t)on_lane[h]];
+        if ((rc = finish_round(P, h))) return rc;
+        if (!P.act.empty()) waiting.push_back((size_t)on_lane[h]);
+        on_lane[h] = -1;
+        if ((rc = fill(h))) return rc;
+    }
     }
 rounds_done:
     if (dbg_time)
