@@ -112,7 +112,8 @@ def test_jobs_trained_in_two_parts_on_two_lanes_equal_the_one_part_run(own_ctx, 
     one part's round hides behind the other part's kernels (nchmm_train.cpp).  A job's rounds do not depend on what it is batched
     with: 60 reads -- 2D with two complement candidates, template only, of adversarial kinds (some of their jobs stop early, some
     roll back, so the parts shrink unevenly) -- give bit-identical parameters, fits, round counts and preferences whether they
-    train in one part (NCHMM_EM_LANES=1) or two, and on a second call of the same context (the lanes' buffers reused)."""
+    train in one part (NCHMM_EM_LANES=1), two, or twenty (a small forward-backward budget), and on a second call of the same context
+    (the lanes' buffers reused)."""
     import adversarial
     opts = api.train_opts(scaling_max_rounds=3, scaling_num_events=160, scaling_select_threshold=5.0)
     names = ["r73.c.p1", "r73.c.p2", "r73.t"]
@@ -142,8 +143,18 @@ def test_jobs_trained_in_two_parts_on_two_lanes_equal_the_one_part_run(own_ctx, 
     monkeypatch.delenv("NCHMM_EM_LANES")
     two = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
     again = gpu_ctx.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+    # ... and in many parts taking turns on the two lanes: a budget of 64 MiB is 4096 events of alpha rows, 2048 per lane -- some
+    # twenty parts of five jobs, which finish at different rounds
+    monkeypatch.setenv("NCHMM_FB_BUDGET_MB", "64")
+    small = na.Context(0)
+    try:
+        many = small.train_reads(opts, states, so, mean, stdv, start, jr, j0, j1)
+        assert int(small.mem_stats()[1]) < (1 << 30)                 # (its workspaces stayed small: 16 KiB x 2 x 2048 events and change)
+    finally:
+        small.close()
+    monkeypatch.delenv("NCHMM_FB_BUDGET_MB")
     assert len(set(one["rounds"].tolist())) > 1                      # the jobs do not all stop together
-    for other in (two, again):
+    for other in (two, again, many):
         for k in ("pm", "st", "fit", "rounds", "preferred"):
             assert one[k].tobytes() == other[k].tobytes(), k
     # ... and a Viterbi launch behind it finds its lanes as they were (the second EM lane computes on Viterbi lane 1's stream)
