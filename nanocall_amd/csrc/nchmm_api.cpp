@@ -1328,7 +1328,7 @@ int em_round_range(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const ui
 {
     EmPending pend;
     int rc = em_round_enqueue(c, n_win, win_src, win_len, win_drift, win_pm, scaled_slot, trans_slot, st_params, n_jobs, job_first_win,
-                              train_drift, out_st != nullptr, &pend);
+                              train_drift, &pend);
     if (rc != NCHMM_OK) return rc;
     return em_round_collect(c, pend, out_lpd, out_st, out_acc);
 }
@@ -1364,7 +1364,7 @@ size_t em_round_pin_bytes(size_t n_win, size_t n_jobs)
 
 int em_round_enqueue(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift, const float* win_pm,
                      const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params, size_t n_jobs, const uint32_t* job_first_win,
-                     int train_drift, bool want_st, EmPending* pend)
+                     int train_drift, EmPending* pend)
 {
     const EmIn I(n_win, n_jobs);
     const EmOut O(n_win, n_jobs);
@@ -1423,7 +1423,6 @@ int em_round_enqueue(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const 
         HIP_TRY(c, hipGetLastError());
     }
     // (one copy back: the three result blocks are adjacent; a round without jobs leaves the last one unwritten and unread)
-    (void)want_st;
     HIP_TRY(c, hipMemcpyAsync(h + I.bytes, d + o_out, O.bytes, hipMemcpyDeviceToHost, s));
     pend->n_win = n_win; pend->n_jobs = n_jobs; pend->stream = (void*)s;
     pend->h_lpd = (const float*)(h + I.bytes + O.lp); pend->h_st = (const float*)(h + I.bytes + O.st); pend->h_acc = (const double*)(h + I.bytes + O.ac);

@@ -106,7 +106,7 @@ size_t em_fb_cap_events(nchmm_ctx* c);                       // events whose alp
 // One round of nchmm_em_round queued on the selected lane: inputs copied to its arena, results land there ...
 int em_round_enqueue(nchmm_ctx* c, size_t n_win, const uint64_t* win_src, const uint32_t* win_len, const float* win_drift, const float* win_pm,
                      const int32_t* scaled_slot, const int32_t* trans_slot, const float* st_params, size_t n_jobs, const uint32_t* job_first_win,
-                     int train_drift, bool want_st, EmPending* pend);
+                     int train_drift, EmPending* pend);
 // ... and copied out once the round's stream has been waited for.
 int em_round_collect(nchmm_ctx* c, const EmPending& pend, float* out_lpd, float* out_st, double* out_acc);
 }  // namespace nchmm

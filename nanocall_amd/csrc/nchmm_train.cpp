@@ -277,7 +277,7 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         P.lpd.resize(n_win); P.st_sums.resize(3 * n_win); P.acc.resize(13 * na);
         if (two)
             rc = nchmm::em_round_enqueue(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
-                                         na, P.first_win.data(), o->train_drift, true, &P.pend);
+                                         na, P.first_win.data(), o->train_drift, &P.pend);
         else
             rc = nchmm_em_round(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
                                 na, P.first_win.data(), o->train_drift, P.lpd.data(), P.st_sums.data(), P.acc.data());
