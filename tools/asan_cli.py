@@ -23,9 +23,12 @@ def one_pass(sanitizers):
     out = tempfile.mkdtemp(prefix="asan_cli_")
     exe = os.path.join(out, "nanocall")
     lib = os.path.join(ROOT, "nanocall_amd")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizers, "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"),
+    built = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizers, "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"),
                     "-I" + os.path.join(lib, "csrc"), "-pthread", os.path.join(lib, "cli", "nanocall.cpp"), "-L" + lib, "-lnanocall_hip", "-lz",
-                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+                    "-Wl,-rpath," + lib, "-o", exe], check=False, capture_output=True, text=True)
+    if built.returncode != 0:
+        sys.stderr.write(built.stderr)
+        raise SystemExit(built.returncode)
     import test_cli_workers_cpu as t
     t.CLI = exe
     os.environ.update(ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="report_signal_unsafe=0", NANOCALL_FULL_EXIT="1")
