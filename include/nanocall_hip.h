@@ -419,7 +419,9 @@ int nchmm_em_round(nchmm_ctx* ctx, size_t n_win, const uint64_t* win_src, const 
  * EM driver loop -- replaces the body of train_reads (src/nanocall/nanocall.cpp:292-574): window
  * extraction :327-338, the round loop with its stop / roll-back rules :367-426 (2D) and :483-542 (1D),
  * and threshold model selection :437-459 / :552-570 -- batched: every round, all jobs still training go
- * through ONE nchmm_fwbw launch.
+ * through one forward-backward launch, or (64 jobs and more) through one per part of the jobs, the parts
+ * taking turns on two lanes of the context so that one part's host steps run behind another's kernels;
+ * a job's rounds and results do not depend on the arrangement (NCHMM_EM_LANES=1: always one part).
  *
  * A job is one iteration of the reference's model loops: (read, m0, m1) with both >= 0 when the read's
  * strands are scaled together, or (read, m, -1) / (read, -1, m) for a single strand.  Reads are given as
@@ -429,7 +431,8 @@ int nchmm_em_round(nchmm_ctx* ctx, size_t n_win, const uint64_t* win_src, const 
  * hold the initial parameters on entry (Fast5_Summary's pm_params_m / st_params_m) and the trained ones on
  * return; job_fit / job_rounds receive the final fit and round count.  read_preferred (may be NULL),
  * n_reads x 3: the job selected for strand 0, strand 1 and the 2D pair (preferred_model), or -1.
- * Uses model slots [0, n_models + 2*jobs) and transition slots [0, 1 + 2*jobs) of the context. */
+ * Uses model slots [0, n_models + 2*jobs) and transition slots [0, 1 + 2*jobs) of the context at most (in parts:
+ * four per job of the largest part), and its internal streams: nothing else may be queued on the context meanwhile. */
 typedef struct nchmm_train_opts {
     uint32_t scaling_num_events;       /* --scaling-num-events      200  nanocall.cpp:72 */
     uint32_t scaling_max_rounds;       /* --scaling-max-rounds       10  :71 (2D jobs run up to twice this, :420) */
