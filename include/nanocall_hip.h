@@ -432,7 +432,8 @@ int nchmm_em_round(nchmm_ctx* ctx, size_t n_win, const uint64_t* win_src, const 
  * return; job_fit / job_rounds receive the final fit and round count.  read_preferred (may be NULL),
  * n_reads x 3: the job selected for strand 0, strand 1 and the 2D pair (preferred_model), or -1.
  * Uses model slots [0, n_models + 2*jobs) and transition slots [0, 1 + 2*jobs) of the context at most (in parts:
- * four per job of the largest part), and its internal streams: nothing else may be queued on the context meanwhile. */
+ * four per job of the largest part); its second lane computes on the stream of Viterbi lane 1 (a batch queued with
+ * nchmm_viterbi_dev_enqueue before the call runs first; the call itself returns with nothing of its own in flight). */
 typedef struct nchmm_train_opts {
     uint32_t scaling_num_events;       /* --scaling-num-events      200  nanocall.cpp:72 */
     uint32_t scaling_max_rounds;       /* --scaling-max-rounds       10  :71 (2D jobs run up to twice this, :420) */
