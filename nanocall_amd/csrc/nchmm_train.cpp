@@ -268,20 +268,20 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             }
         }
         const auto t_1 = now();
-        int rc;
+        int qrc;
         if (two) { nchmm::em_lane_select(ctx, lane); nchmm::em_lane_rewind(ctx); }
-        if ((rc = nchmm_put_models_scaled(ctx, (int)(n_models + slot0), 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return rc;
-        if ((rc = nchmm_put_transitions_fast(ctx, (int)(1 + slot0), 2 * na, t_skip.data(), t_stay.data()))) return rc;
+        if ((qrc = nchmm_put_models_scaled(ctx, (int)(n_models + slot0), 2 * na, model_states_Sx10, m_idx.data(), m_par.data()))) return qrc;
+        if ((qrc = nchmm_put_transitions_fast(ctx, (int)(1 + slot0), 2 * na, t_skip.data(), t_stay.data()))) return qrc;
         const auto t_2 = now();
         // forward-backward, inner and outer sums on the device: 13 doubles per job come back
         P.lpd.resize(n_win); P.st_sums.resize(3 * n_win); P.acc.resize(13 * na);
         if (two)
-            rc = nchmm::em_round_enqueue(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
+            qrc = nchmm::em_round_enqueue(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
                                          na, P.first_win.data(), o->train_drift, &P.pend);
         else
-            rc = nchmm_em_round(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
+            qrc = nchmm_em_round(ctx, n_win, w_src.data(), w_len.data(), w_drift.data(), w_pm.data(), s_slot.data(), t_slot.data(), stp.data(),
                                 na, P.first_win.data(), o->train_drift, P.lpd.data(), P.st_sums.data(), P.acc.data());
-        if (rc != NCHMM_OK) return rc;
+        if (qrc != NCHMM_OK) return qrc;
         P.in_flight = true;
         P.t_prep = ms(t_0, t_1); P.t_tables = ms(t_1, t_2); P.t_queue = ms(t_2, now());
         return NCHMM_OK;
@@ -292,8 +292,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
         const auto t_0 = now();
         if (two) {
             nchmm::em_lane_select(ctx, lane);
-            const int rc = nchmm::em_round_collect(ctx, P.pend, P.lpd.data(), P.st_sums.data(), P.acc.data());
-            if (rc != NCHMM_OK) return rc;
+            const int crc = nchmm::em_round_collect(ctx, P.pend, P.lpd.data(), P.st_sums.data(), P.acc.data());
+            if (crc != NCHMM_OK) return crc;
         }
         P.in_flight = false;
         const auto t_1 = now();
@@ -310,8 +310,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
             bool done = false;
             if (o->train_scaling) {
                 int d = 0;
-                const int rc = nchmm_train_pm_solve(P.job_events[p], &acc[13 * p], o->train_drift, j.old_pm, j.pm, &d);
-                if (rc != NCHMM_OK) { first_err = rc; return; }
+                const int src = nchmm_train_pm_solve(P.job_events[p], &acc[13 * p], o->train_drift, j.old_pm, j.pm, &d);
+                if (src != NCHMM_OK) { first_err = src; return; }
                 done = d != 0;
             }
             if (done) {
@@ -322,8 +322,8 @@ int nchmm_train_reads(nchmm_ctx* ctx, const nchmm_train_opts* o, size_t n_models
                     std::vector<float> mine;
                     for (size_t w = w0; w < w1; ++w)
                         if (j.win[w - w0].strand == (uint32_t)s) mine.insert(mine.end(), &st_sums[3 * w], &st_sums[3 * w] + 3);
-                    const int rc = nchmm_train_st_finish(mine.size() / 3, mine.data(), &j.st[2 * s], &j.st[2 * s + 1]);
-                    if (rc != NCHMM_OK) { first_err = rc; return; }
+                    const int frc = nchmm_train_st_finish(mine.size() / 3, mine.data(), &j.st[2 * s], &j.st[2 * s + 1]);
+                    if (frc != NCHMM_OK) { first_err = frc; return; }
                 }
             }
             // nanocall.cpp:394-426 (2D) / :510-542 (1D)
