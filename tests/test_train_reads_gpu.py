@@ -275,3 +275,19 @@ def test_pool_over_two_distinct_devices_uses_rccl_for_the_counters(gpu_ctx):
     assert np.array_equal(two["states"], one["states"])
     assert two["best_job"].tolist() == one["best_job"].tolist()
     assert two["best_logp"].tobytes() == one["best_logp"].tobytes()
+
+
+def test_short_soak_of_parts_lanes_and_decodes_on_one_context():
+    """tools/soak_em_lanes.py, a short run: training calls in one part and in parts on the two lanes under budgets from 48 MiB to
+    16 GiB, decodes of a ragged batch between them and device-resident decodes queued across them -- no difference anywhere
+    (profiles/r06_soak_em_lanes.json is the long run)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_em_lanes.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ITER="17", POOL="300"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["iterations"] == 17 and d["differences"] == 0 and d["async_decodes"] >= 5 and len(d["parts_budgets_mb"]) == 3
