@@ -1485,6 +1485,9 @@ static int fan_out(const Pore_Model_Dict_Type& models, const std::list<std::stri
     const char* force = std::getenv("NCHMM_POOL_FORCE_RCCL");
     const bool use_rccl = distinct && (W > 1 || (force && force[0] == '1'));
     const unsigned threads_each = std::max(1u, (opts::num_threads.get() + (unsigned)W - 1) / (unsigned)W);
+    // (RCCL across processes exchanges memory handles; a host driver that only exports dmabuf handles needs this set, as bench.py's
+    // launcher does -- a value the user gave stands; if the communicator cannot be formed the counters are summed on the host)
+    if (use_rccl) setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
 
     std::vector<std::unique_ptr<Worker_Stream>> ws;
     for (int k = 0; k < W; ++k) {
